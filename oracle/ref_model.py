@@ -1,0 +1,297 @@
+"""TEST INFRASTRUCTURE ONLY -- fp32 CPU restatement of SafeVLA's three-tower actor-critic.
+
+Restates (paths relative to /root/reference):
+  * ``PositionalEncoder``            architecture/models/transformer_models/text_cond_visual_encoder.py:263-283
+  * llama decoder                    training/online/third_party_models/llama/model.py:28-71,170-467
+  * ``DinoTxGoalEncoder``            architecture/models/allenact_transformer_models/allenact_dino_transformer.py:478-717
+  * ``DinoLLAMATxNavActorCritic``    .../allenact_dino_transformer.py:47-475
+  * three-tower wrapper              .../separate_actor_critic.py:8-37
+  * actor / critic heads [3P AllenAct ``LinearActorHead``/``LinearCriticHead``]: Linear(512,20) -> logits,
+    Linear(512,1) -> (T,B,1)
+
+PINNED: tests/test_oracle_golden.py checks this file against outputs of the reference itself
+(tests/golden/*.npz, produced by tests/golden/make_golden.py in the build container).
+Parameter / buffer names equal the reference's ``state_dict``.
+"""
+import math
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .ref_t5 import RefT5Encoder
+
+N_ACTIONS = 20
+
+
+def bytes_to_str(row: np.ndarray) -> str:
+    """utils/string_utils.py:15-18 -- zero-padded S<max_len> bytes -> str."""
+    return bytes(row.astype(np.uint8)).split(b"\x00", 1)[0].decode()
+
+
+class RefPositionalEncoder(nn.Module):
+    def __init__(self, d_model: int):
+        super().__init__()
+        self.d_model = d_model
+        self.register_buffer("div_term", torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model)))
+
+    def forward(self, position):  # (A,B) int -> (A,B,d)
+        ang = position.unsqueeze(-1) * self.div_term
+        pe = torch.zeros(*position.shape, self.d_model)
+        pe[..., 0::2] = torch.sin(ang)
+        pe[..., 1::2] = torch.cos(ang)
+        return pe
+
+
+# ----------------------------------------------------------------------------- llama decoder
+class RefRMSNorm(nn.Module):
+    def __init__(self, dim, eps):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+    def forward(self, x):
+        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.eps) * self.weight
+
+
+class RefLlamaAttention(nn.Module):
+    def __init__(self, dim, n_heads, max_batch, max_seq):
+        super().__init__()
+        self.h, self.hd = n_heads, dim // n_heads
+        self.wq = nn.Linear(dim, dim, bias=False)
+        self.wk = nn.Linear(dim, dim, bias=False)
+        self.wv = nn.Linear(dim, dim, bias=False)
+        self.wo = nn.Linear(dim, dim, bias=False)
+        self.cache_k = torch.zeros(max_batch, max_seq, n_heads, self.hd)
+        self.cache_v = torch.zeros(max_batch, max_seq, n_heads, self.hd)
+
+    def forward(self, x, start_pos, mask):  # x (B,T,d); mask bool (B,1,T,S) True = attend
+        B, T, _ = x.shape
+        q = self.wq(x).view(B, T, self.h, self.hd)
+        k = self.wk(x).view(B, T, self.h, self.hd)
+        v = self.wv(x).view(B, T, self.h, self.hd)
+        if T == 1:  # KV-cache path, llama/model.py:279-293
+            self.cache_k[:B, start_pos : start_pos + 1] = k.detach()
+            self.cache_v[:B, start_pos : start_pos + 1] = v.detach()
+            k = self.cache_k[:B, : start_pos + 1]
+            v = self.cache_v[:B, : start_pos + 1]
+        q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
+        s = (q @ k.transpose(-1, -2)) / math.sqrt(self.hd)
+        if mask is not None:
+            s = s.masked_fill(~mask, float("-inf"))
+        o = F.softmax(s, dim=-1) @ v
+        return self.wo(o.transpose(1, 2).reshape(B, T, -1))
+
+
+class RefLlamaFFN(nn.Module):
+    def __init__(self, dim, multiple_of=256):
+        super().__init__()
+        hidden = int(2 * (4 * dim) / 3)
+        hidden = multiple_of * ((hidden + multiple_of - 1) // multiple_of)  # 1536 for dim 512
+        self.w1 = nn.Linear(dim, hidden, bias=False)
+        self.w2 = nn.Linear(hidden, dim, bias=False)
+        self.w3 = nn.Linear(dim, hidden, bias=False)
+
+    def forward(self, x):
+        return self.w2(F.silu(self.w1(x)) * self.w3(x))
+
+
+class RefLlamaBlock(nn.Module):
+    def __init__(self, dim, n_heads, eps, max_batch, max_seq):
+        super().__init__()
+        self.attention = RefLlamaAttention(dim, n_heads, max_batch, max_seq)
+        self.feed_forward = RefLlamaFFN(dim)
+        self.attention_norm = RefRMSNorm(dim, eps)
+        self.ffn_norm = RefRMSNorm(dim, eps)
+
+    def forward(self, x, start_pos, mask):
+        h = x + self.attention(self.attention_norm(x), start_pos, mask)
+        return h + self.feed_forward(self.ffn_norm(h))
+
+
+class RefLlamaDecoder(nn.Module):
+    def __init__(self, dim=512, n_layers=3, n_heads=8, eps=1e-5, max_batch=32, max_seq=500):
+        super().__init__()
+        self.layers = nn.ModuleList([RefLlamaBlock(dim, n_heads, eps, max_batch, max_seq) for _ in range(n_layers)])
+        self.norm = RefRMSNorm(dim, eps)
+        self.output = nn.Linear(dim, dim, bias=False)
+
+    def forward(self, x, start_pos, mask):
+        for l in self.layers:
+            x = l(x, start_pos, mask)
+        return self.output(self.norm(x)).float()
+
+
+# ----------------------------------------------------------------------------- fusion encoder
+class _MHAParams(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = nn.Linear(d, d)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+
+
+class RefFusionLayer(nn.Module):
+    """``nn.TransformerEncoderLayer(d,h,batch_first=True)`` defaults: post-LN, ReLU, ff 2048, eps 1e-5."""
+
+    def __init__(self, d=512, h=8, ff=2048, p=0.0):
+        super().__init__()
+        self.self_attn = _MHAParams(d)
+        self.linear1 = nn.Linear(d, ff)
+        self.linear2 = nn.Linear(ff, d)
+        self.norm1 = nn.LayerNorm(d, eps=1e-5)
+        self.norm2 = nn.LayerNorm(d, eps=1e-5)
+        self.h, self.p = h, p
+
+    def forward(self, x):  # (R,S,d); no masks of any kind (allenact_dino_transformer.py:702-708)
+        R, S, d = x.shape
+        hd = d // self.h
+        qkv = F.linear(x, self.self_attn.in_proj_weight, self.self_attn.in_proj_bias)
+        q, k, v = qkv.split(d, dim=-1)
+        q = q.view(R, S, self.h, hd).transpose(1, 2)
+        k = k.view(R, S, self.h, hd).transpose(1, 2)
+        v = v.view(R, S, self.h, hd).transpose(1, 2)
+        pr = F.dropout(F.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), dim=-1), self.p, self.training)
+        a = self.self_attn.out_proj((pr @ v).transpose(1, 2).reshape(R, S, d))
+        x = self.norm1(x + F.dropout(a, self.p, self.training))
+        f = self.linear2(F.dropout(F.relu(self.linear1(x)), self.p, self.training))
+        return self.norm2(x + F.dropout(f, self.p, self.training))
+
+
+class _Layers(nn.Module):
+    def __init__(self, n, d, h, p):
+        super().__init__()
+        self.layers = nn.ModuleList([RefFusionLayer(d, h, 2048, p) for _ in range(n)])
+
+    def forward(self, x):
+        for l in self.layers:
+            x = l(x)
+        return x
+
+
+class RefGoalEncoder(nn.Module):
+    def __init__(self, tokenizer: Callable, d=512, dino_dim=384, n_layers=3, n_heads=8, dropout=0.0,
+                 goal_uuid="natural_language_spec", nav_uuid="rgb_dinov2", manip_uuid="manipulation_rgb_dinov2"):
+        super().__init__()
+        self.goal_uuid, self.nav_uuid, self.manip_uuid = goal_uuid, nav_uuid, manip_uuid
+        self.tokenizer = tokenizer
+        self.text_encoder = RefT5Encoder()
+        for p in self.text_encoder.parameters():
+            p.requires_grad_(True)  # the reference leaves requires_grad on; it is frozen only by no_grad
+        self.text_adapter = nn.Sequential(nn.Linear(512, d), nn.LayerNorm(d), nn.ReLU())
+        self.fusion_token = nn.Parameter(0.1 * torch.rand(d))
+        self.visual_sensor_token_raw_navigation_camera = nn.Parameter(0.1 * torch.rand(d))
+        self.visual_sensor_token_raw_manipulation_camera = nn.Parameter(0.1 * torch.rand(d))
+        self.visual_compressor = nn.Sequential(nn.Conv2d(dino_dim, d, 1), nn.ReLU(), nn.Conv2d(d, d, 1), nn.ReLU())
+        self.visual_adapter = nn.Sequential(nn.Linear(d, d), nn.LayerNorm(d), nn.ReLU())
+        self.fusion_xformer = _Layers(n_layers, d, n_heads, dropout)
+
+    def tokenize(self, goal_bytes: torch.Tensor):
+        """distribute_target's host half (:591-603): bytes -> strings -> ids padded to the batch max."""
+        rows = goal_bytes.cpu().numpy().astype(np.uint8)
+        enc = self.tokenizer([bytes_to_str(r) for r in rows], return_tensors="pt", padding=True)
+        return enc["input_ids"], enc["attention_mask"]
+
+    def text_features(self, goal_bytes):
+        ids, am = self.tokenize(goal_bytes)
+        with torch.no_grad():
+            emb = self.text_encoder(ids, am)
+        return self.text_adapter(emb)
+
+    def _camera(self, feat, token):  # (R,384,7,12) channels-first -> (R,84,512), row-major over the 7x12 grid
+        t = self.visual_compressor(feat).flatten(start_dim=2).permute(0, 2, 1)
+        return self.visual_adapter(t) + token
+
+    def forward(self, obs: Dict[str, torch.Tensor]):
+        nav = obs[self.nav_uuid]
+        T, B = nav.shape[:2]
+        R = T * B
+        parts = [
+            self.fusion_token.view(1, 1, -1).expand(R, -1, -1),
+            self._camera(nav.reshape(R, *nav.shape[-3:]), self.visual_sensor_token_raw_navigation_camera),
+            self._camera(obs[self.manip_uuid].reshape(R, *nav.shape[-3:]), self.visual_sensor_token_raw_manipulation_camera),
+        ]
+        text = self.text_features(obs[self.goal_uuid].reshape(R, -1))
+        parts.append(text)
+        x = self.fusion_xformer(torch.cat(parts, dim=1))[:, 0]
+        return x.view(T, B, -1), text.mean(dim=1).view(T, B, -1)
+
+
+class _ActorHead(nn.Module):
+    def __init__(self, d, n):
+        super().__init__()
+        self.linear = nn.Linear(d, n)
+        nn.init.orthogonal_(self.linear.weight, gain=0.01)
+        nn.init.constant_(self.linear.bias, 0)
+
+    def forward(self, x):
+        return self.linear(x)
+
+
+class _CriticHead(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.fc = nn.Linear(d, 1)
+        nn.init.orthogonal_(self.fc.weight)
+        nn.init.constant_(self.fc.bias, 0)
+
+    def forward(self, x):
+        return self.fc(x).view(*x.shape[:2], -1)
+
+
+class RefTower(nn.Module):
+    """One ``DinoLLAMATxNavActorCritic`` (full-sensor configuration, dinov2_vits_tsfm_base.py:234-270)."""
+
+    def __init__(self, tokenizer, max_steps=500, max_batch=32, dropout=0.0):
+        super().__init__()
+        d = 512
+        self.max_steps = max_steps
+        self.time_step_counter = 0
+        self.visual_encoder = RefGoalEncoder(tokenizer, dropout=dropout)
+        self.object_in_hand_embed = nn.Embedding(3, d)
+        self.object_in_hand_embed.weight.data.uniform_(-0.01, 0.01)
+        self.last_actions_embed = nn.Embedding(N_ACTIONS + 2, d, padding_idx=N_ACTIONS + 1)
+        self.last_actions_embed.weight.data.uniform_(-0.01, 0.01)
+        self.time_encoder = RefPositionalEncoder(d)
+        self.decoder = RefLlamaDecoder(d, 3, 8, 1e-5, max_batch, max_steps)
+        self.actor = _ActorHead(d, N_ACTIONS)
+        self.critic = _CriticHead(d)
+
+    def tower_forward(self, obs, prev_actions, masks):
+        obs_embeds, _ = self.visual_encoder(obs)
+        T, B = prev_actions.shape
+        pa = torch.where(masks.view(T, B) != 0, prev_actions, torch.full_like(prev_actions, N_ACTIONS))
+        joint = obs_embeds + self.last_actions_embed(pa) + self.object_in_hand_embed(obs["an_object_is_in_hand"].squeeze(2))
+        if T > 1 or self.time_step_counter >= self.max_steps:
+            self.time_step_counter = 0
+        joint = self.time_encoder(obs["time_step"]) + joint
+        x = joint.permute(1, 0, 2)
+        if T == 1:  # acting: episode-start window over the KV cache (:388-397)
+            ts = obs["time_step"].permute(1, 0)
+            start = torch.clamp(self.time_step_counter - ts, min=0)
+            mask = (start <= torch.arange(self.time_step_counter + 1)[None, :])[:, None, None, :]
+        else:  # update: same trajectory AND causal (:398-402)
+            tr = obs["traj_index"].permute(1, 0)
+            mask = torch.tril(tr[:, :, None] == tr[:, None, :])[:, None]
+        beliefs = self.decoder(x, self.time_step_counter, mask).permute(1, 0, 2)
+        if T == 1:
+            self.time_step_counter += 1
+        return self.actor(beliefs), self.critic(beliefs), beliefs
+
+
+class RefSafeActorCritic(RefTower):
+    """``SafeDinoLLAMATxNavActorCriticSeparate``: actor tower = self, plus critic_tsfm, c_critic_tsfm."""
+
+    def __init__(self, tokenizer, max_steps=500, max_batch=32, dropout=0.0):
+        super().__init__(tokenizer, max_steps, max_batch, dropout)
+        self.critic_tsfm = RefTower(tokenizer, max_steps, max_batch, dropout)
+        self.c_critic_tsfm = RefTower(tokenizer, max_steps, max_batch, dropout)
+
+    def forward(self, observations, memory, prev_actions, masks):
+        logits, _, _ = self.tower_forward(observations, prev_actions, masks)
+        _, values, _ = self.critic_tsfm.tower_forward(observations, prev_actions, masks)
+        _, c_values, _ = self.c_critic_tsfm.tower_forward(observations, prev_actions, masks)
+        return {"logits": logits, "values": values, "c_values": c_values}, memory

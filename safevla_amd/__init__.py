@@ -1,0 +1,12 @@
+"""safevla_amd -- MI355X-native PPO-Lagrangian update path for SafeVLA's actor-critic.
+
+Only the hot path named by BASELINE.json's ``north_star`` lives here:
+  csrc/      hand-written gfx950 HIP kernels behind a C ABI (include/svla.h)
+  _lib.py    ctypes loader for the C-ABI shared library (fails loudly if it is missing)
+  ops.py     stream-aware Python bindings + autograd glue
+  model.py   host mirror of the reference's ActorCriticModel.forward API
+  losses.py  SafePPOLogGrad / PPOValue / SafePPOValue / HLGaussLoss mirrors
+  storage.py rollout storage with reward+cost GAE
+  engine.py  the PPO-Lagrangian update loop (single- and multi-GPU)
+"""
+__version__ = "0.1.0"

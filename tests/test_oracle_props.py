@@ -1,0 +1,55 @@
+"""Oracle pieces whose arithmetic is NOT in /root/reference (parity unpinned): property tests + the T5 pin."""
+import numpy as np
+import torch
+
+from oracle import ref_rollout
+from oracle.detfill import fill_state_dict
+from oracle.ref_t5 import RefT5Encoder
+
+
+def test_t5_restatement_matches_hf():
+    from transformers import T5Config, T5EncoderModel
+
+    cfg = T5Config(vocab_size=32128, d_model=512, d_kv=64, d_ff=2048, num_layers=6, num_heads=8, feed_forward_proj="relu")
+    hf = T5EncoderModel(cfg).eval()
+    fill_state_dict(hf, seed=3)
+    mine = RefT5Encoder().eval()
+    missing = mine.load_state_dict(hf.state_dict(), strict=True)
+    rs = np.random.RandomState(0)
+    ids = torch.from_numpy(rs.randint(3, 32000, size=(5, 11)))
+    am = torch.ones(5, 11, dtype=torch.int64)
+    for i, n in enumerate([11, 4, 7, 1, 9]):
+        ids[i, n:] = 0
+        am[i, n:] = 0
+    with torch.no_grad():
+        want = hf(input_ids=ids, attention_mask=am).last_hidden_state
+    got = mine(ids, am)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_gae_scan_equals_definition():
+    rs = np.random.RandomState(0)
+    T, B = 37, 5
+    r = torch.from_numpy(rs.standard_normal((T, B, 1)).astype(np.float32))
+    v = torch.from_numpy(rs.standard_normal((T, B, 1)).astype(np.float32))
+    m = torch.from_numpy((rs.rand(T + 1, B, 1) > 0.15).astype(np.float32))
+    nv = torch.from_numpy(rs.standard_normal((B, 1)).astype(np.float32))
+    ret, adv = ref_rollout.gae_scan(r, v, m, nv)
+    ret2, adv2 = ref_rollout.gae_definition(r, v, m, nv)
+    np.testing.assert_allclose(ret.numpy(), ret2.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(adv.numpy(), adv2.numpy(), rtol=1e-5, atol=1e-5)
+    # episode boundary: nothing after a done leaks backwards
+    m[10] = 0.0
+    r2 = r.clone()
+    r2[10:] += 100.0
+    _, a = ref_rollout.gae_scan(r, v, m, nv)
+    _, b = ref_rollout.gae_scan(r2, v, m, nv)
+    np.testing.assert_allclose(a[:10].numpy(), b[:10].numpy(), rtol=0, atol=0)
+
+
+def test_lagrange_monotone_and_clamped():
+    lag = ref_rollout.RefLagrange(cost_limit=2.0, init=0.001, lr=0.035)
+    up = [lag.update(5.0) for _ in range(5)]
+    assert all(b > a for a, b in zip(up, up[1:]))
+    down = [lag.update(0.0) for _ in range(400)]
+    assert down[-1] == 0.0 and min(down) >= 0.0
