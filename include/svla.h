@@ -1,0 +1,121 @@
+/* svla.h -- C ABI of the MI355X (gfx950) PPO-Lagrangian hot path for SafeVLA's actor-critic.
+ *
+ * Boundary contract: plain C entry points, device pointers + sizes + a HIP stream
+ * (void* = hipStream_t), return 0 on success, a hipError_t (>0) on launch failure, -1 on invalid arguments.
+ * No exceptions cross the boundary; the caller owns every buffer; kernels are re-entrant (one stream per call).
+ * bf16 tensors are passed as raw uint16 bits.  The reference has NO native/FFI layer of its own (it is pure
+ * Python on top of PyTorch ops), so each entry point below cites the reference *Python* code whose arithmetic it
+ * replaces (paths relative to /root/reference).  The reference-side binding a maintainer would add is the ctypes
+ * stub in INTEGRATION.md (shipped here as safevla_amd/_lib.py).
+ */
+#ifndef SVLA_H
+#define SVLA_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t svla_bf16;
+
+/* ---- rollout statistics ------------------------------------------------------------------------------ */
+/* Reward + cost GAE reverse scan.  Replaces AllenAct-fork RolloutStorage.compute_returns(use_gae=True) [3P];
+ * hyper-parameters at training/online/dinov2_vits_tsfm_base.py:345-347; arrays are [T,B] (masks [T+1,B]). */
+int svla_gae_scan_f32(const float* rewards, const float* costs, const float* values, const float* c_values,
+                      const float* masks, const float* next_v, const float* next_cv, double gamma, double tau, int T, int B,
+                      float* ret, float* adv, float* c_ret, float* c_adv, void* stream);
+
+/* ---- losses ---------------------------------------------------------------------------------------------- */
+/* SafePPOLogGrad.loss_per_step + loss, forward and backward fused
+ * (training/online/loss/customized_loss.py:317-449).  sums[0..2] += {sum (ret-v)^2 (or clipped max), sum action_loss,
+ * sum -entropy}; dlogits/dvalues = d total / d(logits, values) with means taken as sum * inv_n. */
+int svla_ppo_lag_loss_fwd_bwd_f32(const float* logits, const float* values, const int64_t* actions, const float* old_logp,
+                                  const float* adv, const float* c_adv, const float* returns, const float* old_values,
+                                  int rows, int A, float lam, float clip, float value_coef, float action_w, float ent_coef,
+                                  int use_clipped_value, float inv_n, float* dlogits, float* dvalues, double* sums,
+                                  void* stream);
+/* PPOValue / SafePPOValue [3P AllenAct fork]; call sites training/online/dinov2_vits_tsfm_base.py:337-342. */
+int svla_value_mse_fwd_bwd_f32(const float* values, const float* returns, int rows, float coef, float inv_n, float* dvalues,
+                               double* sums, void* stream);
+
+/* ---- heads ------------------------------------------------------------------------------------------------ */
+/* LinearActorHead / LinearCriticHead [3P AllenAct] applied at
+ * architecture/models/allenact_transformer_models/allenact_dino_transformer.py:441-474.  D must be 512, N <= 20.
+ * T > 0: x rows are (b*T + t) (decoder layout), out rows are (t*B + b). */
+int svla_small_linear_fwd_f32(const float* x, const float* W, const float* bias, int rows, int N, int D, int T, int B,
+                              float* out, void* stream);
+int svla_small_linear_bwd_f32(const float* x, const float* W, const float* dout, int rows, int N, int D, int T, int B,
+                              int accumulate_dx, float* dx, float* dW, float* db, void* stream);
+
+/* ---- normalisation ---------------------------------------------------------------------------------------- */
+/* LayerNorm (rms=0) / RMSNorm (rms=1) rows of width D (512; forward also 384).  Row maps (G,GS,OFF): logical row m is
+ * memory row (m/G)*GS + OFF + m%G (G = 0: identity).  Optional fused ReLU and per-group token add: the
+ * "Linear -> LayerNorm -> ReLU (+ camera token)" adapters (allenact_dino_transformer.py:509-513,539-543,672-688);
+ * nn.TransformerEncoderLayer norm1/norm2 (:545-552); llama RMSNorm (training/online/third_party_models/llama/model.py:28-71). */
+int svla_norm_fwd_bf16(const svla_bf16* x, int xG, int xGS, int xOFF, const float* gamma, const float* beta, float eps, int rows,
+                       int D, int rms, int relu, const float* tok, int tok_group, svla_bf16* y, int yG, int yGS, int yOFF,
+                       float* mean, float* rstd, void* stream);
+int svla_norm_bwd_bf16(const svla_bf16* dy, int dyG, int dyGS, int dyOFF, const svla_bf16* x, int xG, int xGS, int xOFF,
+                       const float* gamma, const float* beta, const float* mean, const float* rstd, int rows, int D, int rms,
+                       int relu, int tok_group, svla_bf16* dx, int dxG, int dxGS, int dxOFF, float* dgamma, float* dbeta,
+                       float* dtok, void* stream);
+
+/* ---- GEMMs (MFMA bf16, fp32 accumulate) --------------------------------------------------------------------- */
+/* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear / 1x1 nn.Conv2d of the policy
+ * (allenact_dino_transformer.py:509-552; llama/model.py:203-222,355-357,437) and, with transposed weights, their input
+ * gradients.  act: 0 none, 1 ReLU, 2 GELU(erf).  relu_mask: zero outputs where mask <= 0.  N % 128 == 0, K % 64 == 0. */
+int svla_gemm_nt_bf16(const svla_bf16* A, long lda, const svla_bf16* B, long ldb, const float* bias, const svla_bf16* residual,
+                      long ldr, const svla_bf16* relu_mask, long ldm, void* C, long ldc, int M, int N, int K, int act,
+                      int out_f32, float alpha, void* stream);
+/* dW[N,K] (fp32) += dY[M,N]^T . X[M,K]: weight gradients (autograd of the same layers).  N,K % 128 == 0. */
+int svla_gemm_tn_f32acc(const svla_bf16* dY, long ldy, const svla_bf16* X, long ldx, float* dW, long ldw, int M, int N, int K,
+                        void* stream);
+/* db[N] += sum_m dY[m*row_stride, :] (bias gradients; row_stride > 1 picks one token of every [S, D] group). */
+int svla_colsum_bf16(const svla_bf16* dY, long ldy, int M, int N, int row_stride, float* db, void* stream);
+
+/* ---- attention ---------------------------------------------------------------------------------------------- */
+/* softmax(scale * Q K^T [+ bias] [mask]) V per (row, head), head_dim 64, tokens of one row contiguous (row*S + s).
+ * mask_mode 0: none (nn.MultiheadAttention in the fusion encoder, allenact_dino_transformer.py:545-552,702-708);
+ * 1: block-causal on traj ids (allenact_dino_transformer.py:398-402 + llama/model.py:317-319).
+ * bias [H,S,S] + kvalid [rows,S]: T5 self-attention.  LSE [rows,H,S] is saved for the backward. */
+int svla_attn_fwd_bf16(const svla_bf16* Q, const svla_bf16* K, const svla_bf16* V, long ld, svla_bf16* O, long ldo, float* LSE,
+                       int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj, const float* bias,
+                       const unsigned char* kvalid, void* stream);
+int svla_attn_bwd_bf16(const svla_bf16* Q, const svla_bf16* K, const svla_bf16* V, long ld, const svla_bf16* O, long ldo,
+                       const float* LSE, const svla_bf16* dO, long lddo, svla_bf16* dQ, svla_bf16* dK, svla_bf16* dV, long ldd,
+                       int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj, const float* bias,
+                       const unsigned char* kvalid, void* stream);
+
+/* ---- observation / embedding glue ---------------------------------------------------------------------------- */
+/* (R,C,7,12) fp32 channels-first DINO features -> bf16 tokens [R, ncam, P, C] (input layout of the 1x1-conv compressor,
+ * allenact_dino_transformer.py:663-667; tensor layout per architecture/allenact_preprocessors/dino_preprocessors.py:31-35). */
+int svla_feat_to_tokens(const float* feat, int R, int C, int P, int cam, int ncam, svla_bf16* out, void* stream);
+/* fusion token + text tokens of the fusion input (allenact_dino_transformer.py:672-692) and the text gradient. */
+int svla_fusion_fill(const float* fusion_token, const svla_bf16* text, const int* gid, int R, int S, int L, int text_off,
+                     svla_bf16* x0, void* stream);
+int svla_fusion_text_bwd(const svla_bf16* dx0, const int* gid, int T, int B, int S, int L, int text_off, float* dtext,
+                         void* stream);
+/* prev-action (null token where masks == 0) + in-hand embeddings + sinusoidal time encoding
+ * (allenact_dino_transformer.py:353-385; architecture/models/transformer_models/text_cond_visual_encoder.py:263-283). */
+int svla_decoder_embed_fwd(const svla_bf16* xf, long xf_row_stride, const float* act_tab, const float* hand_tab,
+                           const float* div_term, const int64_t* prev_actions, const float* masks, const int64_t* hand,
+                           const int64_t* time_step, int T, int B, int n_actions, svla_bf16* out, void* stream);
+int svla_decoder_embed_bwd(const svla_bf16* dout, const int64_t* prev_actions, const float* masks, const int64_t* hand, int T,
+                           int B, int n_actions, svla_bf16* dxf, long dxf_row_stride, float* d_act_tab, float* d_hand_tab,
+                           void* stream);
+/* llama FeedForward gate silu(a)*b (llama/model.py:359-360) on [a | b] rows. */
+int svla_swiglu_fwd(const svla_bf16* ab, long M, int Hd, svla_bf16* g, void* stream);
+int svla_swiglu_bwd(const svla_bf16* ab, const svla_bf16* dg, long M, int Hd, svla_bf16* dab, void* stream);
+/* T5 shared-embedding gather (HF T5EncoderModel called at allenact_dino_transformer.py:603). */
+int svla_embed_gather_f32_bf16(const float* table, const int64_t* ids, long n, int D, svla_bf16* out, void* stream);
+
+/* ---- optimiser (Adam lr 2e-5, max_grad_norm 0.5: training/online/dinov2_vits_tsfm_base.py:331-334) ------------- */
+int svla_sumsq_f32(const float* g, long n, double* out, void* stream);
+int svla_adam_step_f32(float* p, const float* g, float* m, float* v, svla_bf16* p_bf16, long n, float lr, float beta1,
+                       float beta2, float eps, int step, const double* gnorm_sq, float max_norm, float grad_scale, void* stream);
+int svla_cast_f32_bf16(const float* src, svla_bf16* dst, long n, void* stream);
+int svla_transpose_cast_f32_bf16(const float* src, int rows, int cols, svla_bf16* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVLA_H */

@@ -1,0 +1,69 @@
+"""ctypes binding of the C-ABI shared library (include/svla.h is the single source of truth).
+
+The product path has NO fallback: if ``libsvla_hip.so`` is missing or an entry point returns non-zero, this raises.
+"""
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsvla_hip.so")
+HEADER = os.path.join(HERE, "..", "include", "svla.h")
+
+_CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double}
+
+
+def parse_header(path: str = HEADER) -> Dict[str, List[Tuple[str, object]]]:
+    """{symbol: [(arg_name, ctype), ...]} for every ``int svla_*(...)`` declaration."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\bint\s+(svla_\w+)\s*\((.*?)\)\s*;", src, flags=re.S):
+        args = []
+        for a in m.group(2).split(","):
+            a = " ".join(a.split())
+            name = re.findall(r"(\w+)$", a)[0]
+            ty = a[: -len(name)].strip()
+            if "*" in ty:
+                ct = ctypes.c_void_p
+            else:
+                base = ty.replace("const", "").strip()
+                ct = _CT[base]
+            args.append((name, ct))
+        out[m.group(1)] = args
+    return out
+
+
+class SvlaError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise SvlaError(
+                f"{LIB_PATH} not found: the HIP extension is required (no CPU / eager fallback). "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `python safevla_amd/build.py`."
+            )
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        self.decls = parse_header()
+        for name, args in self.decls.items():
+            fn = getattr(self.cdll, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ct for _, ct in args]
+
+    def call(self, name: str, *args):
+        rc = getattr(self.cdll, name)(*args)
+        if rc != 0:
+            raise SvlaError(f"{name} failed with status {rc}" + (" (invalid argument)" if rc == -1 else " (hipError_t)"))
+
+
+_LIB = None
+
+
+def lib() -> _Lib:
+    global _LIB
+    if _LIB is None:
+        _LIB = _Lib()
+    return _LIB

@@ -1,0 +1,347 @@
+// Fused softmax attention, forward + backward, bf16 in/out, fp32 softmax/accumulators, head_dim 64
+// (gfx950, v_mfma_f32_16x16x32_bf16).  Sequences on this path are short (fusion transformer S = 1+84+84+L <= 256,
+// rollout decoder S = T <= 256, T5 L <= 64, ViT 433), so one workgroup owns one (batch row, head) with K and V
+// resident in LDS, and the full score row of a 16-query tile lives in registers: exact two-pass softmax, no online
+// rescale.  Reference ops: nn.MultiheadAttention inside nn.TransformerEncoderLayer (no mask;
+// allenact_dino_transformer.py:545-552,702-708), llama Attention with the block-causal ``traj_index`` mask
+// (llama/model.py:249-322 + allenact_dino_transformer.py:398-402), T5 self-attention (additive position bias +
+// key padding mask, no 1/sqrt(d) scale).
+//
+// Layout trick ("swapped QK^T"): S^T = K.Q^T puts the query index on lane&15, so a query's whole score row is
+// lane-local (+2 cross-lane steps), and the probabilities already sit in the MFMA A-operand layout of P.V;
+// V (and K/Q/dO in the backward) are read as B operands straight from row-major LDS with ds_read_b64_tr_b16.
+#include "common.h"
+
+#define HD 64
+#define LDSROW 72   // padded LDS row in elements (144 B): conflict-free 16-byte row reads
+#define ATT_THREADS 256
+
+enum { MASK_NONE = 0, MASK_BLOCK_CAUSAL = 1 };
+
+struct AttnArgs {
+    const bf16_t *Q, *K, *V; long ld;     // token row stride (elements) of the q/k/v tensors
+    bf16_t* O; long ldo;
+    float* LSE;                           // [rows, H, S]
+    const bf16_t* dO; long lddo;
+    bf16_t *dQ, *dK, *dV; long ldd;
+    const int* traj;                      // [rows, S] (MASK_BLOCK_CAUSAL)
+    const float* bias;                    // [H, S, S] additive (T5) or null
+    const unsigned char* kvalid;          // [rows, S] key padding mask or null
+    int S, H, mask_mode;
+    float scale;
+};
+
+__device__ __forceinline__ bf16x8 lds_row8(const bf16_t* base, int row, int col) {
+    return *(const bf16x8*)(base + row * LDSROW + col);
+}
+// B-operand gather: 8 reduction slots = rows {rA + 4g + 0..3, rB + 4g + 0..3}, column c0 + (lane & 15)
+__device__ __forceinline__ bf16x8 lds_tr8(const bf16_t* base, int rA, int rB, int c0, int lane) {
+    const int p = lane & 15, g = lane >> 4;
+    const bf16x4 lo = lds_tr16_b64(base + (rA + 4 * g + (p >> 2)) * LDSROW + c0 + 4 * (p & 3));
+    const bf16x4 hi = lds_tr16_b64(base + (rB + 4 * g + (p >> 2)) * LDSROW + c0 + 4 * (p & 3));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (short)f2bf(v[i]);
+    return r;
+}
+
+// stage an [S, 64] head slice into LDS rows (zero-filled up to s_pad)
+__device__ __forceinline__ void stage_head(bf16_t* dst, const bf16_t* src, long ld, int S, int s_pad, int tid) {
+    for (int q = tid; q < s_pad * 8; q += ATT_THREADS) {
+        const int row = q >> 3, c = q & 7;
+        u32x4 w = {0, 0, 0, 0};
+        if (row < S) w = *(const u32x4*)(src + (size_t)row * ld + c * 8);
+        *(u32x4*)(dst + row * LDSROW + c * 8) = w;
+    }
+}
+
+__device__ __forceinline__ bool masked(const AttnArgs& p, int q, int key, const int* traj_s, const unsigned char* kv_s) {
+    if (key >= p.S) return true;
+    if (p.mask_mode == MASK_BLOCK_CAUSAL && (key > q || traj_s[key] != traj_s[q])) return true;
+    if (kv_s && !kv_s[key]) return true;
+    return false;
+}
+
+// ================================================================================================ forward
+template <int NKT>
+__global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SP = NKT * 16;
+    bf16_t* Ks = (bf16_t*)smem;
+    bf16_t* Vs = Ks + SP * LDSROW;
+    int* traj_s = (int*)(Vs + SP * LDSROW);
+    unsigned char* kv_s = (unsigned char*)(traj_s + SP);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const size_t tok0 = (size_t)r * p.S;
+    const int S = p.S;
+    stage_head(Ks, p.K + tok0 * p.ld + h * HD, p.ld, S, SP, tid);
+    stage_head(Vs, p.V + tok0 * p.ld + h * HD, p.ld, S, SP, tid);
+    for (int i = tid; i < SP; i += ATT_THREADS) {
+        traj_s[i] = (p.traj && i < S) ? p.traj[tok0 + i] : -1;
+        kv_s[i] = (p.kvalid && i < S) ? p.kvalid[tok0 + i] : 1;
+    }
+    __syncthreads();
+    const unsigned char* kvp = p.kvalid ? kv_s : nullptr;
+    const int ql = lane & 15, g = lane >> 4;
+    const int nqt = (S + 15) / 16;
+    for (int qt = wid; qt < nqt; qt += ATT_THREADS / 64) {
+        const int q = qt * 16 + ql;
+        bf16x8 qf[2] = {bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, bf16x8{0, 0, 0, 0, 0, 0, 0, 0}};
+        if (q < S) {
+            const bf16_t* qp = p.Q + (tok0 + q) * p.ld + h * HD + 8 * g;
+            qf[0] = *(const bf16x8*)qp;
+            qf[1] = *(const bf16x8*)(qp + 32);
+        }
+        float sc[NKT][4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            if (kt * 16 < S) {
+                a = mfma16(lds_row8(Ks, kt * 16 + ql, 8 * g), qf[0], a);
+                a = mfma16(lds_row8(Ks, kt * 16 + ql, 32 + 8 * g), qf[1], a);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = kt * 16 + 4 * g + e;
+                float s = a[e] * p.scale;
+                if (p.bias && q < S && key < S) s += p.bias[((size_t)h * S + q) * S + key];
+                if (masked(p, q < S ? q : 0, key, traj_s, kvp)) s = -INFINITY;
+                sc[kt][e] = s;
+                mx = fmaxf(mx, s);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (mx == -INFINITY) mx = 0.f;
+        float lsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sc[kt][e] = __expf(sc[kt][e] - mx); lsum += sc[kt][e]; }
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NKT / 2; ++u) {
+            if (u * 32 < S) {
+                const float pv[8] = {sc[2 * u][0], sc[2 * u][1], sc[2 * u][2], sc[2 * u][3],
+                                     sc[2 * u + 1][0], sc[2 * u + 1][1], sc[2 * u + 1][2], sc[2 * u + 1][3]};
+                const bf16x8 pa = pack8(pv);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    o[dt] = mfma16(pa, lds_tr8(Vs, 32 * u, 32 * u + 16, dt * 16, lane), o[dt]);
+            }
+        }
+        // o[dt][e]: query row qt*16 + 4g + e, column dt*16 + ql
+        const float inv_own = lsum > 0.f ? 1.f / lsum : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float inv = __shfl(inv_own, 4 * g + e, 64);
+            const int qo = qt * 16 + 4 * g + e;
+            if (qo < S) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    p.O[(tok0 + qo) * p.ldo + h * HD + dt * 16 + ql] = f2bf(o[dt][e] * inv);
+            }
+        }
+        if (p.LSE && g == 0 && q < S) p.LSE[((size_t)r * p.H + h) * S + q] = mx + __logf(lsum);
+    }
+}
+
+// ================================================================================================ backward
+// Pass A (waves own query tiles, swapped layout): dQ = dS.K.  Pass B (waves own key tiles): dK = dS^T.Q, dV = P^T.dO.
+// P is recomputed from the saved log-sum-exp; D = rowsum(dO * O).
+template <int NKT>
+__global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SP = NKT * 16;
+    bf16_t* Qs = (bf16_t*)smem;
+    bf16_t* Ks = Qs + SP * LDSROW;
+    bf16_t* Vs = Ks + SP * LDSROW;
+    bf16_t* Gs = Vs + SP * LDSROW;  // dO
+    float* lse_s = (float*)(Gs + SP * LDSROW);
+    float* D_s = lse_s + SP;
+    int* traj_s = (int*)(D_s + SP);
+    unsigned char* kv_s = (unsigned char*)(traj_s + SP);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const size_t tok0 = (size_t)r * p.S;
+    const int S = p.S;
+    stage_head(Qs, p.Q + tok0 * p.ld + h * HD, p.ld, S, SP, tid);
+    stage_head(Ks, p.K + tok0 * p.ld + h * HD, p.ld, S, SP, tid);
+    stage_head(Vs, p.V + tok0 * p.ld + h * HD, p.ld, S, SP, tid);
+    stage_head(Gs, p.dO + tok0 * p.lddo + h * HD, p.lddo, S, SP, tid);
+    for (int i = tid; i < SP; i += ATT_THREADS) {
+        traj_s[i] = (p.traj && i < S) ? p.traj[tok0 + i] : -1;
+        kv_s[i] = (p.kvalid && i < S) ? p.kvalid[tok0 + i] : 1;
+        lse_s[i] = i < S ? p.LSE[((size_t)r * p.H + h) * S + i] : INFINITY;  // +inf => P = 0 for padded queries
+    }
+    for (int row = wid; row < SP; row += ATT_THREADS / 64) {  // D[q] = sum_d dO[q,d] * O[q,d]
+        float v = 0.f;
+        if (row < S) v = bf2f(p.dO[(tok0 + row) * p.lddo + h * HD + lane]) * bf2f(p.O[(tok0 + row) * p.ldo + h * HD + lane]);
+        v = wave_sum(v);
+        if (lane == 0) D_s[row] = v;
+    }
+    __syncthreads();
+    const unsigned char* kvp = p.kvalid ? kv_s : nullptr;
+    const int ql = lane & 15, g = lane >> 4;
+    const int ntile = (S + 15) / 16;
+
+    // ---------------- pass A: dQ
+    for (int qt = wid; qt < ntile; qt += ATT_THREADS / 64) {
+        const int q = qt * 16 + ql;
+        const bf16x8 qf0 = lds_row8(Qs, q, 8 * g), qf1 = lds_row8(Qs, q, 32 + 8 * g);
+        const bf16x8 gf0 = lds_row8(Gs, q, 8 * g), gf1 = lds_row8(Gs, q, 32 + 8 * g);
+        const float lse_q = lse_s[q], D_q = D_s[q];
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int u = 0; u < NKT / 2; ++u) {
+            if (u * 32 < S) {
+                float dsv[8];
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const int kt = 2 * u + e2;
+                    f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    s = mfma16(lds_row8(Ks, kt * 16 + ql, 8 * g), qf0, s);
+                    s = mfma16(lds_row8(Ks, kt * 16 + ql, 32 + 8 * g), qf1, s);
+                    dp = mfma16(lds_row8(Vs, kt * 16 + ql, 8 * g), gf0, dp);
+                    dp = mfma16(lds_row8(Vs, kt * 16 + ql, 32 + 8 * g), gf1, dp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = kt * 16 + 4 * g + e;
+                        float sv = s[e] * p.scale;
+                        if (p.bias && q < S && key < S) sv += p.bias[((size_t)h * S + q) * S + key];
+                        const bool mk = (q >= S) || masked(p, q < S ? q : 0, key, traj_s, kvp);
+                        const float pr = mk ? 0.f : __expf(sv - lse_q);
+                        dsv[e2 * 4 + e] = pr * (dp[e] - D_q) * p.scale;
+                    }
+                }
+                const bf16x8 da = pack8(dsv);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    dq[dt] = mfma16(da, lds_tr8(Ks, 32 * u, 32 * u + 16, dt * 16, lane), dq[dt]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int qo = qt * 16 + 4 * g + e;
+            if (qo < S) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    p.dQ[(tok0 + qo) * p.ldd + h * HD + dt * 16 + ql] = f2bf(dq[dt][e]);
+            }
+        }
+    }
+
+    // ---------------- pass B: dK, dV
+    for (int kt = wid; kt < ntile; kt += ATT_THREADS / 64) {
+        const int keyl = kt * 16 + ql;  // this lane's key as the B-operand column
+        const bf16x8 kf0 = lds_row8(Ks, keyl, 8 * g), kf1 = lds_row8(Ks, keyl, 32 + 8 * g);
+        const bf16x8 vf0 = lds_row8(Vs, keyl, 8 * g), vf1 = lds_row8(Vs, keyl, 32 + 8 * g);
+        f32x4 dk[4], dv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+        for (int w = 0; w < NKT / 2; ++w) {
+            if (w * 32 < S) {
+                float pv[8], dsv[8];
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const int qt = 2 * w + e2;
+                    f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    s = mfma16(lds_row8(Qs, qt * 16 + ql, 8 * g), kf0, s);
+                    s = mfma16(lds_row8(Qs, qt * 16 + ql, 32 + 8 * g), kf1, s);
+                    dp = mfma16(lds_row8(Gs, qt * 16 + ql, 8 * g), vf0, dp);
+                    dp = mfma16(lds_row8(Gs, qt * 16 + ql, 32 + 8 * g), vf1, dp);
+                    // s[e]: query qt*16 + 4g + e, key keyl
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int q = qt * 16 + 4 * g + e;
+                        float sv = s[e] * p.scale;
+                        if (p.bias && q < S && keyl < S) sv += p.bias[((size_t)h * S + q) * S + keyl];
+                        const bool mk = (q >= S) || masked(p, q < S ? q : 0, keyl, traj_s, kvp);
+                        const float pr = mk ? 0.f : __expf(sv - lse_s[q]);
+                        pv[e2 * 4 + e] = pr;
+                        dsv[e2 * 4 + e] = pr * (dp[e] - D_s[q]) * p.scale;
+                    }
+                }
+                const bf16x8 pa = pack8(pv), da = pack8(dsv);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dv[dt] = mfma16(pa, lds_tr8(Gs, 32 * w, 32 * w + 16, dt * 16, lane), dv[dt]);
+                    dk[dt] = mfma16(da, lds_tr8(Qs, 32 * w, 32 * w + 16, dt * 16, lane), dk[dt]);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ko = kt * 16 + 4 * g + e;
+            if (ko < S) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    p.dK[(tok0 + ko) * p.ldd + h * HD + dt * 16 + ql] = f2bf(dk[dt][e]);
+                    p.dV[(tok0 + ko) * p.ldd + h * HD + dt * 16 + ql] = f2bf(dv[dt][e]);
+                }
+            }
+        }
+    }
+}
+
+template <int NKT>
+static int launch_fwd(const AttnArgs& p, int rows, hipStream_t st) {
+    const size_t lds = (size_t)2 * NKT * 16 * LDSROW * sizeof(bf16_t) + NKT * 16 * (sizeof(int) + 1);
+    static bool attr = false;
+    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL(attn_fwd_kernel<NKT>, dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
+    return svla_launch_status();
+}
+template <int NKT>
+static int launch_bwd(const AttnArgs& p, int rows, hipStream_t st) {
+    const size_t lds = (size_t)4 * NKT * 16 * LDSROW * sizeof(bf16_t) + NKT * 16 * (2 * sizeof(float) + sizeof(int) + 1);
+    static bool attr = false;
+    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL(attn_bwd_kernel<NKT>, dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
+    return svla_launch_status();
+}
+
+extern "C" int svla_attn_fwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t* V, long ld, bf16_t* O, long ldo, float* LSE,
+                                  int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj,
+                                  const float* bias, const unsigned char* kvalid, void* stream) {
+    if (head_dim != HD || rows <= 0 || S <= 0 || S > 448 || (ld % 8) || H <= 0) return SVLA_EINVAL;
+    if (mask_mode == MASK_BLOCK_CAUSAL && !traj) return SVLA_EINVAL;
+    AttnArgs p{};
+    p.Q = Q; p.K = K; p.V = V; p.ld = ld; p.O = O; p.ldo = ldo; p.LSE = LSE; p.traj = traj; p.bias = bias; p.kvalid = kvalid;
+    p.S = S; p.H = H; p.mask_mode = mask_mode; p.scale = scale;
+    hipStream_t st = (hipStream_t)stream;
+    if (S <= 64) return launch_fwd<4>(p, rows, st);
+    if (S <= 128) return launch_fwd<8>(p, rows, st);
+    if (S <= 192) return launch_fwd<12>(p, rows, st);
+    if (S <= 256) return launch_fwd<16>(p, rows, st);
+    return launch_fwd<28>(p, rows, st);
+}
+
+extern "C" int svla_attn_bwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t* V, long ld, const bf16_t* O, long ldo,
+                                  const float* LSE, const bf16_t* dO, long lddo, bf16_t* dQ, bf16_t* dK, bf16_t* dV, long ldd,
+                                  int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj,
+                                  const float* bias, const unsigned char* kvalid, void* stream) {
+    if (head_dim != HD || rows <= 0 || S <= 0 || S > 256 || (ld % 8) || (lddo % 8) || H <= 0) return SVLA_EINVAL;
+    if (mask_mode == MASK_BLOCK_CAUSAL && !traj) return SVLA_EINVAL;
+    AttnArgs p{};
+    p.Q = Q; p.K = K; p.V = V; p.ld = ld; p.O = (bf16_t*)O; p.ldo = ldo; p.LSE = (float*)LSE; p.dO = dO; p.lddo = lddo;
+    p.dQ = dQ; p.dK = dK; p.dV = dV; p.ldd = ldd; p.traj = traj; p.bias = bias; p.kvalid = kvalid;
+    p.S = S; p.H = H; p.mask_mode = mask_mode; p.scale = scale;
+    hipStream_t st = (hipStream_t)stream;
+    if (S <= 64) return launch_bwd<4>(p, rows, st);
+    if (S <= 128) return launch_bwd<8>(p, rows, st);
+    if (S <= 192) return launch_bwd<12>(p, rows, st);
+    return launch_bwd<16>(p, rows, st);
+}

@@ -1,0 +1,67 @@
+// Common device helpers for the gfx950 (CDNA4 / MI355X) kernels.  Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SVLA_OK 0
+#define SVLA_EINVAL (-1)
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA A/B fragment (8 bf16 = 4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even, NaN-preserving
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// LDS transpose read (gfx950 ds_read_b64_tr_b16): within each 16-lane group, lane p supplies the address of
+// 4 contiguous bf16 = (row p>>2, column quad p&3) of a [4][16] block; lane i receives column i of that block
+// (elements row 0..3).  See MI355X guide section 2 / T10.
+__device__ __forceinline__ bf16x4 lds_tr16_b64(const bf16_t* p) {
+    typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 v4bf;
+    v4bf r = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) v4bf*)p);
+    return __builtin_bit_cast(bf16x4, r);
+}
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_hw;
+// D(32x32) += A(32x16) . B(16x32): lane l holds A[l&31][8*(l>>5)+0..7], B[8*(l>>5)+0..7][l&31];
+// D[reg]: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
+}
+// D(16x16) += A(16x32) . B(32x16): lane l holds A[l&15][8*(l>>4)+0..7], B[8*(l>>4)+0..7][l&15];
+// D[reg]: col = l&15, row = 4*(l>>4) + reg
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
+}
+
+#define HIP_CHECK_RET(expr)                        \
+    do {                                           \
+        hipError_t _e = (expr);                    \
+        if (_e != hipSuccess) return (int)_e;      \
+    } while (0)
+
+static inline int svla_launch_status() { return (int)hipGetLastError(); }

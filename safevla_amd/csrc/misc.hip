@@ -1,0 +1,324 @@
+// HBM-bound glue kernels of the policy forward/backward and the optimiser step (gfx950).
+//   feat_to_tokens      : (R,384,7,12) f32 channels-first DINO features -> bf16 token-major [R,2,84,384]
+//   fusion_fill / _bwd  : fusion token + per-episode text tokens into / out of the fusion input [R,S,512]
+//   decoder_embed / _bwd: beliefs input = fusion[:,0] + prev-action emb + in-hand emb + sinusoidal time enc
+//   swiglu / _bwd       : llama FeedForward gate
+//   adam / sumsq / cast / transpose : flat-buffer optimiser step (clip by global norm, no host sync)
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// DataAugmentation/DINO preprocessor output is (R, C=384, 7, 12) fp32 (dino_preprocessors.py:31-35); the 1x1-conv
+// compressor wants tokens with the channel (reduction) index contiguous.  Transpose through LDS, cast to bf16.
+__global__ void feat_to_tokens_kernel(const float* __restrict__ feat, int R, int C, int P, int cam, int ncam,
+                                      bf16_t* __restrict__ out) {
+    __shared__ float tile[64][85];
+    const int r = blockIdx.x, c0 = blockIdx.y * 64;
+    const float* src = feat + ((size_t)r * C + c0) * P;
+    for (int i = threadIdx.x; i < 64 * P; i += blockDim.x) tile[i / P][i % P] = src[i];
+    __syncthreads();
+    bf16_t* dst = out + ((size_t)(r * ncam + cam) * P) * C + c0;
+    for (int i = threadIdx.x; i < P * 32; i += blockDim.x) {
+        const int pp = i >> 5, cp = i & 31;
+        *(uint32_t*)(dst + (size_t)pp * C + 2 * cp) = pack_bf2(tile[2 * cp][pp], tile[2 * cp + 1][pp]);
+    }
+}
+
+extern "C" int svla_feat_to_tokens(const float* feat, int R, int C, int P, int cam, int ncam, bf16_t* out, void* stream) {
+    if (R <= 0 || (C % 64) || P > 85 || cam >= ncam) return SVLA_EINVAL;
+    hipLaunchKernelGGL(feat_to_tokens_kernel, dim3(R, C / 64), dim3(256), 0, (hipStream_t)stream, feat, R, C, P, cam, ncam, out);
+    return svla_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// x0[r, 0, :] = fusion_token; x0[r, text_off + j, :] = text[gid[r], j, :]   (allenact_dino_transformer.py:672-692)
+__global__ void fusion_fill_kernel(const float* __restrict__ fusion_token, const bf16_t* __restrict__ text,
+                                   const int* __restrict__ gid, int R, int S, int L, int text_off, bf16_t* __restrict__ x0) {
+    const int r = blockIdx.x, lane = threadIdx.x;  // 64 threads x 8 elements = 512
+    bf16_t* row = x0 + (size_t)r * S * 512;
+    u32x4 w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = pack_bf2(fusion_token[lane * 8 + 2 * e], fusion_token[lane * 8 + 2 * e + 1]);
+    *(u32x4*)(row + lane * 8) = w;
+    const bf16_t* tsrc = text + (size_t)gid[r] * L * 512;
+    for (int j = 0; j < L; ++j)
+        *(u32x4*)(row + (size_t)(text_off + j) * 512 + lane * 8) = *(const u32x4*)(tsrc + (size_t)j * 512 + lane * 8);
+}
+
+extern "C" int svla_fusion_fill(const float* fusion_token, const bf16_t* text, const int* gid, int R, int S, int L,
+                                int text_off, bf16_t* x0, void* stream) {
+    if (R <= 0 || text_off + L > S) return SVLA_EINVAL;
+    hipLaunchKernelGGL(fusion_fill_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, fusion_token, text, gid, R, S, L, text_off, x0);
+    return svla_launch_status();
+}
+
+// dtext[gid[r], j, :] += dx0[r, text_off + j, :].  Rows are (t*B + b); an env's goal is constant over an episode,
+// so one workgroup walks one env over t and flushes a register accumulator only when the goal id changes.
+__global__ void fusion_text_bwd_kernel(const bf16_t* __restrict__ dx0, const int* __restrict__ gid, int T, int B, int S,
+                                       int L, int text_off, float* __restrict__ dtext) {
+    const int b = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int cur = gid[b];
+    for (int t = 0; t < T; ++t) {
+        const int r = t * B + b;
+        const int g = gid[r];
+        if (g != cur) {
+            float* d = dtext + ((size_t)cur * L + j) * 512 + lane * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { atomicAdd(d + e, acc[e]); acc[e] = 0.f; }
+            cur = g;
+        }
+        const u32x4 w = *(const u32x4*)(dx0 + ((size_t)r * S + text_off + j) * 512 + lane * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(w[e]); acc[2 * e + 1] += bf_hi(w[e]); }
+    }
+    float* d = dtext + ((size_t)cur * L + j) * 512 + lane * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(d + e, acc[e]);
+}
+
+extern "C" int svla_fusion_text_bwd(const bf16_t* dx0, const int* gid, int T, int B, int S, int L, int text_off, float* dtext,
+                                    void* stream) {
+    if (T <= 0 || B <= 0 || L <= 0) return SVLA_EINVAL;
+    hipLaunchKernelGGL(fusion_text_bwd_kernel, dim3(B, L), dim3(64), 0, (hipStream_t)stream, dx0, gid, T, B, S, L, text_off, dtext);
+    return svla_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decoder input (allenact_dino_transformer.py:353-385 + text_cond_visual_encoder.py:263-283):
+//   out[b*T + t, :] = xf[(t*B+b)*S*512 + :]  (fusion token output)  + act_tab[masks ? prev_action : A] + hand_tab[hand]
+//                   + pe(time_step),  pe[2i] = sin(pos*div[i]), pe[2i+1] = cos(pos*div[i])
+__global__ void decoder_embed_kernel(const bf16_t* __restrict__ xf, long xf_row_stride, const float* __restrict__ act_tab,
+                                     const float* __restrict__ hand_tab, const float* __restrict__ div_term,
+                                     const int64_t* __restrict__ prev_actions, const float* __restrict__ masks,
+                                     const int64_t* __restrict__ hand, const int64_t* __restrict__ time_step, int T, int B,
+                                     int n_actions, bf16_t* __restrict__ out) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= T * B) return;
+    const int t = wave / B, b = wave % B;
+    const int64_t a = masks[wave] != 0.f ? prev_actions[wave] : (int64_t)n_actions;
+    const float pos = (float)time_step[wave];
+    const u32x4 w = *(const u32x4*)(xf + (size_t)wave * xf_row_stride + lane * 8);
+    const float* at = act_tab + (size_t)a * 512 + lane * 8;
+    const float* ht = hand_tab + (size_t)hand[wave] * 512 + lane * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float ang = pos * div_term[lane * 4 + e];
+        // reference order: time_enc + ((obs + prev_action_emb) + in_hand_emb)
+        v[2 * e] = sinf(ang) + ((bf_lo(w[e]) + at[2 * e]) + ht[2 * e]);
+        v[2 * e + 1] = cosf(ang) + ((bf_hi(w[e]) + at[2 * e + 1]) + ht[2 * e + 1]);
+    }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+    *(u32x4*)(out + ((size_t)b * T + t) * 512 + lane * 8) = o;
+}
+
+extern "C" int svla_decoder_embed_fwd(const bf16_t* xf, long xf_row_stride, const float* act_tab, const float* hand_tab,
+                                      const float* div_term, const int64_t* prev_actions, const float* masks,
+                                      const int64_t* hand, const int64_t* time_step, int T, int B, int n_actions, bf16_t* out,
+                                      void* stream) {
+    if (T <= 0 || B <= 0) return SVLA_EINVAL;
+    hipLaunchKernelGGL(decoder_embed_kernel, dim3((T * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, xf, xf_row_stride, act_tab,
+                       hand_tab, div_term, prev_actions, masks, hand, time_step, T, B, n_actions, out);
+    return svla_launch_status();
+}
+
+// dxf[(t*B+b) row, :] = dout[b*T+t, :];  d act_tab / d hand_tab accumulated in LDS per block, then flushed.
+__global__ void decoder_embed_bwd_kernel(const bf16_t* __restrict__ dout, const int64_t* __restrict__ prev_actions,
+                                         const float* __restrict__ masks, const int64_t* __restrict__ hand, int T, int B,
+                                         int n_actions, bf16_t* __restrict__ dxf, long dxf_row_stride,
+                                         float* __restrict__ d_act_tab, float* __restrict__ d_hand_tab) {
+    extern __shared__ float tab[];  // [(n_actions + 2) + 3][512]
+    const int nrows_tab = n_actions + 2 + 3;
+    for (int i = threadIdx.x; i < nrows_tab * 512; i += blockDim.x) tab[i] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int nw = (gridDim.x * blockDim.x) >> 6;
+    for (int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wave < T * B; wave += nw) {
+        const int t = wave / B, b = wave % B;
+        const u32x4 w = *(const u32x4*)(dout + ((size_t)b * T + t) * 512 + lane * 8);
+        *(u32x4*)(dxf + (size_t)wave * dxf_row_stride + lane * 8) = w;
+        const int a = masks[wave] != 0.f ? (int)prev_actions[wave] : n_actions;
+        const int hh = n_actions + 2 + (int)hand[wave];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float lo = bf_lo(w[e]), hi = bf_hi(w[e]);
+            atomicAdd(&tab[a * 512 + lane * 8 + 2 * e], lo);
+            atomicAdd(&tab[a * 512 + lane * 8 + 2 * e + 1], hi);
+            atomicAdd(&tab[hh * 512 + lane * 8 + 2 * e], lo);
+            atomicAdd(&tab[hh * 512 + lane * 8 + 2 * e + 1], hi);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nrows_tab * 512; i += blockDim.x) {
+        const float v = tab[i];
+        if (v != 0.f) {
+            if (i < (n_actions + 2) * 512) atomicAdd(&d_act_tab[i], v);
+            else atomicAdd(&d_hand_tab[i - (n_actions + 2) * 512], v);
+        }
+    }
+}
+
+extern "C" int svla_decoder_embed_bwd(const bf16_t* dout, const int64_t* prev_actions, const float* masks, const int64_t* hand,
+                                      int T, int B, int n_actions, bf16_t* dxf, long dxf_row_stride, float* d_act_tab,
+                                      float* d_hand_tab, void* stream) {
+    if (T <= 0 || B <= 0) return SVLA_EINVAL;
+    const size_t lds = (size_t)(n_actions + 5) * 512 * sizeof(float);
+    int blocks = (T * B + 63) / 64;
+    if (blocks > 128) blocks = 128;
+    static bool attr = false;
+    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)decoder_embed_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL(decoder_embed_bwd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, dout, prev_actions, masks, hand,
+                       T, B, n_actions, dxf, dxf_row_stride, d_act_tab, d_hand_tab);
+    return svla_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// llama FeedForward gate (llama/model.py:359-360): g = silu(a) * b with [a | b] = x.[w1 | w3]^T  (row = [a(Hd) | b(Hd)])
+__global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ ab, long M, int Hd, bf16_t* __restrict__ g) {
+    const long n = M * (Hd / 8);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / (Hd / 8);
+        const int c = (int)(i % (Hd / 8)) * 8;
+        const u32x4 a = *(const u32x4*)(ab + m * 2 * Hd + c), b = *(const u32x4*)(ab + m * 2 * Hd + Hd + c);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a0 = bf_lo(a[e]), a1 = bf_hi(a[e]);
+            o[e] = pack_bf2(a0 / (1.f + __expf(-a0)) * bf_lo(b[e]), a1 / (1.f + __expf(-a1)) * bf_hi(b[e]));
+        }
+        *(u32x4*)(g + m * Hd + c) = o;
+    }
+}
+__global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ ab, const bf16_t* __restrict__ dg, long M, int Hd,
+                                  bf16_t* __restrict__ dab) {
+    const long n = M * (Hd / 8);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / (Hd / 8);
+        const int c = (int)(i % (Hd / 8)) * 8;
+        const u32x4 a = *(const u32x4*)(ab + m * 2 * Hd + c), b = *(const u32x4*)(ab + m * 2 * Hd + Hd + c);
+        const u32x4 d = *(const u32x4*)(dg + m * Hd + c);
+        u32x4 oa, ob;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float av[2] = {bf_lo(a[e]), bf_hi(a[e])}, bv[2] = {bf_lo(b[e]), bf_hi(b[e])}, dv[2] = {bf_lo(d[e]), bf_hi(d[e])};
+            float da[2], db[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float sg = 1.f / (1.f + __expf(-av[k]));
+                da[k] = dv[k] * bv[k] * sg * (1.f + av[k] * (1.f - sg));
+                db[k] = dv[k] * av[k] * sg;
+            }
+            oa[e] = pack_bf2(da[0], da[1]); ob[e] = pack_bf2(db[0], db[1]);
+        }
+        *(u32x4*)(dab + m * 2 * Hd + c) = oa;
+        *(u32x4*)(dab + m * 2 * Hd + Hd + c) = ob;
+    }
+}
+extern "C" int svla_swiglu_fwd(const bf16_t* ab, long M, int Hd, bf16_t* g, void* stream) {
+    if (M <= 0 || (Hd % 8)) return SVLA_EINVAL;
+    long blocks = (M * (Hd / 8) + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, ab, M, Hd, g);
+    return svla_launch_status();
+}
+extern "C" int svla_swiglu_bwd(const bf16_t* ab, const bf16_t* dg, long M, int Hd, bf16_t* dab, void* stream) {
+    if (M <= 0 || (Hd % 8)) return SVLA_EINVAL;
+    long blocks = (M * (Hd / 8) + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, ab, dg, M, Hd, dab);
+    return svla_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ optimiser
+__global__ void sumsq_kernel(const float* __restrict__ g, long n, double* __restrict__ out) {
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += g[i] * g[i];
+    s = wave_sum(s);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (double)(part[0] + part[1] + part[2] + part[3]));
+}
+extern "C" int svla_sumsq_f32(const float* g, long n, double* out, void* stream) {
+    if (n <= 0) return SVLA_EINVAL;
+    long blocks = (n + 1023) / 1024; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+    return svla_launch_status();
+}
+
+// torch.optim.Adam (defaults amsgrad=False, weight_decay=0) fused with clip_grad_norm_: the clip coefficient is read
+// from the device-side squared norm (no host sync).  Also refreshes the bf16 mirror of the parameters.
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            bf16_t* __restrict__ p_bf16, long n, float lr, float beta1, float beta2, float eps, float bc1,
+                            float bc2_sqrt, const double* __restrict__ gnorm_sq, float max_norm, float grad_scale) {
+    float clip = grad_scale;
+    if (gnorm_sq && max_norm > 0.f) {
+        const float tn = sqrtf((float)(*gnorm_sq)) * grad_scale;
+        const float c = max_norm / (tn + 1e-6f);
+        clip *= fminf(c, 1.f);
+    }
+    const float step = lr / bc1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * clip;
+        const float mi = m[i] + (gi - m[i]) * (1.f - beta1);        // lerp_
+        const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;    // mul_ + addcmul_
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        const float pi = p[i] - step * (mi / denom);
+        m[i] = mi; v[i] = vi; p[i] = pi;
+        if (p_bf16) p_bf16[i] = f2bf(pi);
+    }
+}
+extern "C" int svla_adam_step_f32(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, long n, float lr, float beta1,
+                                  float beta2, float eps, int step, const double* gnorm_sq, float max_norm, float grad_scale,
+                                  void* stream) {
+    if (n <= 0 || step <= 0) return SVLA_EINVAL;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, p_bf16, n, lr, beta1, beta2, eps,
+                       bc1, bc2s, gnorm_sq, max_norm, grad_scale);
+    return svla_launch_status();
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) d[i] = f2bf(s[i]);
+}
+extern "C" int svla_cast_f32_bf16(const float* src, bf16_t* dst, long n, void* stream) {
+    if (n <= 0) return SVLA_EINVAL;
+    long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    return svla_launch_status();
+}
+
+// dst[c, r] (bf16) = src[r, c] (f32): transposed bf16 weight copies for the input-gradient GEMMs
+__global__ void transpose_cast_kernel(const float* __restrict__ s, int rows, int cols, bf16_t* __restrict__ d) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+    for (int j = ty; j < 32; j += 8)
+        tile[j][tx] = (r0 + j < rows && c0 + tx < cols) ? s[(size_t)(r0 + j) * cols + c0 + tx] : 0.f;
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < cols && r0 + tx < rows) d[(size_t)(c0 + j) * rows + r0 + tx] = f2bf(tile[tx][j]);
+}
+extern "C" int svla_transpose_cast_f32_bf16(const float* src, int rows, int cols, bf16_t* dst, void* stream) {
+    if (rows <= 0 || cols <= 0) return SVLA_EINVAL;
+    hipLaunchKernelGGL(transpose_cast_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, src, rows,
+                       cols, dst);
+    return svla_launch_status();
+}
+
+// rows of a table -> bf16 rows (T5 shared embedding gather): out[i, :] = table[ids[i], :]
+__global__ void embed_gather_kernel(const float* __restrict__ table, const int64_t* __restrict__ ids, long n, int D,
+                                    bf16_t* __restrict__ out) {
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= n) return;
+    const float* src = table + (size_t)ids[wave] * D;
+    for (int c = lane * 2; c < D; c += 128) *(uint32_t*)(out + wave * D + c) = pack_bf2(src[c], src[c + 1]);
+}
+extern "C" int svla_embed_gather_f32_bf16(const float* table, const int64_t* ids, long n, int D, bf16_t* out, void* stream) {
+    if (n <= 0 || (D % 2)) return SVLA_EINVAL;
+    hipLaunchKernelGGL(embed_gather_kernel, dim3((int)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, table, ids, n, D, out);
+    return svla_launch_status();
+}

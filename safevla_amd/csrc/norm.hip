@@ -1,0 +1,177 @@
+// LayerNorm / RMSNorm forward+backward, bf16 activations, fp32 statistics and parameters.  HBM-bound:
+// one wave per row (D/64 contiguous values per lane, 16-byte loads for D=512), grid-stride over rows.
+//
+// Reference ops: nn.LayerNorm inside nn.TransformerEncoderLayer (post-LN, eps 1e-5), the adapter
+// "Linear -> LayerNorm -> ReLU (+ camera token)" stacks (allenact_dino_transformer.py:509-513,539-543,672-688),
+// llama RMSNorm (training/online/third_party_models/llama/model.py:28-71, eps 1e-5), T5 RMS norm (eps 1e-6).
+//
+// Row maps: logical row m lives at memory row (m / G) * GS + OFF + (m % G) (G = 0: identity).  This lets the
+// adapter LayerNorm write straight into (and its backward read straight out of) the token slice of the
+// fusion-transformer input [R, S, D] without a concat/split copy.
+#include "common.h"
+
+struct RowMap { int G, GS, OFF; };
+__device__ __forceinline__ size_t map_row(const RowMap& rm, int m) {
+    return rm.G > 0 ? (size_t)(m / rm.G) * rm.GS + rm.OFF + (m % rm.G) : (size_t)m;
+}
+
+template <int VPL>
+__device__ __forceinline__ void load_row_bf16(const bf16_t* p, float (&v)[VPL]) {
+    if constexpr (VPL == 8) {
+        const u32x4 w = *(const u32x4*)p;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = bf_lo(w[i]); v[2 * i + 1] = bf_hi(w[i]); }
+    } else {
+        const uint32_t* q = (const uint32_t*)p;
+#pragma unroll
+        for (int i = 0; i < VPL / 2; ++i) { const uint32_t w = q[i]; v[2 * i] = bf_lo(w); v[2 * i + 1] = bf_hi(w); }
+    }
+}
+template <int VPL>
+__device__ __forceinline__ void store_row_bf16(bf16_t* p, const float (&v)[VPL]) {
+    if constexpr (VPL == 8) {
+        u32x4 w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
+        *(u32x4*)p = w;
+    } else {
+        uint32_t* q = (uint32_t*)p;
+#pragma unroll
+        for (int i = 0; i < VPL / 2; ++i) q[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- LayerNorm fwd
+// y = [relu](LN(x) * gamma + beta) [+ tok[(m % G) / tok_group]]        (rms != 0: RMS norm, beta ignored)
+template <int D>
+__global__ void norm_fwd_kernel(const bf16_t* __restrict__ x, RowMap xmap, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float eps, int rows, int rms, int relu,
+                                const float* __restrict__ tok, int tok_group, bf16_t* __restrict__ y, RowMap ymap,
+                                float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    constexpr int VPL = D / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    float g[VPL], b[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { g[i] = gamma[lane * VPL + i]; b[i] = (beta && !rms) ? beta[lane * VPL + i] : 0.f; }
+    for (int m = wave; m < rows; m += nw) {
+        float v[VPL];
+        load_row_bf16<VPL>(x + map_row(xmap, m) * D + lane * VPL, v);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) s += v[i];
+        const float mu = rms ? 0.f : wave_sum(s) * (1.f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { const float d = v[i] - mu; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) * (1.f / D) + eps);
+        if (lane == 0) { if (mean_out) mean_out[m] = mu; if (rstd_out) rstd_out[m] = rstd; }
+        const float* tk = tok ? tok + (size_t)((ymap.G > 0 ? (m % ymap.G) : m) / tok_group) * D + lane * VPL : nullptr;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            float o = (v[i] - mu) * rstd * g[i] + b[i];
+            if (relu) o = fmaxf(o, 0.f);
+            if (tk) o += tk[i];
+            v[i] = o;
+        }
+        store_row_bf16<VPL>(y + map_row(ymap, m) * D + lane * VPL, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- LayerNorm bwd
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma [* relu mask];   (rms: no mean(g) term)
+// dgamma += sum dy_masked * xhat; dbeta += sum dy_masked; dtok[k] += sum dy (rows of token group k)
+template <int D>
+__global__ void norm_bwd_kernel(const bf16_t* __restrict__ dy, RowMap dymap, const bf16_t* __restrict__ x, RowMap xmap,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ mean, const float* __restrict__ rstd_in, int rows, int rms,
+                                int relu, int tok_group, bf16_t* __restrict__ dx, RowMap dxmap,
+                                float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dtok) {
+    constexpr int VPL = D / 64;
+    __shared__ float red[4][4 * D];  // [wave][dgamma | dbeta | dtok0 | dtok1]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    float g[VPL], b[VPL], ag[VPL], ab[VPL], at0[VPL], at1[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        g[i] = gamma[lane * VPL + i]; b[i] = (beta && !rms) ? beta[lane * VPL + i] : 0.f;
+        ag[i] = ab[i] = at0[i] = at1[i] = 0.f;
+    }
+    for (int m = wave; m < rows; m += nw) {
+        float xv[VPL], dv[VPL];
+        load_row_bf16<VPL>(x + map_row(xmap, m) * D + lane * VPL, xv);
+        load_row_bf16<VPL>(dy + map_row(dymap, m) * D + lane * VPL, dv);
+        const float mu = rms ? 0.f : mean[m], rs = rstd_in[m];
+        if (dtok) {
+            const int k = (dymap.G > 0 ? (m % dymap.G) : m) / tok_group;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) { if (k == 0) at0[i] += dv[i]; else at1[i] += dv[i]; }
+        }
+        float s1 = 0.f, s2 = 0.f, gg[VPL], xh[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            xh[i] = (xv[i] - mu) * rs;
+            float d = dv[i];
+            if (relu && !(xh[i] * g[i] + b[i] > 0.f)) d = 0.f;
+            ag[i] += d * xh[i]; ab[i] += d;
+            gg[i] = d * g[i];
+            s1 += gg[i]; s2 += gg[i] * xh[i];
+        }
+        s1 = rms ? 0.f : wave_sum(s1) * (1.f / D);
+        s2 = wave_sum(s2) * (1.f / D);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) xv[i] = rs * (gg[i] - s1 - xh[i] * s2);
+        store_row_bf16<VPL>(dx + map_row(dxmap, m) * D + lane * VPL, xv);
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        red[wid][lane * VPL + i] = ag[i]; red[wid][D + lane * VPL + i] = ab[i];
+        red[wid][2 * D + lane * VPL + i] = at0[i]; red[wid][3 * D + lane * VPL + i] = at1[i];
+    }
+    __syncthreads();
+    const int nwv = blockDim.x >> 6;
+    for (int c = threadIdx.x; c < 4 * D; c += blockDim.x) {
+        float s = 0.f;
+        for (int w = 0; w < nwv; ++w) s += red[w][c];
+        if (c < D) { if (dgamma) atomicAdd(&dgamma[c], s); }
+        else if (c < 2 * D) { if (dbeta && !rms) atomicAdd(&dbeta[c - D], s); }
+        else if (dtok) atomicAdd(&dtok[c - 2 * D], s);
+    }
+}
+
+static inline int norm_grid(int rows) {
+    int blocks = (rows + 3) / 4;
+    return blocks > 2048 ? 2048 : (blocks < 1 ? 1 : blocks);
+}
+
+extern "C" int svla_norm_fwd_bf16(const bf16_t* x, int xG, int xGS, int xOFF, const float* gamma, const float* beta, float eps,
+                                  int rows, int D, int rms, int relu, const float* tok, int tok_group, bf16_t* y, int yG,
+                                  int yGS, int yOFF, float* mean, float* rstd, void* stream) {
+    if (rows <= 0) return SVLA_EINVAL;
+    if (tok && tok_group <= 0) return SVLA_EINVAL;
+    RowMap xm{xG, xGS, xOFF}, ym{yG, yGS, yOFF};
+    dim3 grid(norm_grid(rows)), block(256);
+    if (D == 512)
+        hipLaunchKernelGGL(norm_fwd_kernel<512>, grid, block, 0, (hipStream_t)stream, x, xm, gamma, beta, eps, rows, rms, relu,
+                           tok, tok_group, y, ym, mean, rstd);
+    else if (D == 384)
+        hipLaunchKernelGGL(norm_fwd_kernel<384>, grid, block, 0, (hipStream_t)stream, x, xm, gamma, beta, eps, rows, rms, relu,
+                           tok, tok_group, y, ym, mean, rstd);
+    else
+        return SVLA_EINVAL;
+    return svla_launch_status();
+}
+
+extern "C" int svla_norm_bwd_bf16(const bf16_t* dy, int dyG, int dyGS, int dyOFF, const bf16_t* x, int xG, int xGS, int xOFF,
+                                  const float* gamma, const float* beta, const float* mean, const float* rstd, int rows,
+                                  int D, int rms, int relu, int tok_group, bf16_t* dx, int dxG, int dxGS, int dxOFF,
+                                  float* dgamma, float* dbeta, float* dtok, void* stream) {
+    if (rows <= 0 || D != 512) return SVLA_EINVAL;
+    if (dtok && tok_group <= 0) return SVLA_EINVAL;
+    RowMap dym{dyG, dyGS, dyOFF}, xm{xG, xGS, xOFF}, dxm{dxG, dxGS, dxOFF};
+    int blocks = norm_grid(rows);
+    if (blocks > 512) blocks = 512;  // fewer, fatter blocks: each ends with 4*D atomics
+    hipLaunchKernelGGL(norm_bwd_kernel<512>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, dym, x, xm, gamma, beta, mean,
+                       rstd, rows, rms, relu, tok_group > 0 ? tok_group : 1, dx, dxm, dgamma, dbeta, dtok);
+    return svla_launch_status();
+}

@@ -1,0 +1,273 @@
+// PPO-Lagrangian scalar-side kernels: reward+cost GAE scan, fused SafePPOLogGrad forward+backward,
+// value losses, small policy/value heads.  All fp32 (the reference computes these in fp32), HBM/latency-bound.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// GAE reverse scan, reward and cost twins fused.  One thread per env (coalesced over B), sequential in T.
+// Restates AllenAct RolloutStorage.compute_returns(use_gae=True) [3P; SURVEY.md App. C]:
+//   delta = r[t] + gamma*V[t+1]*m[t+1] - V[t];  g = delta + (gamma*tau)*m[t+1]*g;  ret[t] = g + V[t];  adv = ret - V
+// The explicit __f*_rn calls pin the evaluation order / no-FMA-contraction so results are bit-identical
+// to the fp32 torch oracle.
+template <int UNROLL>
+__global__ void gae_scan_kernel(const float* __restrict__ rewards, const float* __restrict__ costs,
+                                const float* __restrict__ values, const float* __restrict__ c_values,
+                                const float* __restrict__ masks, const float* __restrict__ next_v,
+                                const float* __restrict__ next_cv, float gamma, float gamma_tau, int T, int B,
+                                float* __restrict__ ret, float* __restrict__ adv, float* __restrict__ c_ret,
+                                float* __restrict__ c_adv) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float g = 0.f, gc = 0.f, vn = next_v[b], cvn = next_cv[b];
+    int t = T - 1;
+    for (; t >= 0; t -= UNROLL) {
+        float r[UNROLL], c[UNROLL], v[UNROLL], cv[UNROLL], m[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {  // issue all loads of the chunk before the dependent chain
+            const int tt = t - u;
+            const bool ok = tt >= 0;
+            const size_t i = (size_t)(ok ? tt : 0) * B + b;
+            r[u] = rewards[i]; c[u] = costs[i]; v[u] = values[i]; cv[u] = c_values[i];
+            m[u] = masks[i + B];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int tt = t - u;
+            if (tt < 0) break;
+            const size_t i = (size_t)tt * B + b;
+            float d = __fsub_rn(__fadd_rn(r[u], __fmul_rn(__fmul_rn(gamma, vn), m[u])), v[u]);
+            g = __fadd_rn(d, __fmul_rn(__fmul_rn(gamma_tau, m[u]), g));
+            const float rt = __fadd_rn(g, v[u]);
+            ret[i] = rt; adv[i] = __fsub_rn(rt, v[u]);
+            vn = v[u];
+            float dc = __fsub_rn(__fadd_rn(c[u], __fmul_rn(__fmul_rn(gamma, cvn), m[u])), cv[u]);
+            gc = __fadd_rn(dc, __fmul_rn(__fmul_rn(gamma_tau, m[u]), gc));
+            const float crt = __fadd_rn(gc, cv[u]);
+            c_ret[i] = crt; c_adv[i] = __fsub_rn(crt, cv[u]);
+            cvn = cv[u];
+        }
+    }
+}
+
+extern "C" int svla_gae_scan_f32(const float* rewards, const float* costs, const float* values, const float* c_values,
+                                 const float* masks, const float* next_v, const float* next_cv, double gamma, double tau,
+                                 int T, int B, float* ret, float* adv, float* c_ret, float* c_adv, void* stream) {
+    if (T <= 0 || B <= 0) return SVLA_EINVAL;
+    const int threads = 64;
+    hipLaunchKernelGGL(gae_scan_kernel<8>, dim3((B + threads - 1) / threads), dim3(threads), 0, (hipStream_t)stream,
+                       rewards, costs, values, c_values, masks, next_v, next_cv, (float)gamma, (float)(gamma * tau), T, B,
+                       ret, adv, c_ret, c_adv);
+    return svla_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused SafePPOLogGrad forward + backward (training/online/loss/customized_loss.py:317-449).
+// One thread per (t,b) row, A <= 32 logits in registers.  sums[0..2] += {value_sq_err, action_loss, -entropy}
+// (double atomics); dlogits/dvalues are the gradients of
+//   total = value_coef*0.5*mean(v_err) + action_w*mean(action_loss) + ent_coef*mean(-H)
+// with mean = sum * inv_n (inv_n = 1/rows of the *whole* minibatch, so micro-batches/ranks add up exactly).
+template <int A_MAX>
+__global__ void ppo_lag_loss_kernel(const float* __restrict__ logits, const float* __restrict__ values,
+                                    const int64_t* __restrict__ actions, const float* __restrict__ old_logp,
+                                    const float* __restrict__ adv, const float* __restrict__ c_adv,
+                                    const float* __restrict__ returns, const float* __restrict__ old_values, int rows,
+                                    int A, float lam, float clip, float value_coef, float action_w, float ent_coef,
+                                    int use_clipped_value, float inv_n, float* __restrict__ dlogits,
+                                    float* __restrict__ dvalues, double* __restrict__ sums) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    float s_v = 0.f, s_a = 0.f, s_e = 0.f;
+    if (r < rows) {
+        float z[A_MAX];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < A_MAX; ++j) {
+            z[j] = j < A ? logits[(size_t)r * A + j] : -INFINITY;
+            mx = fmaxf(mx, z[j]);
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int j = 0; j < A_MAX; ++j) se += (j < A) ? expf(z[j] - mx) : 0.f;
+        const float lse = mx + logf(se);
+        const int a = (int)actions[r];
+        float H = 0.f, lp_a = 0.f;
+#pragma unroll
+        for (int j = 0; j < A_MAX; ++j) {
+            if (j < A) {
+                const float lp = z[j] - lse;
+                const float p = expf(lp);
+                H -= p * lp;
+                if (j == a) lp_a = lp;
+                z[j] = lp;  // keep log-probs
+            }
+        }
+        const float ratio = expf(lp_a - old_logp[r]);
+        const float clamped = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+        const float advm = (adv[r] - lam * (c_adv ? c_adv[r] : 0.f)) / (1.f + lam);
+        const float surr1 = ratio * advm, surr2 = clamped * advm;
+        const bool use_clamped = surr2 < surr1;
+        s_a = -(use_clamped ? surr2 : surr1);
+        const bool inside = (ratio >= 1.f - clip) && (ratio <= 1.f + clip);
+        const float dL_dlp = -((use_clamped && !inside) ? 0.f : ratio * advm) * action_w * inv_n;
+        s_e = -H;
+        const float ce = ent_coef * inv_n;
+#pragma unroll
+        for (int j = 0; j < A_MAX; ++j) {
+            if (j < A) {
+                const float p = expf(z[j]);
+                dlogits[(size_t)r * A + j] = dL_dlp * ((j == a ? 1.f : 0.f) - p) + ce * p * (z[j] + H);
+            }
+        }
+        const float v = values[r], rt = returns[r];
+        if (use_clipped_value) {
+            const float ov = old_values[r];
+            const float dv = v - ov;
+            const float vc = ov + fminf(fmaxf(dv, -clip), clip);
+            const float l1 = (v - rt) * (v - rt), l2 = (vc - rt) * (vc - rt);
+            s_v = fmaxf(l1, l2);
+            // torch.max backward: gradient goes to the larger operand (ties: equal split is measure-zero here)
+            float gv = (l1 >= l2) ? 2.f * (v - rt) : ((dv >= -clip && dv <= clip) ? 2.f * (vc - rt) : 0.f);
+            dvalues[r] = value_coef * 0.5f * gv * inv_n;
+        } else {
+            s_v = (rt - v) * (rt - v);
+            dvalues[r] = value_coef * (v - rt) * inv_n;
+        }
+    }
+    s_v = wave_sum(s_v); s_a = wave_sum(s_a); s_e = wave_sum(s_e);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&sums[0], (double)s_v);
+        atomicAdd(&sums[1], (double)s_a);
+        atomicAdd(&sums[2], (double)s_e);
+    }
+}
+
+extern "C" int svla_ppo_lag_loss_fwd_bwd_f32(const float* logits, const float* values, const int64_t* actions,
+                                             const float* old_logp, const float* adv, const float* c_adv,
+                                             const float* returns, const float* old_values, int rows, int A, float lam,
+                                             float clip, float value_coef, float action_w, float ent_coef,
+                                             int use_clipped_value, float inv_n, float* dlogits, float* dvalues,
+                                             double* sums, void* stream) {
+    if (rows <= 0 || A <= 0 || A > 32) return SVLA_EINVAL;
+    if (use_clipped_value && !old_values) return SVLA_EINVAL;
+    const int threads = 128;
+    hipLaunchKernelGGL(ppo_lag_loss_kernel<32>, dim3((rows + threads - 1) / threads), dim3(threads), 0,
+                       (hipStream_t)stream, logits, values, actions, old_logp, adv, c_adv, returns, old_values, rows, A, lam,
+                       clip, value_coef, action_w, ent_coef, use_clipped_value, inv_n, dlogits, dvalues, sums);
+    return svla_launch_status();
+}
+
+// PPOValue / SafePPOValue [3P]: 0.5*mean((returns - values)^2); sums[0] += sum sq err; dvalues = coef*(v-ret)*inv_n.
+__global__ void value_mse_kernel(const float* __restrict__ values, const float* __restrict__ returns, int rows, float coef,
+                                 float inv_n, float* __restrict__ dvalues, double* __restrict__ sums) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    float s = 0.f;
+    if (r < rows) {
+        const float d = values[r] - returns[r];
+        s = d * d;
+        dvalues[r] = coef * d * inv_n;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sums[0], (double)s);
+}
+
+extern "C" int svla_value_mse_fwd_bwd_f32(const float* values, const float* returns, int rows, float coef, float inv_n,
+                                          float* dvalues, double* sums, void* stream) {
+    if (rows <= 0) return SVLA_EINVAL;
+    hipLaunchKernelGGL(value_mse_kernel, dim3((rows + 127) / 128), dim3(128), 0, (hipStream_t)stream, values, returns, rows,
+                       coef, inv_n, dvalues, sums);
+    return svla_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small heads on fp32 beliefs (AllenAct LinearActorHead / LinearCriticHead [3P]): out[r, n] = x[r,:].W[n,:] + b[n],
+// D = 512 (8 values per lane, one wave per row), N <= 32.  ``row_perm_T``/``row_perm_B`` > 0: x rows are stored
+// (b*T + t) (decoder layout) while out rows are (t*B + b) (the [step, sampler] layout of the API).
+template <int N_MAX>
+__global__ void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                        const float* __restrict__ bias, int rows, int N, int T, int B,
+                                        float* __restrict__ out) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= rows) return;
+    int src = wave;
+    if (T > 0) { const int t = wave / B, b = wave % B; src = b * T + t; }
+    const float4* xp = (const float4*)(x + (size_t)src * 512 + lane * 8);
+    const float4 x0 = xp[0], x1 = xp[1];
+    for (int n = 0; n < N; ++n) {
+        const float4* wp = (const float4*)(W + (size_t)n * 512 + lane * 8);
+        const float4 w0 = wp[0], w1 = wp[1];
+        float s = x0.x * w0.x + x0.y * w0.y + x0.z * w0.z + x0.w * w0.w + x1.x * w1.x + x1.y * w1.y + x1.z * w1.z + x1.w * w1.w;
+        s = wave_sum(s);
+        if (lane == 0) out[(size_t)wave * N + n] = s + (bias ? bias[n] : 0.f);
+    }
+}
+
+// dx[src_row,:] (+)= sum_n dout[r,n] W[n,:]; dW[n,:] += sum_r dout[r,n] x[src_row,:]; db[n] += sum_r dout[r,n]
+template <int N_MAX>
+__global__ void small_linear_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                        const float* __restrict__ dout, int rows, int N, int T, int B, int accumulate_dx,
+                                        float* __restrict__ dx, float* __restrict__ dW, float* __restrict__ db) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    float gw[N_MAX][8];
+    float gb[N_MAX];
+#pragma unroll
+    for (int n = 0; n < N_MAX; ++n) {
+        gb[n] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gw[n][k] = 0.f;
+    }
+    for (int r = wave; r < rows; r += nwaves) {
+        int src = r;
+        if (T > 0) { const int t = r / B, b = r % B; src = b * T + t; }
+        const float4* xp = (const float4*)(x + (size_t)src * 512 + lane * 8);
+        const float4 x0 = xp[0], x1 = xp[1];
+        const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int n = 0; n < N_MAX; ++n) {
+            if (n < N) {
+                const float g = dout[(size_t)r * N + n];
+                const float4* wp = (const float4*)(W + (size_t)n * 512 + lane * 8);
+                const float4 w0 = wp[0], w1 = wp[1];
+                const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { acc[k] += g * wv[k]; gw[n][k] += g * xv[k]; }
+                gb[n] += g;
+            }
+        }
+        float* dp = dx + (size_t)src * 512 + lane * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dp[k] = accumulate_dx ? dp[k] + acc[k] : acc[k];
+    }
+#pragma unroll
+    for (int n = 0; n < N_MAX; ++n) {
+        if (n < N) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) atomicAdd(&dW[(size_t)n * 512 + lane * 8 + k], gw[n][k]);
+            if (lane == 0 && db) atomicAdd(&db[n], gb[n]);
+        }
+    }
+}
+
+extern "C" int svla_small_linear_fwd_f32(const float* x, const float* W, const float* bias, int rows, int N, int D, int T,
+                                         int B, float* out, void* stream) {
+    if (D != 512 || N <= 0 || N > 32 || rows <= 0) return SVLA_EINVAL;
+    if (T > 0 && T * B != rows) return SVLA_EINVAL;
+    hipLaunchKernelGGL(small_linear_fwd_kernel<32>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, bias,
+                       rows, N, T, B, out);
+    return svla_launch_status();
+}
+
+extern "C" int svla_small_linear_bwd_f32(const float* x, const float* W, const float* dout, int rows, int N, int D, int T,
+                                         int B, int accumulate_dx, float* dx, float* dW, float* db, void* stream) {
+    if (D != 512 || N <= 0 || N > 20 || rows <= 0) return SVLA_EINVAL;
+    if (T > 0 && T * B != rows) return SVLA_EINVAL;
+    int blocks = (rows + 3) / 4;
+    if (blocks > 256) blocks = 256;
+    if (N <= 1)
+        hipLaunchKernelGGL(small_linear_bwd_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, W, dout, rows, N,
+                           T, B, accumulate_dx, dx, dW, db);
+    else
+        hipLaunchKernelGGL(small_linear_bwd_kernel<20>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, W, dout, rows,
+                           N, T, B, accumulate_dx, dx, dW, db);
+    return svla_launch_status();
+}

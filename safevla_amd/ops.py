@@ -1,0 +1,224 @@
+"""Stream-aware Python bindings of the C-ABI kernels (include/svla.h).  torch is plumbing only: device memory
+and the current HIP stream.  Every function launches on ``torch.cuda.current_stream()`` and raises on failure."""
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import lib
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+MASK_NONE, MASK_BLOCK_CAUSAL = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a CUDA/HIP tensor (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+# ------------------------------------------------------------------------------------------------ rollout / losses
+def gae_scan(rewards, costs, values, c_values, masks, next_v, next_cv, gamma=0.99, tau=0.95):
+    """All [T,B] fp32 contiguous (masks [T+1,B]); returns (ret, adv, c_ret, c_adv) each [T,B]."""
+    T, B = rewards.shape[:2]
+    for n, t in (("rewards", rewards), ("costs", costs), ("values", values), ("c_values", c_values), ("masks", masks)):
+        _chk(t, F32, n)
+        assert t.is_contiguous()
+    assert masks.shape[0] == T + 1
+    out = [torch.empty(T, B, device=rewards.device, dtype=F32) for _ in range(4)]
+    lib().call("svla_gae_scan_f32", _p(rewards), _p(costs), _p(values), _p(c_values), _p(masks), _p(next_v), _p(next_cv),
+               float(gamma), float(tau), T, B, *[_p(o) for o in out], _stream())
+    return tuple(out)
+
+
+def ppo_lag_loss_fwd_bwd(logits, values, actions, old_logp, adv, c_adv, returns, old_values, lam, clip, value_coef,
+                         action_w, ent_coef, use_clipped_value, inv_n, sums=None):
+    """logits [R,A] f32, everything else [R]; returns (sums[3] double, dlogits [R,A], dvalues [R])."""
+    R, A = logits.shape
+    _chk(logits, F32, "logits")
+    _chk(actions, torch.int64, "actions")
+    dlogits = torch.empty_like(logits)
+    dvalues = torch.empty(R, device=logits.device, dtype=F32)
+    if sums is None:
+        sums = torch.zeros(3, device=logits.device, dtype=torch.float64)
+    lib().call("svla_ppo_lag_loss_fwd_bwd_f32", _p(logits), _p(values), _p(actions), _p(old_logp), _p(adv), _p(c_adv),
+               _p(returns), _p(old_values), R, A, float(lam), float(clip), float(value_coef), float(action_w),
+               float(ent_coef), int(bool(use_clipped_value)), float(inv_n), _p(dlogits), _p(dvalues), _p(sums), _stream())
+    return sums, dlogits, dvalues
+
+
+def value_mse_fwd_bwd(values, returns, coef, inv_n, sums=None):
+    R = values.numel()
+    dvalues = torch.empty(R, device=values.device, dtype=F32)
+    if sums is None:
+        sums = torch.zeros(1, device=values.device, dtype=torch.float64)
+    lib().call("svla_value_mse_fwd_bwd_f32", _p(values), _p(returns), R, float(coef), float(inv_n), _p(dvalues), _p(sums), _stream())
+    return sums, dvalues
+
+
+def small_linear_fwd(x, W, bias, T=0, B=0):
+    rows, D = x.shape
+    N = W.shape[0]
+    out = torch.empty(rows, N, device=x.device, dtype=F32)
+    lib().call("svla_small_linear_fwd_f32", _p(x), _p(W), _p(bias), rows, N, D, T, B, _p(out), _stream())
+    return out
+
+
+def small_linear_bwd(x, W, dout, dx, dW, db, T=0, B=0, accumulate_dx=False):
+    rows, D = x.shape
+    N = W.shape[0]
+    lib().call("svla_small_linear_bwd_f32", _p(x), _p(W), _p(dout), rows, N, D, T, B, int(accumulate_dx), _p(dx), _p(dW),
+               _p(db), _stream())
+
+
+# ------------------------------------------------------------------------------------------------ norms
+def norm_fwd(x, gamma, beta, eps, rows, D=512, rms=False, relu=False, tok=None, tok_group=0, y=None,
+             xmap=(0, 0, 0), ymap=(0, 0, 0), save_stats=True):
+    _chk(x, BF16, "x")
+    if y is None:
+        y = torch.empty(rows, D, device=x.device, dtype=BF16)
+    mean = torch.empty(rows, device=x.device, dtype=F32) if (save_stats and not rms) else None
+    rstd = torch.empty(rows, device=x.device, dtype=F32) if save_stats else None
+    lib().call("svla_norm_fwd_bf16", _p(x), *xmap, _p(gamma), _p(beta), float(eps), rows, D, int(rms), int(relu), _p(tok),
+               int(tok_group), _p(y), *ymap, _p(mean), _p(rstd), _stream())
+    return y, mean, rstd
+
+
+def norm_bwd(dy, x, gamma, beta, mean, rstd, rows, dgamma, dbeta, D=512, rms=False, relu=False, dtok=None, tok_group=0,
+             dx=None, dymap=(0, 0, 0), xmap=(0, 0, 0), dxmap=(0, 0, 0)):
+    _chk(dy, BF16, "dy")
+    if dx is None:
+        dx = torch.empty(rows, D, device=x.device, dtype=BF16)
+    lib().call("svla_norm_bwd_bf16", _p(dy), *dymap, _p(x), *xmap, _p(gamma), _p(beta), _p(mean), _p(rstd), rows, D, int(rms),
+               int(relu), int(tok_group), _p(dx), *dxmap, _p(dgamma), _p(dbeta), _p(dtok), _stream())
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------ GEMMs
+def gemm_nt(A, B, M, N, K, bias=None, residual=None, relu_mask=None, act=ACT_NONE, out=None, out_f32=False, alpha=1.0,
+            lda=None, ldb=None, ldc=None, ldr=None, ldm=None):
+    """out[M,N] = epi(alpha * A[M,K] @ B[N,K]^T).  A/B bf16; leading dims default to the last-dim stride of 2-D views."""
+    _chk(A, BF16, "A")
+    _chk(B, BF16, "B")
+    lda = lda if lda is not None else A.stride(-2)
+    ldb = ldb if ldb is not None else B.stride(-2)
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=F32 if out_f32 else BF16)
+    ldc = ldc if ldc is not None else out.stride(-2)
+    ldr = ldr if ldr is not None else (residual.stride(-2) if residual is not None else 0)
+    ldm = ldm if ldm is not None else (relu_mask.stride(-2) if relu_mask is not None else 0)
+    lib().call("svla_gemm_nt_bf16", _p(A), lda, _p(B), ldb, _p(bias), _p(residual), ldr, _p(relu_mask), ldm, _p(out), ldc, M, N, K,
+               int(act), int(out_f32), float(alpha), _stream())
+    return out
+
+
+def gemm_tn_acc(dY, X, dW, M, N, K, ldy=None, ldx=None, ldw=None):
+    """dW[N,K] (fp32) += dY[M,N]^T @ X[M,K]."""
+    _chk(dY, BF16, "dY")
+    _chk(X, BF16, "X")
+    _chk(dW, F32, "dW")
+    lib().call("svla_gemm_tn_f32acc", _p(dY), ldy if ldy is not None else dY.stride(-2), _p(X),
+               ldx if ldx is not None else X.stride(-2), _p(dW), ldw if ldw is not None else dW.stride(-2), M, N, K, _stream())
+
+
+def colsum_acc(dY, db, M, N, ldy=None, row_stride=1):
+    lib().call("svla_colsum_bf16", _p(dY), ldy if ldy is not None else dY.stride(-2), M, N, row_stride, _p(db), _stream())
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attn_fwd(q, k, v, ld, rows, S, H, scale, out=None, ldo=None, mask_mode=MASK_NONE, traj=None, bias=None, kvalid=None,
+             save_lse=True):
+    """q/k/v: bf16 views whose element (token, h*64+d) sits at token*ld + h*64 + d."""
+    if out is None:
+        out = torch.empty(rows * S, H * 64, device=q.device, dtype=BF16)
+    ldo = ldo if ldo is not None else out.stride(-2)
+    lse = torch.empty(rows, H, S, device=q.device, dtype=F32) if save_lse else None
+    lib().call("svla_attn_fwd_bf16", _p(q), _p(k), _p(v), ld, _p(out), ldo, _p(lse), rows, S, H, 64, float(scale), mask_mode,
+               _p(traj), _p(bias), _p(kvalid), _stream())
+    return out, lse
+
+
+def attn_bwd(q, k, v, ld, o, ldo, lse, do, lddo, dq, dk, dv, ldd, rows, S, H, scale, mask_mode=MASK_NONE, traj=None,
+             bias=None, kvalid=None):
+    lib().call("svla_attn_bwd_bf16", _p(q), _p(k), _p(v), ld, _p(o), ldo, _p(lse), _p(do), lddo, _p(dq), _p(dk), _p(dv), ldd,
+               rows, S, H, 64, float(scale), mask_mode, _p(traj), _p(bias), _p(kvalid), _stream())
+
+
+# ------------------------------------------------------------------------------------------------ glue
+def feat_to_tokens(feat, out, cam, ncam=2):
+    """feat (R,C,7,12) or (R,C,P) fp32 -> out bf16 [R, ncam, P, C] slot ``cam``."""
+    _chk(feat, F32, "feat")
+    R, C = feat.shape[:2]
+    P = feat[0, 0].numel()
+    lib().call("svla_feat_to_tokens", _p(feat), R, C, P, cam, ncam, _p(out), _stream())
+
+
+def fusion_fill(fusion_token, text, gid, x0, R, S, L, text_off):
+    lib().call("svla_fusion_fill", _p(fusion_token), _p(text), _p(gid), R, S, L, text_off, _p(x0), _stream())
+
+
+def fusion_text_bwd(dx0, gid, T, B, S, L, text_off, dtext):
+    lib().call("svla_fusion_text_bwd", _p(dx0), _p(gid), T, B, S, L, text_off, _p(dtext), _stream())
+
+
+def decoder_embed_fwd(xf, xf_row_stride, act_tab, hand_tab, div_term, prev_actions, masks, hand, time_step, T, B, out,
+                      n_actions=20):
+    lib().call("svla_decoder_embed_fwd", _p(xf), xf_row_stride, _p(act_tab), _p(hand_tab), _p(div_term), _p(prev_actions),
+               _p(masks), _p(hand), _p(time_step), T, B, n_actions, _p(out), _stream())
+
+
+def decoder_embed_bwd(dout, prev_actions, masks, hand, T, B, dxf, dxf_row_stride, d_act_tab, d_hand_tab, n_actions=20):
+    lib().call("svla_decoder_embed_bwd", _p(dout), _p(prev_actions), _p(masks), _p(hand), T, B, n_actions, _p(dxf),
+               dxf_row_stride, _p(d_act_tab), _p(d_hand_tab), _stream())
+
+
+def swiglu_fwd(ab, M, Hd, out=None):
+    if out is None:
+        out = torch.empty(M, Hd, device=ab.device, dtype=BF16)
+    lib().call("svla_swiglu_fwd", _p(ab), M, Hd, _p(out), _stream())
+    return out
+
+
+def swiglu_bwd(ab, dg, M, Hd, dab=None):
+    if dab is None:
+        dab = torch.empty(M, 2 * Hd, device=ab.device, dtype=BF16)
+    lib().call("svla_swiglu_bwd", _p(ab), _p(dg), M, Hd, _p(dab), _stream())
+    return dab
+
+
+def embed_gather(table, ids, out=None):
+    n, D = ids.numel(), table.shape[1]
+    if out is None:
+        out = torch.empty(n, D, device=table.device, dtype=BF16)
+    lib().call("svla_embed_gather_f32_bf16", _p(table), _p(ids), n, D, _p(out), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ optimiser
+def sumsq(g, out):
+    lib().call("svla_sumsq_f32", _p(g), g.numel(), _p(out), _stream())
+
+
+def adam_step(p, g, m, v, p_bf16, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, gnorm_sq=None, max_norm=0.0, grad_scale=1.0):
+    lib().call("svla_adam_step_f32", _p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), float(lr), float(beta1), float(beta2),
+               float(eps), int(step), _p(gnorm_sq), float(max_norm), float(grad_scale), _stream())
+
+
+def cast_bf16(src, dst):
+    lib().call("svla_cast_f32_bf16", _p(src), _p(dst), src.numel(), _stream())
+
+
+def transpose_cast_bf16(src, dst):
+    rows, cols = src.shape
+    lib().call("svla_transpose_cast_f32_bf16", _p(src), rows, cols, _p(dst), _stream())

@@ -1,0 +1,419 @@
+"""Per-kernel parity: every C-ABI entry point (called through the ctypes binding, i.e. through the C ABI) against a
+plain fp32/fp64 torch restatement of the same op on identical seeded inputs.  bf16 kernels are fed bf16-exact inputs,
+so the only differences are accumulation order and the final bf16 rounding (2^-9 relative)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from safevla_amd import ops as o
+
+    return o
+
+
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def bf(x):  # bf16-exact fp32 values
+    return x.to(torch.bfloat16).float()
+
+
+def close(got, want, rtol, atol, name=""):
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    bad = err > tol
+    if bad.any() or not torch.isfinite(got).all():
+        i = int(torch.argmax(err - tol))
+        idx = np.unravel_index(i, got.shape) if got.dim() else ()
+        raise AssertionError(
+            f"{name}: {int(bad.sum())}/{got.numel()} off; worst at {idx}: got {got.flatten()[i]:.6g} want {want.flatten()[i]:.6g}"
+            f" | max abs err {err.max():.3g}, want absmax {want.abs().max():.3g}, finite={bool(torch.isfinite(got).all())}"
+        )
+
+
+# ------------------------------------------------------------------------------------------------ GAE
+@pytest.mark.parametrize("T,B", [(37, 5), (256, 32), (128, 200), (1, 1)])
+def test_gae_bit_exact(ops, T, B):
+    from oracle.ref_rollout import gae_scan
+
+    r, c = rnd(T, B, 1, seed=1), rnd(T, B, 1, seed=2).abs().round()
+    v, cv = rnd(T, B, 1, seed=3), rnd(T, B, 1, seed=4)
+    m = (torch.rand(T + 1, B, 1, generator=torch.Generator().manual_seed(5)) > 0.1).float()
+    nv, ncv = rnd(B, 1, seed=6), rnd(B, 1, seed=7)
+    ret, adv = gae_scan(r, v, m, nv)
+    cret, cadv = gae_scan(c, cv, m, ncv)
+    d = lambda t: t.reshape(t.shape[0], B).contiguous().to(DEV)
+    got = ops.gae_scan(d(r), d(c), d(v), d(cv), d(m), nv.reshape(B).to(DEV), ncv.reshape(B).to(DEV))
+    for g_, w_, n in zip(got, (ret, adv, cret, cadv), ("ret", "adv", "c_ret", "c_adv")):
+        assert torch.equal(g_.cpu(), w_.reshape(T, B)), n  # bit-exact
+
+
+def test_gae_full_size_properties(ops):
+    """C4-size (T=256, B=256): episode boundaries cut the recursion; linear in (rewards)."""
+    T, B = 256, 256
+    r, v = rnd(T, B, seed=1).to(DEV), rnd(T, B, seed=3).to(DEV)
+    z = torch.zeros(T, B, device=DEV)
+    m = (torch.rand(T + 1, B, generator=torch.Generator().manual_seed(5)) > 0.02).float().to(DEV)
+    nv = rnd(B, seed=6).to(DEV)
+    a = ops.gae_scan(r, z, v, z, m, nv, torch.zeros(B, device=DEV))
+    b = ops.gae_scan(2 * r, r, 2 * v, v, m, 2 * nv, nv)
+    close(b[1], 2 * a[1], 1e-5, 1e-5, "linearity")
+    close(b[3], a[1], 1e-5, 1e-5, "cost twin == reward twin on same data")
+    r2 = r.clone()
+    r2[100:] += 50.0
+    m2 = m.clone()
+    m2[100] = 0
+    a1 = ops.gae_scan(r, z, v, z, m2, nv, torch.zeros(B, device=DEV))
+    a2 = ops.gae_scan(r2, z, v, z, m2, nv, torch.zeros(B, device=DEV))
+    assert torch.equal(a1[1][:99], a2[1][:99])
+
+
+# ------------------------------------------------------------------------------------------------ losses
+@pytest.mark.parametrize("clipped", [False, True])
+@pytest.mark.parametrize("lam", [0.0, 0.37, 5.0])
+def test_ppo_lag_loss_vs_reference_golden(ops, lam, clipped):
+    g = dict(np.load(os.path.join(G, "g6_losses.npz")))
+    T, B, A = g["raw_logits"].shape
+    R = T * B
+    t = lambda k: torch.from_numpy(g[k]).reshape(R, *g[k].shape[2:]).contiguous().to(DEV)
+    sums, dl, dv = ops.ppo_lag_loss_fwd_bwd(
+        t("raw_logits"), t("values_pred").reshape(R), t("batch:actions"), t("batch:old_action_log_probs"),
+        t("batch:adv_targ").reshape(R), t("batch:c_adv_targ").reshape(R), t("batch:returns").reshape(R),
+        t("batch:values").reshape(R), lam, 0.1, 0.5, 1.0, 0.01, clipped, 1.0 / R)
+    key = f"safe:{int(clipped)}:{lam}"
+    s = sums.cpu().numpy() / R
+    value, action, ent = (0.5 * s[0], s[1], s[2])
+    total = 0.5 * value + action + 0.01 * ent
+    np.testing.assert_allclose([total, value, action, ent], g[key + ":scalars"], rtol=2e-5)
+    close(dl.reshape(T, B, A), torch.from_numpy(g[key + ":dlogits"]), 1e-4, 1e-8, "dlogits")
+    close(dv.reshape(T, B, 1), torch.from_numpy(g[key + ":dvalues"]), 1e-4, 1e-8, "dvalues")
+
+
+def test_value_mse(ops):
+    v, r = rnd(1000, seed=1), rnd(1000, seed=2)
+    sums, dv = ops.value_mse_fwd_bwd(v.to(DEV), r.to(DEV), 1.0, 1.0 / 1000)
+    vv = v.clone().requires_grad_(True)
+    l = 0.5 * (r - vv).pow(2).mean()
+    l.backward()
+    np.testing.assert_allclose(0.5 * sums.item() / 1000, l.item(), rtol=1e-5)
+    close(dv, vv.grad, 1e-5, 1e-9, "dv")
+
+
+@pytest.mark.parametrize("N,T,B", [(20, 0, 0), (1, 0, 0), (20, 7, 5), (1, 7, 5)])
+def test_small_linear(ops, N, T, B):
+    rows = T * B if T else 37
+    x, W, b = rnd(rows, 512, seed=1), rnd(N, 512, seed=2, scale=0.05), rnd(N, seed=3)
+    out = ops.small_linear_fwd(x.to(DEV), W.to(DEV), b.to(DEV), T, B)
+    xs = x.view(B, T, 512).permute(1, 0, 2).reshape(rows, 512) if T else x  # (b*T+t) storage -> (t*B+b) rows
+    want = xs @ W.t() + b
+    close(out, want, 1e-4, 1e-5, "fwd")
+    dout = rnd(rows, N, seed=4)
+    dx = torch.zeros(rows, 512, device=DEV)
+    dW = torch.ones(N, 512, device=DEV)
+    db = torch.ones(N, device=DEV)
+    ops.small_linear_bwd(x.to(DEV), W.to(DEV), dout.to(DEV), dx, dW, db, T, B)
+    dxs = dout @ W
+    if T:
+        dxs = dxs.view(T, B, 512).permute(1, 0, 2).reshape(rows, 512)
+    close(dx, dxs, 1e-4, 1e-5, "dx")
+    close(dW, 1 + dout.t() @ xs, 1e-4, 1e-4, "dW")
+    close(db, 1 + dout.sum(0), 1e-4, 1e-4, "db")
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("rms", [False, True])
+def test_norm_fwd_bwd_plain(ops, rms):
+    rows = 333
+    x = bf(rnd(rows, 512, seed=1) * 2 + 0.3)
+    gma, bta = 1 + 0.1 * rnd(512, seed=2), 0.1 * rnd(512, seed=3)
+    eps = 1e-5
+    xr = x.clone().requires_grad_(True)
+    gr, br = gma.clone().requires_grad_(True), bta.clone().requires_grad_(True)
+    if rms:
+        want = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + eps) * gr
+    else:
+        want = F.layer_norm(xr, (512,), gr, br, eps)
+    y, mean, rstd = ops.norm_fwd(x.to(DEV).bfloat16(), gma.to(DEV), bta.to(DEV), eps, rows, rms=rms)
+    close(y.float(), want, 8e-3, 8e-3, "y")
+    dy = bf(rnd(rows, 512, seed=4))
+    want.backward(dy)
+    dg, db = torch.zeros(512, device=DEV), torch.zeros(512, device=DEV)
+    dx = ops.norm_bwd(dy.to(DEV).bfloat16(), x.to(DEV).bfloat16(), gma.to(DEV), bta.to(DEV), mean, rstd, rows, dg, db, rms=rms)
+    close(dx.float(), xr.grad, 1e-2, 1e-2, "dx")
+    close(dg, gr.grad, 2e-3, 2e-3 * gr.grad.abs().max().item(), "dgamma")
+    if not rms:
+        close(db, br.grad, 2e-3, 2e-3 * br.grad.abs().max().item(), "dbeta")
+
+
+def test_norm_adapter_rowmap_relu_tok(ops):
+    """Linear->LN->ReLU(+camera token) writing into the [R,S,512] fusion input: rows m=(r*2+cam)*84+p -> r*S+1+m%168."""
+    R, S, Gp = 5, 181, 168
+    rows = R * Gp
+    x = bf(rnd(rows, 512, seed=1))
+    gma, bta, tok = 1 + 0.1 * rnd(512, seed=2), 0.1 * rnd(512, seed=3), rnd(2, 512, seed=4)
+    xr, gr, br, tr = [t.clone().requires_grad_(True) for t in (x, gma, bta, tok)]
+    z = F.relu(F.layer_norm(xr, (512,), gr, br, 1e-5)).view(R, 2, 84, 512) + tr.view(1, 2, 1, 512)
+    x0 = torch.full((R, S, 512), 7.0, device=DEV, dtype=torch.bfloat16)
+    _, mean, rstd = ops.norm_fwd(x.to(DEV).bfloat16(), gma.to(DEV), bta.to(DEV), 1e-5, rows, relu=True, tok=tok.to(DEV),
+                                 tok_group=84, y=x0, ymap=(Gp, S, 1))
+    close(x0[:, 1:169].float(), z.reshape(R, Gp, 512), 8e-3, 8e-3, "y slice")
+    assert (x0[:, 0] == 7).all() and (x0[:, 169:] == 7).all()
+    dx0 = bf(rnd(R, S, 512, seed=5))
+    z.backward(dx0[:, 1:169].reshape(R, 2, 84, 512))
+    dg, db, dt = torch.zeros(512, device=DEV), torch.zeros(512, device=DEV), torch.zeros(2, 512, device=DEV)
+    dx = ops.norm_bwd(dx0.to(DEV).bfloat16(), x.to(DEV).bfloat16(), gma.to(DEV), bta.to(DEV), mean, rstd, rows, dg, db, relu=True,
+                      dtok=dt, tok_group=84, dymap=(Gp, S, 1))
+    close(dx.float(), xr.grad, 1e-2, 1e-2, "dx")
+    close(dg, gr.grad, 2e-3, 2e-3 * gr.grad.abs().max().item(), "dgamma")
+    close(db, br.grad, 2e-3, 2e-3 * br.grad.abs().max().item(), "dbeta")
+    close(dt, tr.grad, 2e-3, 2e-3 * tr.grad.abs().max().item(), "dtok")
+
+
+def test_norm_fwd_384(ops):
+    x = bf(rnd(100, 384, seed=1))
+    gma, bta = 1 + 0.1 * rnd(384, seed=2), 0.1 * rnd(384, seed=3)
+    y, _, _ = ops.norm_fwd(x.to(DEV).bfloat16(), gma.to(DEV), bta.to(DEV), 1e-6, 100, D=384)
+    close(y.float(), F.layer_norm(x, (384,), gma, bta, 1e-6), 8e-3, 8e-3, "y384")
+
+
+# ------------------------------------------------------------------------------------------------ GEMMs
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 128, 64), (1000, 512, 512), (777, 1536, 384), (2500, 512, 2048)])
+def test_gemm_nt_plain(ops, M, N, K):
+    A, B = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2) / math.sqrt(K))
+    out = ops.gemm_nt(A.to(DEV).bfloat16(), B.to(DEV).bfloat16(), M, N, K)
+    close(out.float(), A @ B.t(), 6e-3, 6e-3, "C")
+
+
+def test_gemm_nt_epilogues(ops):
+    M, N, K = 650, 256, 192
+    A, B = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2) / math.sqrt(K))
+    bias, res, msk = rnd(N, seed=3), bf(rnd(M, N, seed=4)), bf(rnd(M, N, seed=5))
+    d = lambda t: t.to(DEV).bfloat16()
+    base = A @ B.t()
+    close(ops.gemm_nt(d(A), d(B), M, N, K, bias=bias.to(DEV), act=ops.ACT_RELU).float(), F.relu(base + bias), 6e-3, 6e-3, "bias+relu")
+    close(ops.gemm_nt(d(A), d(B), M, N, K, bias=bias.to(DEV), residual=d(res)).float(), bf(base + bias) + res, 8e-3, 8e-3, "bias+res")
+    close(ops.gemm_nt(d(A), d(B), M, N, K, relu_mask=d(msk), residual=d(res)).float(), bf(base) * (msk > 0) + res, 8e-3, 8e-3, "mask+res")
+    close(ops.gemm_nt(d(A), d(B), M, N, K, bias=bias.to(DEV), act=ops.ACT_GELU).float(), F.gelu(base + bias), 6e-3, 6e-3, "gelu")
+    o32 = ops.gemm_nt(d(A), d(B), M, N, K, bias=bias.to(DEV), out_f32=True, alpha=0.5)
+    assert o32.dtype == torch.float32
+    close(o32, 0.5 * base + bias, 1e-4, 1e-4, "f32 out")
+    # strided views: A is a column slice of a wider matrix, C a column slice of a wider output
+    wide = bf(rnd(M, 3 * K, seed=6))
+    outw = torch.zeros(M, 2 * N, device=DEV, dtype=torch.bfloat16)
+    wd = d(wide)
+    ops.gemm_nt(wd[:, K : 2 * K], d(B), M, N, K, out=outw[:, N:], lda=3 * K, ldc=2 * N)
+    close(outw[:, N:].float(), wide[:, K : 2 * K] @ B.t(), 6e-3, 6e-3, "strided")
+    assert (outw[:, :N] == 0).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (1000, 128, 128), (5000, 512, 384), (3001, 1536, 512), (20000, 512, 2048)])
+def test_gemm_tn(ops, M, N, K):
+    dY, X = bf(rnd(M, N, seed=1)), bf(rnd(M, K, seed=2))
+    dW = torch.ones(N, K, device=DEV)
+    ops.gemm_tn_acc(dY.to(DEV).bfloat16(), X.to(DEV).bfloat16(), dW, M, N, K)
+    want = 1 + dY.double().t() @ X.double()
+    close(dW, want, 2e-4, 2e-4 * math.sqrt(M), "dW")
+
+
+def test_colsum(ops):
+    for M, N, rs in ((1000, 512, 1), (333, 2048, 1), (50, 512, 181), (100, 1536, 1)):
+        dY = bf(rnd(M * rs, N, seed=1))
+        db = torch.ones(N, device=DEV)
+        ops.colsum_acc(dY.to(DEV).bfloat16(), db, M, N, row_stride=rs)
+        close(db, 1 + dY[::rs].sum(0), 1e-4, 1e-3, f"colsum {M} {N} {rs}")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attn_ref(q, k, v, scale, mask=None, bias=None):
+    s = (q @ k.transpose(-1, -2)) * scale
+    if bias is not None:
+        s = s + bias
+    if mask is not None:
+        s = s.masked_fill(~mask, float("-inf"))
+    return torch.softmax(s, -1) @ v
+
+
+def _attn_case(ops, rows, S, H, mask_mode=0, traj=None, bias=None, kvalid=None, scale=0.125, bwd=True, seed=0):
+    qkv = bf(rnd(rows * S, 3 * H * 64, seed=seed + 1))
+    d_qkv = qkv.to(DEV).bfloat16()
+    ld = 3 * H * 64
+    q, k, v = [qkv[:, i * H * 64 : (i + 1) * H * 64].view(rows, S, H, 64).transpose(1, 2).clone().requires_grad_(True) for i in range(3)]
+    mask = None
+    if mask_mode == 1:
+        mask = torch.tril(traj[:, :, None] == traj[:, None, :])[:, None]
+    if kvalid is not None:
+        km = kvalid.bool()[:, None, None, :]
+        mask = km if mask is None else (mask & km)
+    want = attn_ref(q, k, v, scale, mask, bias[None] if bias is not None else None)
+    out, lse = ops.attn_fwd(d_qkv, d_qkv[:, H * 64 :], d_qkv[:, 2 * H * 64 :], ld, rows, S, H, scale, mask_mode=mask_mode,
+                            traj=None if traj is None else traj.int().to(DEV), bias=None if bias is None else bias.to(DEV),
+                            kvalid=None if kvalid is None else kvalid.to(torch.uint8).to(DEV))
+    close(out.float().view(rows, S, H, 64), want.transpose(1, 2), 1e-2, 1e-2, f"O S={S}")
+    if not bwd:
+        return
+    do = bf(rnd(rows * S, H * 64, seed=seed + 2))
+    want.backward(do.view(rows, S, H, 64).transpose(1, 2))
+    dqkv = torch.zeros_like(d_qkv)
+    ops.attn_bwd(d_qkv, d_qkv[:, H * 64 :], d_qkv[:, 2 * H * 64 :], ld, out, H * 64, lse, do.to(DEV).bfloat16(), H * 64,
+                 dqkv, dqkv[:, H * 64 :], dqkv[:, 2 * H * 64 :], ld, rows, S, H, scale, mask_mode=mask_mode,
+                 traj=None if traj is None else traj.int().to(DEV), bias=None if bias is None else bias.to(DEV),
+                 kvalid=None if kvalid is None else kvalid.to(torch.uint8).to(DEV))
+    for i, (n, t) in enumerate((("dQ", q), ("dK", k), ("dV", v))):
+        got = dqkv[:, i * H * 64 : (i + 1) * H * 64].float().view(rows, S, H, 64)
+        w = t.grad.transpose(1, 2)
+        close(got, w, 2e-2, 2e-2 * w.abs().max().item() + 1e-3, f"{n} S={S}")
+
+
+@pytest.mark.parametrize("S", [5, 16, 64, 100, 181, 192, 233, 256])
+def test_attn_nomask(ops, S):
+    _attn_case(ops, 3, S, 8)
+
+
+def test_attn_block_causal(ops):
+    for S, rows in ((128, 4), (256, 2), (32, 3)):
+        g = torch.Generator().manual_seed(S)
+        traj = torch.cumsum((torch.rand(rows, S, generator=g) < 0.05).long(), dim=1) + 3
+        _attn_case(ops, rows, S, 8, mask_mode=1, traj=traj)
+
+
+def test_attn_t5_bias_and_padding(ops):
+    rows, S, H = 5, 11, 8
+    bias = rnd(H, S, S, seed=9)
+    kvalid = torch.ones(rows, S)
+    for i, n in enumerate([11, 4, 7, 1, 9]):
+        kvalid[i, n:] = 0
+    _attn_case(ops, rows, S, H, bias=bias, kvalid=kvalid, scale=1.0, bwd=False)
+
+
+def test_attn_vit_length_fwd(ops):
+    _attn_case(ops, 2, 433, 6, bwd=False)
+
+
+# ------------------------------------------------------------------------------------------------ glue
+def test_feat_to_tokens(ops):
+    R = 7
+    f0, f1 = rnd(R, 384, 7, 12, seed=1), rnd(R, 384, 7, 12, seed=2)
+    out = torch.zeros(R, 2, 84, 384, device=DEV, dtype=torch.bfloat16)
+    ops.feat_to_tokens(f0.to(DEV), out, 0)
+    ops.feat_to_tokens(f1.to(DEV), out, 1)
+    want = torch.stack([f0.flatten(2).permute(0, 2, 1), f1.flatten(2).permute(0, 2, 1)], 1)
+    assert torch.equal(out.float().cpu(), bf(want))
+
+
+def test_fusion_fill_and_text_bwd(ops):
+    T, B, L, S = 9, 4, 6, 181
+    R, U = T * B, 5
+    ft, text = rnd(512, seed=1), bf(rnd(U, L, 512, seed=2))
+    g = torch.Generator().manual_seed(3)
+    gid = torch.zeros(T, B, dtype=torch.int32)
+    cur = torch.randint(0, U, (B,), generator=g)
+    for t in range(T):
+        flip = torch.rand(B, generator=g) < 0.3
+        cur = torch.where(flip, torch.randint(0, U, (B,), generator=g), cur)
+        gid[t] = cur
+    x0 = torch.full((R, S, 512), 3.0, device=DEV, dtype=torch.bfloat16)
+    ops.fusion_fill(ft.to(DEV), text.to(DEV).bfloat16(), gid.reshape(R).to(DEV), x0, R, S, L, 169)
+    assert torch.equal(x0[:, 0].float().cpu(), bf(ft).expand(R, 512))
+    assert torch.equal(x0[:, 169 : 169 + L].float().cpu(), text[gid.reshape(R).long()])
+    assert (x0[:, 1:169] == 3).all() and (x0[:, 169 + L :] == 3).all()
+    dx0 = bf(rnd(R, S, 512, seed=4))
+    dtext = torch.zeros(U, L, 512, device=DEV)
+    ops.fusion_text_bwd(dx0.to(DEV).bfloat16(), gid.reshape(R).to(DEV), T, B, S, L, 169, dtext)
+    want = torch.zeros(U, L, 512).index_add_(0, gid.reshape(R).long(), dx0[:, 169 : 169 + L])
+    close(dtext, want, 1e-5, 1e-5, "dtext")
+
+
+def test_decoder_embed(ops):
+    T, B, S = 6, 5, 181
+    R = T * B
+    g = torch.Generator().manual_seed(0)
+    xf = bf(rnd(R, S, 512, seed=1))
+    act, hand_t = rnd(22, 512, seed=2, scale=0.3), rnd(3, 512, seed=3, scale=0.3)
+    div = torch.exp(torch.arange(0, 512, 2) * (-math.log(10000.0) / 512))
+    pa = torch.randint(0, 20, (T, B), generator=g)
+    masks = (torch.rand(T, B, generator=g) > 0.3).float()
+    hand = torch.randint(0, 2, (T, B), generator=g)
+    ts = torch.randint(0, 500, (T, B), generator=g)
+    out = torch.empty(B * T, 512, device=DEV, dtype=torch.bfloat16)
+    ops.decoder_embed_fwd(xf.to(DEV).bfloat16(), S * 512, act.to(DEV), hand_t.to(DEV), div.to(DEV), pa.to(DEV), masks.to(DEV),
+                          hand.to(DEV), ts.to(DEV), T, B, out)
+    pe = torch.zeros(T, B, 512)
+    pe[..., 0::2] = torch.sin(ts.unsqueeze(-1) * div)
+    pe[..., 1::2] = torch.cos(ts.unsqueeze(-1) * div)
+    idx = torch.where(masks != 0, pa, torch.full_like(pa, 20))
+    want = pe + xf[:, 0].view(T, B, 512) + act[idx] + hand_t[hand]
+    close(out.float().view(B, T, 512).permute(1, 0, 2), want, 8e-3, 8e-3, "joint")
+    dout = bf(rnd(B * T, 512, seed=5))
+    dxf = torch.zeros(R, S, 512, device=DEV, dtype=torch.bfloat16)
+    da, dh = torch.zeros(22, 512, device=DEV), torch.zeros(3, 512, device=DEV)
+    ops.decoder_embed_bwd(dout.to(DEV).bfloat16(), pa.to(DEV), masks.to(DEV), hand.to(DEV), T, B, dxf, S * 512, da, dh)
+    d_tb = dout.view(B, T, 512).permute(1, 0, 2).reshape(R, 512)
+    assert torch.equal(dxf[:, 0].float().cpu(), d_tb) and (dxf[:, 1:] == 0).all()
+    close(da, torch.zeros(22, 512).index_add_(0, idx.reshape(R), d_tb), 1e-5, 1e-4, "d act")
+    close(dh, torch.zeros(3, 512).index_add_(0, hand.reshape(R), d_tb), 1e-5, 1e-4, "d hand")
+
+
+def test_swiglu(ops):
+    M, Hd = 333, 1536
+    ab = bf(rnd(M, 2 * Hd, seed=1))
+    abr = ab.clone().requires_grad_(True)
+    want = F.silu(abr[:, :Hd]) * abr[:, Hd:]
+    g = ops.swiglu_fwd(ab.to(DEV).bfloat16(), M, Hd)
+    close(g.float(), want, 8e-3, 8e-3, "g")
+    dg = bf(rnd(M, Hd, seed=2))
+    want.backward(dg)
+    dab = ops.swiglu_bwd(ab.to(DEV).bfloat16(), dg.to(DEV).bfloat16(), M, Hd)
+    close(dab.float(), abr.grad, 1e-2, 1e-2, "dab")
+
+
+def test_embed_gather_and_casts(ops):
+    tab = rnd(1000, 512, seed=1)
+    ids = torch.randint(0, 1000, (77,), generator=torch.Generator().manual_seed(2))
+    out = ops.embed_gather(tab.to(DEV), ids.to(DEV))
+    assert torch.equal(out.float().cpu(), bf(tab[ids]))
+    w = rnd(1536, 512, seed=3)
+    d1 = torch.empty(1536, 512, device=DEV, dtype=torch.bfloat16)
+    d2 = torch.empty(512, 1536, device=DEV, dtype=torch.bfloat16)
+    ops.cast_bf16(w.to(DEV), d1)
+    ops.transpose_cast_bf16(w.to(DEV), d2)
+    assert torch.equal(d1.float().cpu(), bf(w)) and torch.equal(d2.float().cpu(), bf(w).t())
+
+
+def test_adam_clip_matches_torch(ops):
+    n = 100_003
+    p0, grads = rnd(n, seed=1), [rnd(n, seed=10 + i, scale=0.01 * (i + 1)) for i in range(3)]
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pt], lr=2e-5)
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pb = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    for i, g in enumerate(grads):
+        pt.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([pt], 0.5)
+        opt.step()
+        gd = g.to(DEV)
+        ss = torch.zeros(1, device=DEV, dtype=torch.float64)
+        ops.sumsq(gd, ss)
+        np.testing.assert_allclose(ss.item(), float(g.double().pow(2).sum()), rtol=1e-6)
+        ops.adam_step(p, gd, m, v, pb, 2e-5, i + 1, gnorm_sq=ss, max_norm=0.5)
+    close(p, pt.data, 1e-6, 1e-7, "adam p")
+    assert torch.equal(pb.float().cpu(), bf(p.cpu()))
