@@ -6,8 +6,7 @@
 // GAE reverse scan, reward and cost twins fused.  One thread per env (coalesced over B), sequential in T.
 // Restates AllenAct RolloutStorage.compute_returns(use_gae=True) [3P; SURVEY.md App. C]:
 //   delta = r[t] + gamma*V[t+1]*m[t+1] - V[t];  g = delta + (gamma*tau)*m[t+1]*g;  ret[t] = g + V[t];  adv = ret - V
-// The explicit __f*_rn calls pin the evaluation order / no-FMA-contraction so results are bit-identical
-// to the fp32 torch oracle.
+// FP contraction is switched off in the kernel body so results are bit-identical to the fp32 torch oracle.
 template <int UNROLL>
 __global__ void gae_scan_kernel(const float* __restrict__ rewards, const float* __restrict__ costs,
                                 const float* __restrict__ values, const float* __restrict__ c_values,
@@ -15,6 +14,7 @@ __global__ void gae_scan_kernel(const float* __restrict__ rewards, const float* 
                                 const float* __restrict__ next_cv, float gamma, float gamma_tau, int T, int B,
                                 float* __restrict__ ret, float* __restrict__ adv, float* __restrict__ c_ret,
                                 float* __restrict__ c_adv) {
+#pragma clang fp contract(off)  // forbid FMA contraction: evaluation order/rounding identical to the fp32 torch oracle
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     float g = 0.f, gc = 0.f, vn = next_v[b], cvn = next_cv[b];
@@ -34,15 +34,16 @@ __global__ void gae_scan_kernel(const float* __restrict__ rewards, const float* 
             const int tt = t - u;
             if (tt < 0) break;
             const size_t i = (size_t)tt * B + b;
-            float d = __fsub_rn(__fadd_rn(r[u], __fmul_rn(__fmul_rn(gamma, vn), m[u])), v[u]);
-            g = __fadd_rn(d, __fmul_rn(__fmul_rn(gamma_tau, m[u]), g));
-            const float rt = __fadd_rn(g, v[u]);
-            ret[i] = rt; adv[i] = __fsub_rn(rt, v[u]);
+            // plain operators (not the __f*_rn wrappers: those are inline functions outside this pragma's scope)
+            const float d = (r[u] + (gamma * vn) * m[u]) - v[u];
+            g = d + (gamma_tau * m[u]) * g;
+            const float rt = g + v[u];
+            ret[i] = rt; adv[i] = rt - v[u];
             vn = v[u];
-            float dc = __fsub_rn(__fadd_rn(c[u], __fmul_rn(__fmul_rn(gamma, cvn), m[u])), cv[u]);
-            gc = __fadd_rn(dc, __fmul_rn(__fmul_rn(gamma_tau, m[u]), gc));
-            const float crt = __fadd_rn(gc, cv[u]);
-            c_ret[i] = crt; c_adv[i] = __fsub_rn(crt, cv[u]);
+            const float dc = (c[u] + (gamma * cvn) * m[u]) - cv[u];
+            gc = dc + (gamma_tau * m[u]) * gc;
+            const float crt = gc + cv[u];
+            c_ret[i] = crt; c_adv[i] = crt - cv[u];
             cvn = cv[u];
         }
     }
