@@ -56,8 +56,8 @@ int svla_norm_fwd_bf16(const svla_bf16* x, int xG, int xGS, int xOFF, const floa
                        float* mean, float* rstd, void* stream);
 int svla_norm_bwd_bf16(const svla_bf16* dy, int dyG, int dyGS, int dyOFF, const svla_bf16* x, int xG, int xGS, int xOFF,
                        const float* gamma, const float* beta, const float* mean, const float* rstd, int rows, int D, int rms,
-                       int relu, int tok_group, svla_bf16* dx, int dxG, int dxGS, int dxOFF, float* dgamma, float* dbeta,
-                       float* dtok, void* stream);
+                       int relu, int tok_group, const svla_bf16* dres, svla_bf16* dx, int dxG, int dxGS, int dxOFF, float* dgamma,
+                       float* dbeta, float* dtok, void* stream);
 
 /* ---- GEMMs (MFMA bf16, fp32 accumulate) --------------------------------------------------------------------- */
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear / 1x1 nn.Conv2d of the policy
@@ -105,6 +105,9 @@ int svla_decoder_embed_bwd(const svla_bf16* dout, const int64_t* prev_actions, c
 /* llama FeedForward gate silu(a)*b (llama/model.py:359-360) on [a | b] rows. */
 int svla_swiglu_fwd(const svla_bf16* ab, long M, int Hd, svla_bf16* g, void* stream);
 int svla_swiglu_bwd(const svla_bf16* ab, const svla_bf16* dg, long M, int Hd, svla_bf16* dab, void* stream);
+/* 64-bit content hash of fixed-width byte rows: de-duplicates the per-row goal strings that the reference tokenises
+ * one by one on the host (allenact_dino_transformer.py:591-603; row format utils/string_utils.py:11-18). */
+int svla_row_hash_u8(const unsigned char* rows, long n_rows, int row_bytes, int64_t* out, void* stream);
 /* T5 shared-embedding gather (HF T5EncoderModel called at allenact_dino_transformer.py:603). */
 int svla_embed_gather_f32_bf16(const float* table, const int64_t* ids, long n, int D, svla_bf16* out, void* stream);
 

@@ -322,3 +322,31 @@ extern "C" int svla_embed_gather_f32_bf16(const float* table, const int64_t* ids
     hipLaunchKernelGGL(embed_gather_kernel, dim3((int)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, table, ids, n, D, out);
     return svla_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Order-independent 64-bit content hash of byte rows: h = sum_i (byte_i + 1) * mix(i).  One wave per row.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void row_hash_kernel(const unsigned char* __restrict__ rows, long n_rows, int row_bytes, int64_t* __restrict__ out) {
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= n_rows) return;
+    const unsigned char* p = rows + (size_t)wave * row_bytes;
+    uint64_t h = 0;
+    for (int i = lane; i < row_bytes; i += 64) h += (uint64_t)(p[i] + 1u) * splitmix64((uint64_t)i);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)h, o, 64), hi = __shfl_xor((uint32_t)(h >> 32), o, 64);
+        h += ((uint64_t)hi << 32) | lo;
+    }
+    if (lane == 0) out[wave] = (int64_t)(h >> 1);  // keep it non-negative
+}
+extern "C" int svla_row_hash_u8(const unsigned char* rows, long n_rows, int row_bytes, int64_t* out, void* stream) {
+    if (n_rows <= 0 || row_bytes <= 0) return SVLA_EINVAL;
+    hipLaunchKernelGGL(row_hash_kernel, dim3((int)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rows, n_rows, row_bytes, out);
+    return svla_launch_status();
+}

@@ -85,8 +85,9 @@ template <int D>
 __global__ void norm_bwd_kernel(const bf16_t* __restrict__ dy, RowMap dymap, const bf16_t* __restrict__ x, RowMap xmap,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                 const float* __restrict__ mean, const float* __restrict__ rstd_in, int rows, int rms,
-                                int relu, int tok_group, bf16_t* __restrict__ dx, RowMap dxmap,
-                                float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dtok) {
+                                int relu, int tok_group, const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
+                                RowMap dxmap, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                float* __restrict__ dtok) {
     constexpr int VPL = D / 64;
     __shared__ float red[4][4 * D];  // [wave][dgamma | dbeta | dtok0 | dtok1]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -121,6 +122,12 @@ __global__ void norm_bwd_kernel(const bf16_t* __restrict__ dy, RowMap dymap, con
         s2 = wave_sum(s2) * (1.f / D);
 #pragma unroll
         for (int i = 0; i < VPL; ++i) xv[i] = rs * (gg[i] - s1 - xh[i] * s2);
+        if (dres) {  // residual-branch gradient (pre-norm blocks: d h = d out + norm_bwd(...))
+            float rv[VPL];
+            load_row_bf16<VPL>(dres + (size_t)m * D + lane * VPL, rv);
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) xv[i] += rv[i];
+        }
         store_row_bf16<VPL>(dx + map_row(dxmap, m) * D + lane * VPL, xv);
     }
 #pragma unroll
@@ -164,14 +171,14 @@ extern "C" int svla_norm_fwd_bf16(const bf16_t* x, int xG, int xGS, int xOFF, co
 
 extern "C" int svla_norm_bwd_bf16(const bf16_t* dy, int dyG, int dyGS, int dyOFF, const bf16_t* x, int xG, int xGS, int xOFF,
                                   const float* gamma, const float* beta, const float* mean, const float* rstd, int rows,
-                                  int D, int rms, int relu, int tok_group, bf16_t* dx, int dxG, int dxGS, int dxOFF,
-                                  float* dgamma, float* dbeta, float* dtok, void* stream) {
+                                  int D, int rms, int relu, int tok_group, const bf16_t* dres, bf16_t* dx, int dxG, int dxGS,
+                                  int dxOFF, float* dgamma, float* dbeta, float* dtok, void* stream) {
     if (rows <= 0 || D != 512) return SVLA_EINVAL;
     if (dtok && tok_group <= 0) return SVLA_EINVAL;
     RowMap dym{dyG, dyGS, dyOFF}, xm{xG, xGS, xOFF}, dxm{dxG, dxGS, dxOFF};
     int blocks = norm_grid(rows);
     if (blocks > 512) blocks = 512;  // fewer, fatter blocks: each ends with 4*D atomics
     hipLaunchKernelGGL(norm_bwd_kernel<512>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, dym, x, xm, gamma, beta, mean,
-                       rstd, rows, rms, relu, tok_group > 0 ? tok_group : 1, dx, dxm, dgamma, dbeta, dtok);
+                       rstd, rows, rms, relu, tok_group > 0 ? tok_group : 1, dres, dx, dxm, dgamma, dbeta, dtok);
     return svla_launch_status();
 }

@@ -96,12 +96,12 @@ def norm_fwd(x, gamma, beta, eps, rows, D=512, rms=False, relu=False, tok=None, 
 
 
 def norm_bwd(dy, x, gamma, beta, mean, rstd, rows, dgamma, dbeta, D=512, rms=False, relu=False, dtok=None, tok_group=0,
-             dx=None, dymap=(0, 0, 0), xmap=(0, 0, 0), dxmap=(0, 0, 0)):
+             dx=None, dymap=(0, 0, 0), xmap=(0, 0, 0), dxmap=(0, 0, 0), dres=None):
     _chk(dy, BF16, "dy")
     if dx is None:
         dx = torch.empty(rows, D, device=x.device, dtype=BF16)
     lib().call("svla_norm_bwd_bf16", _p(dy), *dymap, _p(x), *xmap, _p(gamma), _p(beta), _p(mean), _p(rstd), rows, D, int(rms),
-               int(relu), int(tok_group), _p(dx), *dxmap, _p(dgamma), _p(dbeta), _p(dtok), _stream())
+               int(relu), int(tok_group), _p(dres), _p(dx), *dxmap, _p(dgamma), _p(dbeta), _p(dtok), _stream())
     return dx
 
 
@@ -195,6 +195,15 @@ def swiglu_bwd(ab, dg, M, Hd, dab=None):
         dab = torch.empty(M, 2 * Hd, device=ab.device, dtype=BF16)
     lib().call("svla_swiglu_bwd", _p(ab), _p(dg), M, Hd, _p(dab), _stream())
     return dab
+
+
+def row_hash(rows_u8):
+    """rows_u8: contiguous 2-D byte view [n, row_bytes] (any dtype reinterpreted) -> int64 [n] content hashes."""
+    n = rows_u8.shape[0]
+    row_bytes = rows_u8[0].numel() * rows_u8.element_size()
+    out = torch.empty(n, device=rows_u8.device, dtype=torch.int64)
+    lib().call("svla_row_hash_u8", _p(rows_u8), n, row_bytes, _p(out), _stream())
+    return out
 
 
 def embed_gather(table, ids, out=None):
