@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s through the PPO-Lagrangian update on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = ONE full PPO-Lagrangian update over a synthetic rollout already resident in HBM:
+  reward+cost GAE  ->  lambda update  ->  update_repeats(4) x [3 towers x (forward, fused loss, backward),
+  all-reduce of the flat gradient arena, global-norm clip + Adam].
+Workload at N=1 = one GPU's shard of BASELINE.json configs[3] ("Fetch, 256 envs sharded 8xMI355X, 256-step rollout"):
+T=256 steps x 32 envs per GPU, 12 goal tokens; weak scaling (32 envs per GPU at every N).
+Prints ONE JSON line (rank 0) with the roofline of the dominant kernel (the bf16 MFMA GEMM, timed with HIP events on
+its launch stream in a separate instrumented update) and a CPU baseline (the fp32 oracle port on the host cores, bounded
+sample).  The oracle is only the checker/baseline leg here -- the measured path is the HIP library.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def flops_per_update(R, S, L, U, epochs):
+    """Algorithmic FLOPs (2*MAC) of the trainable path, SURVEY.md section 8(d): per row per tower forward,
+    x3 (fwd + 2x bwd) x 3 towers x epochs.  Frozen T5 (once per unique goal) excluded."""
+    d = 512
+    fusion = 3 * S * (4 * d * d + 2 * d * 2048 + 2 * S * d) * 2
+    compress = 2 * 84 * (384 * d + d * d + d * d) * 2
+    text = L * d * d * 2
+    decoder = 3 * (4 * d * d + 3 * d * 1536 + 2 * 256 * d) * 2 + d * d * 2 + 21 * d * 2
+    return R * 3 * 3 * epochs * (fusion + compress + decoder) + U * 3 * 3 * epochs * text
+
+
+class GemmTimer:
+    """HIP-event timing of every svla_gemm_nt_bf16 launch on the launch stream (torch's current stream)."""
+
+    def __init__(self, ops):
+        self.ops, self.rec = ops, []
+        self.orig = ops.gemm_nt
+
+    def __enter__(self):
+        def wrapped(A, B, M, N, K, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self.orig(A, B, M, N, K, **kw)
+            e1.record()
+            self.rec.append((e0, e1, 2.0 * M * N * K, M * K * 2 + N * K * 2 + M * N * (4 if kw.get("out_f32") else 2)))
+            return out
+
+        self.ops.gemm_nt = wrapped
+        return self
+
+    def __exit__(self, *a):
+        self.ops.gemm_nt = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = [e0.elapsed_time(e1) for e0, e1, _, _ in self.rec]
+        fl = sum(f for _, _, f, _ in self.rec)
+        by = sum(b for _, _, _, b in self.rec)
+        tot = sum(ms) * 1e-3
+        return dict(launches=len(ms), avg_ms=sum(ms) / max(1, len(ms)), tflops=fl / tot / 1e12, flops_per_launch=fl / max(1, len(ms)),
+                    min_bytes_per_launch=by / max(1, len(ms)), total_s=tot)
+
+
+def cpu_baseline(T=8, B=4, L=12):
+    """fp32 CPU port (oracle) of the same update on a bounded sample: one epoch = 3-tower forward, SafePPOLogGrad +
+    SafePPOValue, backward, clip 0.5, Adam; env-steps/s = T*B / (4 epochs)."""
+    import numpy as np
+
+    from oracle import ref_loss, ref_model
+    from safevla_amd.text import GoalTokenizer
+
+    n = min(16, os.cpu_count() or 1)   # more threads only add fork/join overhead on these op sizes (measured: 256 threads 40x slower)
+    torch.set_num_threads(n)
+    torch.manual_seed(0)
+
+    class _Tok:  # fixed-length synthetic ids, same as the GPU workload
+        def __call__(self, goals, return_tensors="pt", padding=True):
+            ids = torch.randint(3, 32000, (len(goals), L))
+            return {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
+
+    m = ref_model.RefSafeActorCritic(_Tok(), max_steps=500, max_batch=B).eval()
+    params = [p for n_, p in m.named_parameters() if "text_encoder" not in n_]
+    opt = torch.optim.Adam(params, lr=2e-5)
+    obs = {"rgb_dinov2": torch.randn(T, B, 384, 7, 12), "manipulation_rgb_dinov2": torch.randn(T, B, 384, 7, 12),
+           "natural_language_spec": torch.zeros(T, B, 1000, dtype=torch.uint8), "time_step": torch.arange(T)[:, None].expand(T, B).contiguous(),
+           "traj_index": torch.zeros(T, B, dtype=torch.int64), "an_object_is_in_hand": torch.zeros(T, B, 1, dtype=torch.int64)}
+    batch = {"actions": torch.randint(0, 20, (T, B)), "old_action_log_probs": torch.full((T, B), -3.0), "adv_targ": torch.randn(T, B, 1),
+             "c_adv_targ": torch.randn(T, B, 1), "returns": torch.randn(T, B, 1), "values": torch.randn(T, B, 1), "c_returns": torch.randn(T, B, 1)}
+    pa, mk = torch.randint(0, 20, (T, B)), torch.ones(T, B, 1)
+    t0 = time.time()
+    opt.zero_grad()
+    out, _ = m(obs, None, pa, mk)
+    total, _ = ref_loss.safe_ppo_log_grad(out["logits"], out["values"], batch, 0.1)
+    (total + ref_loss.safe_ppo_value(out["c_values"], batch["c_returns"])).backward()
+    torch.nn.utils.clip_grad_norm_(params, 0.5)
+    opt.step()
+    dt = time.time() - t0
+    return {"value": T * B / (4.0 * dt), "unit": "env-steps/s", "cores": n, "kind": "port",
+            "sample": f"fp32 torch-CPU oracle, 1 of 4 epochs timed on T={T} x B={B} rows ({dt:.1f} s), L={L}, dropout off, scaled x4"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--T", type=int, default=256)
+    ap.add_argument("--envs-per-gpu", type=int, default=32)
+    ap.add_argument("--L", type=int, default=12)
+    ap.add_argument("--task", default="Fetch")
+    ap.add_argument("--env-chunk", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from safevla_amd import ops, parallel
+    from safevla_amd.engine import PPOLagConfig, PPOLagEngine
+    from safevla_amd.model import SafeDinoLLAMATxNavActorCriticSeparate
+    from safevla_amd.synth_env import SynthSpec, fill_synthetic_rollout
+
+    rank, local, world = parallel.init_from_env()
+    assert world == max(1, args.gpus) or world == 1, (world, args.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.manual_seed(1234 + rank)
+    model = SafeDinoLLAMATxNavActorCriticSeparate(device=dev)
+    if world > 1:  # identical initial weights on every rank
+        torch.distributed.broadcast(model.arena.flat_p, src=0)
+        for t in model.towers:
+            for p in t.visual_encoder.text_encoder.parameters():
+                torch.distributed.broadcast(p.data, src=0)
+        model.sync_weights()
+    T, B = args.T, args.envs_per_gpu
+    cfg = PPOLagConfig(env_chunk=args.env_chunk or None)
+    eng = PPOLagEngine(model, cfg)
+    st, nxt, ep = fill_synthetic_rollout(model, SynthSpec(T=T, B=B, L=args.L, task=args.task, seed=1234 + rank), device=dev)
+
+    def step():
+        return eng.update(st, nxt["next_value"], nxt["next_c_value"], ep["episode_cost_sum"], ep["n_episodes"])
+
+    for _ in range(args.warmup):
+        info = step()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info = step()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = tt.item()
+    ms = dt / args.steps * 1e3
+    env_steps = T * B * world
+    S, R = 169 + args.L, T * B
+    U = int(st.observations["goal_token_ids"][:T].reshape(R, -1).unique(dim=0).shape[0])
+    algo = flops_per_update(R, S, args.L, U, cfg.update_repeats)
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        with GemmTimer(ops) as gt:
+            step()
+        g = gt.summary()
+        roof = {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel (svla_gemm_nt_bf16)", "achieved": round(g["tflops"], 1), "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(g["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_per_update": g["launches"],
+                "avg_launch_ms": round(g["avg_ms"], 4), "flops_per_launch": g["flops_per_launch"], "gemm_nt_share_of_update": round(g["total_s"] / (ms * 1e-3), 3)}
+    if world > 1:
+        parallel.barrier()
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(L=args.L)
+    if rank == 0:
+        out = {"metric": "env-steps/sec through PPO-Lagrangian update", "value": round(env_steps / (ms * 1e-3), 1), "unit": "env-steps/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"C4-shard: {args.task}, T={T}-step rollout x {B} envs/GPU (BASELINE configs[3] per-GPU shard), "
+                                      f"L={args.L} goal tokens, S={S} fusion tokens, 3 towers x 4 epochs x 1 minibatch, Adam+clip",
+                          "global_envs": B * world, "rollout_steps": T, "rows_per_gpu": R, "parallelism": f"dp{world}",
+                          "stage_losses": list(cfg.stage_losses), "weights": "random-init, reference geometry (168.9 M params)"},
+               "update_algorithmic_tflop": round(algo / 1e12, 1), "update_tflops_per_gpu": round(algo / (ms * 1e-3) / 1e12, 1),
+               "loss": {k: (round(v, 5) if isinstance(v, float) else v) for k, v in info.items()},
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

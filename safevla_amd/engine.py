@@ -1,0 +1,133 @@
+"""PPO-Lagrangian update engine (single- and multi-GPU).
+
+Replaces the update half of the AllenAct-fork ``OnPolicyTrainer`` [3P, not in /root/reference] as configured by the
+reference's ``training_pipeline()`` (/root/reference/training/online/dinov2_vits_tsfm_base.py:293-380):
+Adam(lr), ``num_mini_batch=1``, ``update_repeats=4``, ``max_grad_norm=0.5``, gamma 0.99, GAE lambda 0.95, stage loss
+lists, ``cost_limit`` via ``start_train(cost_limit=...)`` (/root/reference/training/online/allenact_trainer.py:63-72).
+
+One update = GAE(reward+cost) -> lambda update -> update_repeats x num_mini_batch x
+   [zero grads; per env-chunk: 3 x (tower forward, fused loss fwd+bwd, tower backward); all-reduce flat grads;
+    global-norm clip + Adam (one fused launch over the flat arena); refresh bf16 transposes].
+Towers run one after another (each tower's loss depends only on its own outputs), so only one tower's activations are
+resident at a time; env-chunking gives exact gradient accumulation because every loss is a mean over rows
+(inv_n = 1 / global rows).
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops, parallel
+from .lagrange import Lagrange
+from .model import N_ACTIONS, SafeDinoLLAMATxNavActorCriticSeparate
+from .storage import RolloutStorage
+
+
+@dataclass
+class PPOLagConfig:
+    update_repeats: int = 4
+    num_mini_batch: int = 1
+    lr: float = 2e-5
+    max_grad_norm: float = 0.5
+    gamma: float = 0.99
+    gae_lambda: float = 0.95
+    clip_param: float = 0.1
+    value_loss_coef: float = 0.5
+    entropy_coef: float = 0.0
+    action_weight: float = 1.0
+    stage_losses: Tuple[str, ...] = ("ppo_log_loss", "safe_ppo_value_loss")
+    cost_limit: float = 2.31964          # README.md:255 example
+    lambda_init: float = 0.001
+    lambda_lr: float = 0.035
+    lambda_optimizer: str = "Adam"
+    lambda_upper_bound: Optional[float] = None
+    env_chunk: Optional[int] = None       # envs per micro-batch (None: whole local minibatch)
+    adam_betas: Tuple[float, float] = (0.9, 0.999)
+    adam_eps: float = 1e-8
+
+
+class PPOLagEngine:
+    def __init__(self, model: SafeDinoLLAMATxNavActorCriticSeparate, cfg: PPOLagConfig):
+        self.model, self.cfg = model, cfg
+        self.lagrange = Lagrange(cfg.cost_limit, cfg.lambda_init, cfg.lambda_lr, cfg.lambda_optimizer, cfg.lambda_upper_bound)
+        self.opt_step = 0
+        dev = model.device_
+        self._gnorm_sq = torch.zeros(1, device=dev, dtype=torch.float64)
+        self._sums = torch.zeros(5, device=dev, dtype=torch.float64)   # v_sq, action, -entropy, (pad), c_v_sq
+        self.gemm_flops = 0
+
+    # ---- one minibatch: forward/backward of the three towers with fused losses ------------------------------------
+    def _accumulate(self, batch: Dict, n_total: int, lam: float):
+        cfg, m = self.cfg, self.model
+        T, Bc = batch["actions"].shape
+        R = T * Bc
+        inv_n = 1.0 / float(n_total)
+        prep = m.prepare(batch["observations"], batch["prev_actions"], batch["masks"])
+        f = lambda t: t.reshape(R).contiguous()
+        names = set(cfg.stage_losses)
+        sums = self._sums
+        if "ppo_log_loss" in names:
+            # actor: clipped surrogate on the lambda-mixed advantage (+ entropy); critic: value_loss_coef * 0.5 * mse
+            logits, _, c = m.run_forward(prep, need_grad=True)
+            ret = f(batch["returns"])
+            _, dl, _ = ops.ppo_lag_loss_fwd_bwd(logits.reshape(R, N_ACTIONS), ret, f(batch["actions"]), f(batch["old_action_log_probs"]),
+                                                f(batch["adv_targ"]), f(batch["c_adv_targ"]), ret, None, lam, cfg.clip_param, 0.0,
+                                                cfg.action_weight, cfg.entropy_coef, False, inv_n, sums=sums[0:3])
+            m.run_backward(prep, c, dl.view(T, Bc, N_ACTIONS), None)
+            del c, logits, dl
+        if "ppo_log_loss" in names or "ppo_value_loss" in names:
+            coef = cfg.value_loss_coef if "ppo_log_loss" in names else 1.0
+            tw = m.critic_tsfm
+            _, values, c = tw.run_forward(prep, need_grad=True)
+            _, dv = ops.value_mse_fwd_bwd(values.reshape(R), f(batch["returns"]), coef, inv_n, sums=sums[0:1])
+            tw.run_backward(prep, c, None, dv.view(T, Bc, 1))
+            del c, values, dv
+        if "safe_ppo_value_loss" in names:
+            tw = m.c_critic_tsfm
+            _, c_values, c = tw.run_forward(prep, need_grad=True)
+            _, dv = ops.value_mse_fwd_bwd(c_values.reshape(R), f(batch["c_returns"]), 1.0, inv_n, sums=sums[4:5])
+            tw.run_backward(prep, c, None, dv.view(T, Bc, 1))
+            del c, c_values, dv
+
+    def optimizer_step(self):
+        cfg, ar = self.cfg, self.model.arena
+        parallel.allreduce_sum_(ar.flat_g)
+        self._gnorm_sq.zero_()
+        ops.sumsq(ar.flat_g, self._gnorm_sq)
+        self.opt_step += 1
+        ops.adam_step(ar.flat_p, ar.flat_g, ar.flat_m, ar.flat_v, ar.flat_bf16, cfg.lr, self.opt_step, cfg.adam_betas[0], cfg.adam_betas[1],
+                      cfg.adam_eps, gnorm_sq=self._gnorm_sq, max_norm=cfg.max_grad_norm)
+        for t in self.model.towers:
+            t.refresh_transposes()
+
+    # ---- one full PPO-Lagrangian update on a filled storage --------------------------------------------------------------
+    def update(self, storage: RolloutStorage, next_value: torch.Tensor, next_c_value: torch.Tensor,
+               episode_cost_sum: float, n_episodes: float, generator: Optional[torch.Generator] = None) -> Dict[str, float]:
+        cfg, m = self.cfg, self.model
+        dev = m.device_
+        storage.compute_returns(next_value, next_c_value, True, cfg.gamma, cfg.gae_lambda)
+        Jc, n_ep = parallel.mean_episode_cost(episode_cost_sum, n_episodes, dev)
+        lam = self.lagrange.update_lagrange_multiplier(Jc) if n_ep > 0 else self.lagrange.lagrangian_multiplier
+        T, B = storage.T, storage.B
+        info_acc = torch.zeros(5, device=dev, dtype=torch.float64)
+        n_mb = 0
+        for _ in range(cfg.update_repeats):
+            bounds = [round(i * B / cfg.num_mini_batch) for i in range(cfg.num_mini_batch + 1)]
+            order = torch.randperm(cfg.num_mini_batch, generator=generator).tolist() if cfg.num_mini_batch > 1 else [0]
+            for i in order:
+                b0, b1 = bounds[i], bounds[i + 1]
+                n_total = parallel.global_count(T * (b1 - b0), dev)
+                m.zero_grad()
+                self._sums.zero_()
+                chunk = cfg.env_chunk or (b1 - b0)
+                for c0 in range(b0, b1, chunk):
+                    self._accumulate(storage.batch_slice(c0, min(b1, c0 + chunk)), n_total, lam)
+                self.optimizer_step()
+                parallel.allreduce_sum_(self._sums)
+                info_acc += self._sums / n_total
+                n_mb += 1
+        s = (info_acc / n_mb).cpu().tolist()      # the update's only host sync
+        value, action, ent, c_value = 0.5 * s[0], s[1], s[2], 0.5 * s[4]
+        return {"ppo_total": cfg.value_loss_coef * value + cfg.action_weight * action + cfg.entropy_coef * ent, "value": value,
+                "action": action, "entropy": ent, "c_value": c_value, "lagrangian_multiplier": lam, "Jc": Jc,
+                "env_steps": parallel.global_count(T * B, dev)}

@@ -527,8 +527,7 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
     @torch.no_grad()
     def prepare(self, observations: Dict[str, torch.Tensor], prev_actions: torch.Tensor, masks: torch.Tensor) -> Prep:
         u = self.uuids
-        nav = observations[u["nav"]]
-        T, B = nav.shape[:2]
+        T, B = prev_actions.shape[:2]
         R = T * B
         dev = self.device_
         p = Prep()
@@ -537,7 +536,7 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
             p.tokens = observations["dino_tokens"].reshape(R, 2, NPATCH, DINO)
         else:
             p.tokens = torch.empty(R, 2, NPATCH, DINO, device=dev, dtype=BF16)
-            ops.feat_to_tokens(nav.reshape(R, DINO, NPATCH).contiguous(), p.tokens, 0)
+            ops.feat_to_tokens(observations[u["nav"]].reshape(R, DINO, NPATCH).contiguous(), p.tokens, 0)
             ops.feat_to_tokens(observations[u["manip"]].reshape(R, DINO, NPATCH).contiguous(), p.tokens, 1)
         p.prev_actions = prev_actions.reshape(R).contiguous()
         p.masks = masks.reshape(R).to(F32).contiguous()
