@@ -156,54 +156,58 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
 }
 
 // ================================================================================================ backward
-// Pass A (waves own query tiles, swapped layout): dQ = dS.K.  Pass B (waves own key tiles): dK = dS^T.Q, dV = P^T.dO.
+// Two kernels, each with only two [S,64] operands resident in LDS (2 workgroups per CU):
+//   dQ  kernel (waves own query tiles, swapped layout, K and V in LDS):   dQ = dS.K
+//   dKV kernel (waves own key tiles, Q and dO in LDS):                    dK = dS^T.Q, dV = P^T.dO
 // P is recomputed from the saved log-sum-exp; D = rowsum(dO * O).
+__device__ __forceinline__ bf16x8 gld8(const bf16_t* p, bool ok) {
+    return ok ? *(const bf16x8*)p : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+}
+__device__ __forceinline__ float dot8(bf16x8 a, bf16x8 b) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += bf2f((bf16_t)a[i]) * bf2f((bf16_t)b[i]);
+    return s;
+}
+
 template <int NKT>
-__global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs p) {
+__global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dq_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16;
-    bf16_t* Qs = (bf16_t*)smem;
-    bf16_t* Ks = Qs + SP * LDSROW;
+    bf16_t* Ks = (bf16_t*)smem;
     bf16_t* Vs = Ks + SP * LDSROW;
-    bf16_t* Gs = Vs + SP * LDSROW;  // dO
-    float* lse_s = (float*)(Gs + SP * LDSROW);
-    float* D_s = lse_s + SP;
-    int* traj_s = (int*)(D_s + SP);
+    int* traj_s = (int*)(Vs + SP * LDSROW);
     unsigned char* kv_s = (unsigned char*)(traj_s + SP);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const size_t tok0 = (size_t)r * p.S;
     const int S = p.S;
-    stage_head(Qs, p.Q + tok0 * p.ld + h * HD, p.ld, S, SP, tid);
     stage_head(Ks, p.K + tok0 * p.ld + h * HD, p.ld, S, SP, tid);
     stage_head(Vs, p.V + tok0 * p.ld + h * HD, p.ld, S, SP, tid);
-    stage_head(Gs, p.dO + tok0 * p.lddo + h * HD, p.lddo, S, SP, tid);
     for (int i = tid; i < SP; i += ATT_THREADS) {
         traj_s[i] = (p.traj && i < S) ? p.traj[tok0 + i] : -1;
         kv_s[i] = (p.kvalid && i < S) ? p.kvalid[tok0 + i] : 1;
-        lse_s[i] = i < S ? p.LSE[((size_t)r * p.H + h) * S + i] : INFINITY;  // +inf => P = 0 for padded queries
-    }
-    for (int row = wid; row < SP; row += ATT_THREADS / 64) {  // D[q] = sum_d dO[q,d] * O[q,d]
-        float v = 0.f;
-        if (row < S) v = bf2f(p.dO[(tok0 + row) * p.lddo + h * HD + lane]) * bf2f(p.O[(tok0 + row) * p.ldo + h * HD + lane]);
-        v = wave_sum(v);
-        if (lane == 0) D_s[row] = v;
     }
     __syncthreads();
     const unsigned char* kvp = p.kvalid ? kv_s : nullptr;
     const int ql = lane & 15, g = lane >> 4;
     const int ntile = (S + 15) / 16;
-
-    // ---------------- pass A: dQ
     for (int qt = wid; qt < ntile; qt += ATT_THREADS / 64) {
         const int q = qt * 16 + ql;
-        const bf16x8 qf0 = lds_row8(Qs, q, 8 * g), qf1 = lds_row8(Qs, q, 32 + 8 * g);
-        const bf16x8 gf0 = lds_row8(Gs, q, 8 * g), gf1 = lds_row8(Gs, q, 32 + 8 * g);
-        const float lse_q = lse_s[q], D_q = D_s[q];
+        const bool qok = q < S;
+        const bf16_t* qp = p.Q + (tok0 + (qok ? q : 0)) * p.ld + h * HD + 8 * g;
+        const bf16_t* gp = p.dO + (tok0 + (qok ? q : 0)) * p.lddo + h * HD + 8 * g;
+        const bf16_t* op = p.O + (tok0 + (qok ? q : 0)) * p.ldo + h * HD + 8 * g;
+        const bf16x8 qf0 = gld8(qp, qok), qf1 = gld8(qp + 32, qok);
+        const bf16x8 gf0 = gld8(gp, qok), gf1 = gld8(gp + 32, qok);
+        float D_q = dot8(gf0, gld8(op, qok)) + dot8(gf1, gld8(op + 32, qok));
+        D_q += __shfl_xor(D_q, 16, 64);
+        D_q += __shfl_xor(D_q, 32, 64);
+        const float lse_q = qok ? p.LSE[((size_t)r * p.H + h) * S + q] : INFINITY;
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
+#pragma unroll 2
         for (int u = 0; u < NKT / 2; ++u) {
             if (u * 32 < S) {
                 float dsv[8];
@@ -219,8 +223,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs p) {
                     for (int e = 0; e < 4; ++e) {
                         const int key = kt * 16 + 4 * g + e;
                         float sv = s[e] * p.scale;
-                        if (p.bias && q < S && key < S) sv += p.bias[((size_t)h * S + q) * S + key];
-                        const bool mk = (q >= S) || masked(p, q < S ? q : 0, key, traj_s, kvp);
+                        if (p.bias && qok && key < S) sv += p.bias[((size_t)h * S + q) * S + key];
+                        const bool mk = !qok || masked(p, qok ? q : 0, key, traj_s, kvp);
                         const float pr = mk ? 0.f : __expf(sv - lse_q);
                         dsv[e2 * 4 + e] = pr * (dp[e] - D_q) * p.scale;
                     }
@@ -241,16 +245,50 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs p) {
             }
         }
     }
+}
 
-    // ---------------- pass B: dK, dV
+template <int NKT>
+__global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dkv_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SP = NKT * 16;
+    bf16_t* Qs = (bf16_t*)smem;
+    bf16_t* Gs = Qs + SP * LDSROW;  // dO
+    float* lse_s = (float*)(Gs + SP * LDSROW);
+    float* D_s = lse_s + SP;
+    int* traj_s = (int*)(D_s + SP);
+    unsigned char* kv_s = (unsigned char*)(traj_s + SP);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const size_t tok0 = (size_t)r * p.S;
+    const int S = p.S;
+    stage_head(Qs, p.Q + tok0 * p.ld + h * HD, p.ld, S, SP, tid);
+    stage_head(Gs, p.dO + tok0 * p.lddo + h * HD, p.lddo, S, SP, tid);
+    for (int i = tid; i < SP; i += ATT_THREADS) {
+        traj_s[i] = (p.traj && i < S) ? p.traj[tok0 + i] : -1;
+        kv_s[i] = (p.kvalid && i < S) ? p.kvalid[tok0 + i] : 1;
+        lse_s[i] = i < S ? p.LSE[((size_t)r * p.H + h) * S + i] : INFINITY;  // +inf => P = 0 for padded queries
+    }
+    for (int row = wid; row < SP; row += ATT_THREADS / 64) {  // D[q] = sum_d dO[q,d] * O[q,d]
+        float v = 0.f;
+        if (row < S) v = bf2f(p.dO[(tok0 + row) * p.lddo + h * HD + lane]) * bf2f(p.O[(tok0 + row) * p.ldo + h * HD + lane]);
+        v = wave_sum(v);
+        if (lane == 0) D_s[row] = v;
+    }
+    __syncthreads();
+    const unsigned char* kvp = p.kvalid ? kv_s : nullptr;
+    const int ql = lane & 15, g = lane >> 4;
+    const int ntile = (S + 15) / 16;
     for (int kt = wid; kt < ntile; kt += ATT_THREADS / 64) {
         const int keyl = kt * 16 + ql;  // this lane's key as the B-operand column
-        const bf16x8 kf0 = lds_row8(Ks, keyl, 8 * g), kf1 = lds_row8(Ks, keyl, 32 + 8 * g);
-        const bf16x8 vf0 = lds_row8(Vs, keyl, 8 * g), vf1 = lds_row8(Vs, keyl, 32 + 8 * g);
+        const bool kok = keyl < S;
+        const bf16_t* kp = p.K + (tok0 + (kok ? keyl : 0)) * p.ld + h * HD + 8 * g;
+        const bf16_t* vp = p.V + (tok0 + (kok ? keyl : 0)) * p.ld + h * HD + 8 * g;
+        const bf16x8 kf0 = gld8(kp, kok), kf1 = gld8(kp + 32, kok);
+        const bf16x8 vf0 = gld8(vp, kok), vf1 = gld8(vp + 32, kok);
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll 1
+#pragma unroll 2
         for (int w = 0; w < NKT / 2; ++w) {
             if (w * 32 < S) {
                 float pv[8], dsv[8];
@@ -267,7 +305,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs p) {
                     for (int e = 0; e < 4; ++e) {
                         const int q = qt * 16 + 4 * g + e;
                         float sv = s[e] * p.scale;
-                        if (p.bias && q < S && keyl < S) sv += p.bias[((size_t)h * S + q) * S + keyl];
+                        if (p.bias && q < S && kok) sv += p.bias[((size_t)h * S + q) * S + keyl];
                         const bool mk = (q >= S) || masked(p, q < S ? q : 0, keyl, traj_s, kvp);
                         const float pr = mk ? 0.f : __expf(sv - lse_s[q]);
                         pv[e2 * 4 + e] = pr;
@@ -306,10 +344,16 @@ static int launch_fwd(const AttnArgs& p, int rows, hipStream_t st) {
 }
 template <int NKT>
 static int launch_bwd(const AttnArgs& p, int rows, hipStream_t st) {
-    const size_t lds = (size_t)4 * NKT * 16 * LDSROW * sizeof(bf16_t) + NKT * 16 * (2 * sizeof(float) + sizeof(int) + 1);
+    const size_t lds_q = (size_t)2 * NKT * 16 * LDSROW * sizeof(bf16_t) + NKT * 16 * (sizeof(int) + 1);
+    const size_t lds_kv = (size_t)2 * NKT * 16 * LDSROW * sizeof(bf16_t) + NKT * 16 * (2 * sizeof(float) + sizeof(int) + 1);
     static bool attr = false;
-    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-    hipLaunchKernelGGL(attn_bwd_kernel<NKT>, dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv));
+        attr = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<NKT>, dim3(rows * p.H), dim3(ATT_THREADS), lds_q, st, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NKT>, dim3(rows * p.H), dim3(ATT_THREADS), lds_kv, st, p);
     return svla_launch_status();
 }
 

@@ -90,6 +90,21 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // epilogue operands of this thread's 8 output chunks (row = (tid + 256 j) >> 4, 16-byte chunk ecc = tid & 15)
+    const int ecc = tid & 15;
+    float ebias[8];
+    u32x4 eres[8], emask[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ebias[e] = p.bias ? p.bias[n0 + ecc * 8 + e] : 0.f;
+    if (!p.out_f32) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = m0 + ((tid + NTHREADS * j) >> 4);
+            eres[j] = (p.residual && m < p.M) ? *(const u32x4*)(p.residual + (size_t)m * p.ldr + n0 + ecc * 8) : u32x4{0, 0, 0, 0};
+            emask[j] = (p.relu_mask && m < p.M) ? *(const u32x4*)(p.relu_mask + (size_t)m * p.ldm + n0 + ecc * 8) : u32x4{0, 0, 0, 0};
+        }
+    }
+
     const int nk = p.K / BK;
     gload(0);
     lstore(0);
@@ -149,8 +164,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p)
         }
         return;
     }
-    constexpr int CS = BN + 8;  // padded row (elements); 272 B keeps 16-byte alignment
-    bf16_t* Cs = (bf16_t*)smem;  // reuse staging LDS (all MFMA reads are behind the loop's last barrier)
+    // fp32 tile staged through LDS (reusing the operand buffers: all MFMA reads are behind the loop's last barrier);
+    // bias / activation / ReLU-mask / residual are applied in fp32 on whole 16-byte output chunks whose mask and
+    // residual operands were prefetched before the K loop (their HBM latency hides under the main loop).
+    constexpr int CS = BN + 4;  // padded fp32 row: 528 B, conflict-free ds_write_b128 / ds_read_b128
+    float* Cs = (float*)smem;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -158,42 +176,35 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int nl = wn * 64 + j * 32 + 8 * rg + 4 * fh;
-                float v[4];
+                f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[i][j][rg * 4 + e] * p.alpha + (p.bias ? p.bias[n0 + nl + e] : 0.f);
-                    if (p.act == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
-                    else if (p.act == ACT_GELU) v[e] = gelu_f(v[e]);
-                }
-                u32x2 w;
-                w[0] = pack_bf2(v[0], v[1]); w[1] = pack_bf2(v[2], v[3]);
-                *(u32x2*)(Cs + (wm * 64 + i * 32 + fr) * CS + nl) = w;
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e] * p.alpha;
+                *(f32x4*)(Cs + (wm * 64 + i * 32 + fr) * CS + nl) = v;
             }
     __syncthreads();
     bf16_t* C = (bf16_t*)p.C;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int q = tid + NTHREADS * j;
-        const int row = q >> 4, cc = q & 15;
+        const int row = q >> 4;
         const int m = m0 + row;
         if (m >= p.M) continue;
-        u32x4 w = *(const u32x4*)(Cs + row * CS + cc * 8);
-        if (p.relu_mask || p.residual) {
-            u32x4 mk = {0, 0, 0, 0}, rs = {0, 0, 0, 0};
-            if (p.relu_mask) mk = *(const u32x4*)(p.relu_mask + (size_t)m * p.ldm + n0 + cc * 8);
-            if (p.residual) rs = *(const u32x4*)(p.residual + (size_t)m * p.ldr + n0 + cc * 8);
+        const f32x4 a = *(const f32x4*)(Cs + row * CS + ecc * 8), b = *(const f32x4*)(Cs + row * CS + ecc * 8 + 4);
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        u32x4 w;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float lo = bf_lo(w[e]), hi = bf_hi(w[e]);
-                if (p.relu_mask) {
-                    if (!(bf_lo(mk[e]) > 0.f)) lo = 0.f;
-                    if (!(bf_hi(mk[e]) > 0.f)) hi = 0.f;
-                }
-                if (p.residual) { lo += bf_lo(rs[e]); hi += bf_hi(rs[e]); }
-                w[e] = pack_bf2(lo, hi);
+        for (int e = 0; e < 4; ++e) {
+            float lo = v[2 * e] + ebias[2 * e], hi = v[2 * e + 1] + ebias[2 * e + 1];
+            if (p.act == ACT_RELU) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+            else if (p.act == ACT_GELU) { lo = gelu_f(lo); hi = gelu_f(hi); }
+            if (p.relu_mask) {
+                if (!(bf_lo(emask[j][e]) > 0.f)) lo = 0.f;
+                if (!(bf_hi(emask[j][e]) > 0.f)) hi = 0.f;
             }
+            if (p.residual) { lo += bf_lo(eres[j][e]); hi += bf_hi(eres[j][e]); }
+            w[e] = pack_bf2(lo, hi);
         }
-        *(u32x4*)(C + (size_t)m * p.ldc + n0 + cc * 8) = w;
+        *(u32x4*)(C + (size_t)m * p.ldc + n0 + ecc * 8) = w;
     }
 }
 
@@ -204,7 +215,7 @@ extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, lon
     if ((lda % 8) || (ldb % 8) || (ldc % (out_f32 ? 4 : 8)) || (residual && (ldr % 8)) || (relu_mask && (ldm % 8))) return SVLA_EINVAL;
     GemmNtArgs p{A, lda, B, ldb, bias, residual, ldr, relu_mask, ldm, C, ldc, M, N, K, act, out_f32, alpha};
     const int mt = (M + BM - 1) / BM, nt = N / BN;
-    const size_t lds = 2 * (BM + BN) * BK * sizeof(bf16_t);  // 64 KiB (epilogue tile 128 x 136 x 2 B = 34 KiB fits)
+    const size_t lds = BM * (BN + 4) * sizeof(float);  // 66 KiB: max(operand double buffers 64 KiB, fp32 epilogue tile)
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -36,18 +36,18 @@ class Lagrange:
 
     def update_lagrange_multiplier(self, Jc: float) -> float:
         f = np.float32
-        g = f(-(f(Jc) - f(self.cost_limit)))          # d loss / d lambda
+        g = f(-(float(Jc) - self.cost_limit))         # d loss / d lambda (difference in double, like the python scalars in omnisafe)
         if self.lambda_optimizer == "SGD":
             self._lam = f(self._lam - f(self.lambda_lr) * g)
         else:  # torch.optim.Adam defaults, fp32 like a torch scalar parameter
             b1, b2, eps = f(0.9), f(0.999), f(1e-8)
             self._t += 1
-            self._m = f(self._m + (g - self._m) * (f(1) - b1))
-            self._v = f(self._v * b2 + (f(1) - b2) * g * g)
-            bc1 = f(1.0 - 0.9 ** self._t)
+            self._m = f(self._m + (g - self._m) * f(1.0 - 0.9))          # lerp_(grad, 1 - beta1): weight is a double scalar
+            self._v = f(f(self._v * b2) + f(f(1.0 - 0.999) * f(g * g)))   # mul_(beta2).addcmul_(g, g, value=1 - beta2)
+            step_size = f(self.lambda_lr / (1.0 - 0.9 ** self._t))      # scalars in double, cast once (as torch does)
             bc2s = f(math.sqrt(1.0 - 0.999 ** self._t))
             denom = f(f(np.sqrt(self._v)) / bc2s + eps)
-            self._lam = f(self._lam - f(f(self.lambda_lr) / bc1) * f(self._m / denom))
+            self._lam = f(self._lam - step_size * f(self._m / denom))
         hi = np.inf if self.lagrangian_upper_bound is None else float(self.lagrangian_upper_bound)
         self._lam = f(min(max(float(self._lam), 0.0), hi))
         return float(self._lam)

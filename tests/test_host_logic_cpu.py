@@ -1,0 +1,53 @@
+"""Host logic that needs no GPU: Lagrange multiplier mirror vs the oracle, env sharding, tokenizer, API containers."""
+import numpy as np
+import torch
+
+from oracle.ref_rollout import RefLagrange
+from safevla_amd import parallel
+from safevla_amd.api import CategoricalDistr
+from safevla_amd.lagrange import Lagrange
+from safevla_amd.text import GoalTokenizer, bytes_to_str, str_to_bytes
+
+
+def test_lagrange_matches_torch_adam_oracle():
+    a, b = Lagrange(2.31964, 0.001, 0.035), RefLagrange(2.31964, 0.001, 0.035)
+    rs = np.random.RandomState(0)
+    for jc in rs.uniform(0.0, 6.0, 200):
+        x, y = a.update_lagrange_multiplier(float(jc)), b.update(float(jc))
+        assert abs(x - y) <= 1e-6 * max(1.0, abs(y)), (x, y)
+    assert a.lagrangian_multiplier >= 0.0
+    sd = a.state_dict()
+    c = Lagrange(2.31964)
+    c.load_state_dict(sd)
+    assert c.update_lagrange_multiplier(3.0) == a.update_lagrange_multiplier(3.0)
+    s = Lagrange(1.0, 0.5, 0.1, "SGD", lagrangian_upper_bound=0.55)
+    assert abs(s.update_lagrange_multiplier(2.0) - 0.55) < 1e-7      # 0.5 + 0.1*1 = 0.6 -> clamped
+    assert s.update_lagrange_multiplier(-100.0) == 0.0
+
+
+def test_env_sharding_matches_reference_bins():
+    assert parallel.evenly_distribute_count_into_bins(10, 4) == [3, 3, 2, 2]
+    assert [parallel.shard_envs(256, 8, r) for r in range(8)] == [(32 * r, 32) for r in range(8)]
+    cover = []
+    for r in range(3):
+        s, n = parallel.shard_envs(32, 3, r)
+        cover += list(range(s, s + n))
+    assert cover == list(range(32))
+
+
+def test_goal_bytes_and_tokenizer():
+    row = str_to_bytes("find a mug", 1000).reshape(-1)
+    assert row.shape == (1000,) and bytes_to_str(row) == "find a mug"
+    tok = GoalTokenizer()
+    enc = tok(["find a mug", "navigate to the red apple"], return_tensors="pt", padding=True)
+    assert enc["input_ids"].shape == (2, 6) and enc["attention_mask"].sum().item() == 4 + 6
+    assert enc["input_ids"][0, 3].item() == 1 and enc["input_ids"][0, 4].item() == 0      # EOS then PAD
+    assert tok.encode("Find A Mug") == tok.encode("find a mug")
+
+
+def test_categorical_distr_matches_torch():
+    lg = torch.randn(5, 3, 20)
+    d, t = CategoricalDistr(lg), torch.distributions.Categorical(logits=lg)
+    a = torch.randint(0, 20, (5, 3))
+    assert torch.allclose(d.log_prob(a), t.log_prob(a), atol=1e-6) and torch.allclose(d.entropy(), t.entropy(), atol=1e-6)
+    assert d.sample().shape == (5, 3) and torch.equal(d.mode(), lg.argmax(-1))

@@ -1,0 +1,80 @@
+"""N > 1 path on CPU: two gloo ranks shard the environments, each computes gradients of the (oracle) policy on its
+shard with the global 1/N normalisation, SUM-all-reduce the flat gradient and the cost accumulator through
+safevla_amd.parallel -- the result must equal the single-process full-batch gradient and Jc."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tiny_policy():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 21))
+
+
+def _loss_sum(net, x, batch, lam, n_total):
+    from oracle import ref_loss
+
+    out = net(x)
+    logits, values = out[..., :20], out[..., 20:]
+    total, _ = ref_loss.safe_ppo_log_grad(logits, values, batch, lam)
+    return total * (x.shape[0] * x.shape[1]) / n_total        # mean over local rows -> sum / global rows
+
+
+def _make(T=6, B=8):
+    rs = np.random.RandomState(0)
+    x = torch.from_numpy(rs.standard_normal((T, B, 16)).astype(np.float32))
+    batch = {"actions": torch.from_numpy(rs.randint(0, 20, (T, B))), "old_action_log_probs": torch.full((T, B), -3.0),
+             "adv_targ": torch.from_numpy(rs.standard_normal((T, B, 1)).astype(np.float32)),
+             "c_adv_targ": torch.from_numpy(rs.standard_normal((T, B, 1)).astype(np.float32)),
+             "returns": torch.from_numpy(rs.standard_normal((T, B, 1)).astype(np.float32)), "values": torch.zeros(T, B, 1)}
+    return x, batch
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from safevla_amd import parallel
+
+    r, _, w = parallel.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and parallel.is_dist()
+    x, batch = _make()
+    T, B = x.shape[:2]
+    s, n = parallel.shard_envs(B, world, rank)
+    net = _tiny_policy()
+    n_total = parallel.global_count(T * n, "cpu")
+    assert n_total == T * B
+    loss = _loss_sum(net, x[:, s:s + n], {k: v[:, s:s + n] for k, v in batch.items()}, 0.37, n_total)
+    loss.backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    parallel.allreduce_sum_(flat)
+    jc, n_ep = parallel.mean_episode_cost(3.0 * (rank + 1), 2.0, "cpu")
+    parallel.barrier()
+    if rank == 0:
+        q.put((flat.numpy(), jc, n_ep))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_equals_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    flat, jc, n_ep = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x, batch = _make()
+    net = _tiny_policy()
+    _loss_sum(net, x, batch, 0.37, x.shape[0] * x.shape[1]).backward()
+    want = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy()
+    np.testing.assert_allclose(flat, want, rtol=1e-5, atol=1e-7)
+    assert n_ep == 4.0 and abs(jc - (3.0 + 6.0) / 4.0) < 1e-12
