@@ -533,7 +533,7 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
         p = Prep()
         p.T, p.B, p.R = T, B, R
         if "dino_tokens" in observations:       # storage-native layout [T,B,2,84,384] bf16
-            p.tokens = observations["dino_tokens"].reshape(R, 2, NPATCH, DINO)
+            p.tokens = observations["dino_tokens"].reshape(R, 2, NPATCH, DINO).contiguous()
         else:
             p.tokens = torch.empty(R, 2, NPATCH, DINO, device=dev, dtype=BF16)
             ops.feat_to_tokens(observations[u["nav"]].reshape(R, DINO, NPATCH).contiguous(), p.tokens, 0)

@@ -42,9 +42,19 @@ def test_state_dict_names_match_reference(model):
 
 
 def test_t5_encoder_vs_oracle(model):
+    from oracle.detfill import fill_state_dict
     from oracle.ref_t5 import RefT5Encoder
 
-    t5 = model.visual_encoder.text_encoder
+    from safevla_amd.model import T5Frozen
+
+    # own instance: name-seeded weights with the query projection scaled down so the (un-scaled, T5-style) softmax is
+    # not saturated -- a saturated softmax turns bf16 rounding into arg-max flips, which tests chaos, not the kernels
+    t5 = T5Frozen(torch.device(DEV))
+    fill_state_dict(t5, seed=11)
+    with torch.no_grad():
+        for b in t5.encoder.block:
+            b.layer[0].SelfAttention.q.weight.mul_(0.25)
+    t5.sync()
     ref = RefT5Encoder().eval()
     ref.load_state_dict({k: v.detach().cpu() for k, v in t5.state_dict().items()})
     rs = np.random.RandomState(0)
@@ -57,7 +67,7 @@ def test_t5_encoder_vs_oracle(model):
     got = t5.encode(ids.to(DEV), am.to(DEV)).float().view(5, 11, 512).cpu()
     valid = am.bool()
     err = (got - want)[valid].abs().max().item()
-    assert err < 0.08 * want[valid].abs().max().item(), err
+    assert err < 0.04 * want[valid].abs().max().item(), (err, want[valid].abs().max().item())
 
 
 @pytest.mark.parametrize("tag", ["g5_samelen", "g5_mixedlen"])
