@@ -66,6 +66,8 @@ int svla_norm_bwd_bf16(const svla_bf16* dy, int dyG, int dyGS, int dyOFF, const 
 int svla_gemm_nt_bf16(const svla_bf16* A, long lda, const svla_bf16* B, long ldb, const float* bias, const svla_bf16* residual,
                       long ldr, const svla_bf16* relu_mask, long ldm, void* C, long ldc, int M, int N, int K, int act,
                       int out_f32, float alpha, void* stream);
+/* Test hook: force the 128x128-tile kernel even where the 256x256 one would be chosen (same cited layers). */
+int svla_gemm_force_small_tile(int on);
 /* dW[N,K] (fp32) += dY[M,N]^T . X[M,K]: weight gradients (autograd of the same layers).  N,K % 128 == 0. */
 int svla_gemm_tn_f32acc(const svla_bf16* dY, long ldy, const svla_bf16* X, long ldx, float* dW, long ldw, int M, int N, int K,
                         void* stream);

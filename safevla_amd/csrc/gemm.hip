@@ -8,18 +8,20 @@
 //
 // Shapes on this path: M = rows x tokens (1e5..2e6), N,K in {384,512,1536,2048}: A streams from HBM once, the
 // weights stay L2-resident.  Tile 128x128x64, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 tiles.
-// Register-staged double-buffered LDS pipeline (one barrier per K-tile), XOR-swizzled 16-byte chunks so both the
-// ds_write_b128 staging stores and the ds_read_b128 fragment loads are bank-conflict free, XCD-aware tile order so
+// global_load_lds (LDS-DMA) double-buffered pipeline (one barrier per K-tile), XOR swizzle on the DMA source
+// address + on the ds_read_b128 fragment loads (bank-conflict free), XCD-aware tile order so
 // the N-tiles that share an A panel run back-to-back on one XCD's L2, LDS-staged epilogue with 16-byte stores.
 #include "common.h"
 
 #define BM 128
 #define BN 128
-#define BK 64
+#define BK 32
+#define NST 4     // LDS pipeline stages (3 K-tiles of DMA in flight)
 #define NTHREADS 256
 
-// physical 16-byte chunk inside a 128-byte (64 x bf16) LDS row
-__device__ __forceinline__ int swz_nt(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+// physical 16-byte chunk inside a 64-byte (32 x bf16) LDS row: 16 consecutive rows x one logical chunk hit 16 distinct
+// 16-byte bank slots (conflict-free ds_read_b128)
+__device__ __forceinline__ int swz_nt(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
 
 // bijective XCD remap: workgroup b runs on XCD b % 8; give every XCD a contiguous range of tile ids.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -44,41 +46,37 @@ __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff
 
 __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* As = (bf16_t*)smem;                 // [2][BM][BK]
-    bf16_t* Bs = As + 2 * BM * BK;              // [2][BN][BK]
+    bf16_t* As = (bf16_t*)smem;                 // [NST][BM][BK]
+    bf16_t* Bs = As + NST * BM * BK;            // [NST][BN][BK]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int ntn = p.N / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
 
-    // staging assignment: 4 chunks of A and 4 of B per thread per K-tile
-    int srow[4], schunk[4];
-    const bf16_t* ga[4];
-    const bf16_t* gb[4];
-    bool aok[4];
+    // staging: global -> LDS DMA (global_load_lds_dwordx4, 1 KiB = 16 tile rows of 64 B per wave instruction; 2 A + 2 B
+    // per wave per K-tile).  The DMA writes lane-linear, so the XOR swizzle is applied to the per-lane SOURCE address:
+    // lane i lands at (row rbase + i/4, physical chunk i%4) and therefore fetches logical chunk (i%4) ^ swz(row).
+    const bf16_t* ga[2];
+    const bf16_t* gb[2];
+    int ldsoff[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int q = tid + NTHREADS * j;
-        srow[j] = q >> 3; schunk[j] = q & 7;
-        aok[j] = (m0 + srow[j]) < p.M;
-        ga[j] = p.A + (size_t)(aok[j] ? m0 + srow[j] : 0) * p.lda + schunk[j] * 8;
-        gb[j] = p.B + (size_t)(n0 + srow[j]) * p.ldb + schunk[j] * 8;
+    for (int j = 0; j < 2; ++j) {
+        const int rbase = (wid * 2 + j) * 16;
+        const int row = rbase + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        const int am = min(m0 + row, p.M - 1);          // M tail: clamp (those output rows are never stored)
+        ga[j] = p.A + (size_t)am * p.lda + c * 8;
+        gb[j] = p.B + (size_t)(n0 + row) * p.ldb + c * 8;
+        ldsoff[j] = __builtin_amdgcn_readfirstlane(rbase * BK);
     }
-    u32x4 ra[4], rb[4];
-    auto gload = [&](int k0) {
+    auto stage = [&](int st, int k0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            ra[j] = aok[j] ? *(const u32x4*)(ga[j] + k0) : u32x4{0, 0, 0, 0};
-            rb[j] = *(const u32x4*)(gb[j] + k0);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int off = srow[j] * BK + swz_nt(srow[j], schunk[j]) * 8;
-            *(u32x4*)(As + buf * BM * BK + off) = ra[j];
-            *(u32x4*)(Bs + buf * BN * BK + off) = rb[j];
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[j] + k0),
+                                             (__attribute__((address_space(3))) void*)(As + st * BM * BK + ldsoff[j]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[j] + k0),
+                                             (__attribute__((address_space(3))) void*)(Bs + st * BN * BK + ldsoff[j]), 16, 0, 0);
         }
     };
 
@@ -95,45 +93,69 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p)
     float ebias[8];
     u32x4 eres[8], emask[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ebias[e] = p.bias ? p.bias[n0 + ecc * 8 + e] : 0.f;
-    if (!p.out_f32) {
+    for (int e = 0; e < 8; ++e) ebias[e] = 0.f;
+    if (p.bias) {
+        const f32x4 b0 = *(const f32x4*)(p.bias + n0 + ecc * 8), b1 = *(const f32x4*)(p.bias + n0 + ecc * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ebias[e] = b0[e]; ebias[4 + e] = b1[e]; }
+    }
+    // branch-free per lane (rows past M are clamped: never stored); only wave-uniform branches on the pointers
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { eres[j] = u32x4{0, 0, 0, 0}; emask[j] = u32x4{0, 0, 0, 0}; }
+    if (!p.out_f32 && p.residual) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int m = m0 + ((tid + NTHREADS * j) >> 4);
-            eres[j] = (p.residual && m < p.M) ? *(const u32x4*)(p.residual + (size_t)m * p.ldr + n0 + ecc * 8) : u32x4{0, 0, 0, 0};
-            emask[j] = (p.relu_mask && m < p.M) ? *(const u32x4*)(p.relu_mask + (size_t)m * p.ldm + n0 + ecc * 8) : u32x4{0, 0, 0, 0};
+            const int m = min(m0 + ((tid + NTHREADS * j) >> 4), p.M - 1);
+            eres[j] = *(const u32x4*)(p.residual + (size_t)m * p.ldr + n0 + ecc * 8);
+        }
+    }
+    if (!p.out_f32 && p.relu_mask) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = min(m0 + ((tid + NTHREADS * j) >> 4), p.M - 1);
+            emask[j] = *(const u32x4*)(p.relu_mask + (size_t)m * p.ldm + n0 + ecc * 8);
         }
     }
 
+    // NST-stage pipeline: up to NST-1 K-tiles of DMA in flight; ONE raw s_barrier per K-tile.  Each wave waits (counted
+    // vmcnt, 4 DMA instructions per tile per wave) for its own pieces of tile kt, the barrier then publishes the whole
+    // tile and proves every wave is done reading the stage the next DMA overwrites.
     const int nk = p.K / BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nk) stage(s, s * BK);
     const int fr = lane & 31, fh = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);
-        const bf16_t* Ab = As + buf * BM * BK;
-        const bf16_t* Bb = Bs + buf * BN * BK;
+        const int rem = nk - 1 - kt;       // tiles issued after tile kt that may stay in flight
+        if (rem >= NST - 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + NST - 1 < nk) stage((kt + NST - 1) % NST, (kt + NST - 1) * BK);
+        const int st = kt % NST;
+        const bf16_t* Ab = As + st * BM * BK;
+        const bf16_t* Bb = Bs + st * BN * BK;
+        // all fragment reads of the tile first (one exposed LDS latency per tile), then 8 back-to-back MFMAs
+        bf16x8 fa[BK / 16][2], fb[BK / 16][2];
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8 fa[2], fb[2];
+        for (int kk = 0; kk < BK / 16; ++kk)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int ra_ = wm * 64 + t * 32 + fr, rb_ = wn * 64 + t * 32 + fr;
-                fa[t] = *(const bf16x8*)(Ab + ra_ * BK + swz_nt(ra_, kk * 2 + fh) * 8);
-                fb[t] = *(const bf16x8*)(Bb + rb_ * BK + swz_nt(rb_, kk * 2 + fh) * 8);
+                fa[kk][t] = *(const bf16x8*)(Ab + ra_ * BK + swz_nt(ra_, kk * 2 + fh) * 8);
+                fb[kk][t] = *(const bf16x8*)(Bb + rb_ * BK + swz_nt(rb_, kk * 2 + fh) * 8);
             }
-            // operands swapped (W rows as the MFMA "A" side): each lane then owns 4 consecutive output columns
+        // operands swapped (W rows as the MFMA "A" side): each lane then owns 4 consecutive output columns
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = mfma32(fb[j], fa[i], acc[i][j]);
-        }
-        if (kt + 1 < nk) lstore(buf ^ 1);
-        __syncthreads();
+                    acc[i][j] = mfma32(fb[kk][j], fa[kk][i], acc[i][j]);
     }
+    __syncthreads();   // all MFMA reads of the operand stages are done before the epilogue reuses the LDS
 
     // ---- epilogue.  acc[i][j][reg]: output row m = wm*64 + i*32 + (lane&31),
     //                                 output col n = wn*64 + j*32 + (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -208,14 +230,225 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p)
     }
 }
 
+// =================================================================================================
+// 256x256 tile variant (8 waves = 2(M) x 4(N), wave tile 128x64 = 4x2 MFMA 32x32 tiles) for the big row-streaming
+// GEMMs.  Why: a 128x128 tile needs 32 KiB of operands per 64-deep K step per 512 MFMA cycles = the CU's whole
+// 64 B/clk L1->LDS path (measured: 47 % of wave time parked, 24 % MFMA busy); 256x256 halves the bytes per FLOP and the
+// LDS reads per MFMA (6 fragments per 8 MFMAs).  Same 4-stage LDS-DMA pipeline with counted vmcnt; the epilogue goes
+// straight from registers: bias/activation/mask/residual in fp32 on the accumulator layout (4 consecutive columns per
+// lane), one bf16 rounding, v_permlane32_swap pairs the two half-waves into 16-byte row segments.
+#define NT256_THREADS 512
+// PERSISTENT: one workgroup per CU walks a list of tiles; the K-steps of consecutive tiles form one continuous DMA stream
+// (the first three K-steps of the next tile are in flight while the current tile's epilogue stores run), so the
+// per-tile prologue latency disappears and only the register epilogue itself is un-overlapped.
+__global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256_bf16_kernel(GemmNtArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* As = (bf16_t*)smem;                  // [NST][256][BK]
+    bf16_t* Bs = As + NST * 256 * BK;            // [NST][256][BK]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3;
+    const int ntn = p.N / 256, MT = (p.M + 255) / 256;
+    // XCD-aware persistent schedule: workgroup w runs on XCD w % 8 (observed dispatch rule, used for L2 locality only).
+    // XCD x owns m-tiles x, x+8, ...; its workgroups take (m-tile, n-tile) pairs in order, so the n-tiles of one A panel
+    // run at the same time on the same XCD's L2.
+    const int xcd = blockIdx.x & 7, lw = blockIdx.x >> 3, lstride = gridDim.x >> 3;
+    const int n_local = ((MT - xcd + 7) / 8) * ntn;      // tiles owned by this XCD (MT >= 8 guaranteed by the launcher)
+
+    int ldsoff[2];
+    int srow[2], schunk[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rbase = (wid * 2 + j) * 16;
+        srow[j] = rbase + (lane >> 2);
+        schunk[j] = ((lane & 3) ^ ((srow[j] >> 2) & 3)) * 8;
+        ldsoff[j] = __builtin_amdgcn_readfirstlane(rbase * BK);
+    }
+    struct Src { const bf16_t* a[2]; const bf16_t* b[2]; };
+    auto tile_src = [&](int li, int& m0, int& n0) -> Src {
+        m0 = ((li / ntn) * 8 + xcd) * 256;
+        n0 = (li % ntn) * 256;
+        Src s;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            s.a[j] = p.A + (size_t)min(m0 + srow[j], p.M - 1) * p.lda + schunk[j];
+            s.b[j] = p.B + (size_t)(n0 + srow[j]) * p.ldb + schunk[j];
+        }
+        return s;
+    };
+    auto stage = [&](int st, const Src& s, int k0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s.a[j] + k0),
+                                             (__attribute__((address_space(3))) void*)(As + st * 256 * BK + ldsoff[j]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s.b[j] + k0),
+                                             (__attribute__((address_space(3))) void*)(Bs + st * 256 * BK + ldsoff[j]), 16, 0, 0);
+        }
+    };
+    f32x16 acc[4][2];
+    const int nk = p.K / BK;     // >= 3 (launcher)
+    const int fr = lane & 31, fh = lane >> 5;
+    bf16_t* C = (bf16_t*)p.C;
+
+    // one prefetched epilogue operand stream ("aux" = residual, else the ReLU mask), double-buffered per 32-row slab
+    const bf16_t* aux = p.residual ? p.residual : p.relu_mask;
+    const long ldaux = p.residual ? p.ldr : p.ldm;
+    u32x2 auxbuf[2][2][4];
+    auto load_aux = [&](int i, u32x2 (&buf)[2][4], int tm0, int tn0) {
+        const int mc = min(tm0 + wm * 128 + i * 32 + fr, p.M - 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                buf[j][rg] = *(const u32x2*)(aux + (size_t)mc * ldaux + tn0 + wn * 64 + j * 32 + 8 * rg + 4 * fh);
+    };
+
+    int li = lw;
+    if (li >= n_local) return;
+    int m0, n0;
+    Src cur = tile_src(li, m0, n0);
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) stage(s, cur, s * BK);
+    int g = 0;           // global K-step counter: LDS stage of step g is g % NST
+    bool first = true;
+    while (true) {
+        const int li_next = li + lstride;
+        const bool has_next = li_next < n_local;
+        int m0n = 0, n0n = 0;
+        Src nxt = cur;
+        if (has_next) nxt = tile_src(li_next, m0n, n0n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            // younger DMA groups allowed to stay in flight behind step (tile, kt): 2 while the stream continues.
+            // After an epilogue (loads/stores on the same counter) drain everything once: vmcnt(0).
+            const int rem = has_next ? 2 : nk - 1 - kt;
+            if (kt == 0 && !first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (rem >= NST - 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt == nk - 2 && aux) load_aux(0, auxbuf[0], m0, n0);   // epilogue operand of the first 32-row slab, hidden under the last K-steps
+            const int ka = kt + NST - 1;
+            if (ka < nk) stage((g + NST - 1) % NST, cur, ka * BK);
+            else if (has_next) stage((g + NST - 1) % NST, nxt, (ka - nk) * BK);
+            const int st = g % NST;
+            const bf16_t* Ab = As + st * 256 * BK;
+            const bf16_t* Bb = Bs + st * 256 * BK;
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                bf16x8 fa[4], fb[2];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int r_ = wm * 128 + t * 32 + fr;
+                    fa[t] = *(const bf16x8*)(Ab + r_ * BK + swz_nt(r_, kk * 2 + fh) * 8);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int r_ = wn * 64 + t * 32 + fr;
+                    fb[t] = *(const bf16x8*)(Bb + r_ * BK + swz_nt(r_, kk * 2 + fh) * 8);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = mfma32(fb[j], fa[i], acc[i][j]);
+            }
+        }
+
+        // ---- epilogue from registers.  acc[i][j][4*rg + e]: row m = m0 + wm*128 + i*32 + fr,
+        //                                col n = n0 + wn*64 + j*32 + 8*rg + 4*fh + e
+        f32x4 bias4[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                bias4[j][rg] = p.bias ? *(const f32x4*)(p.bias + n0 + wn * 64 + j * 32 + 8 * rg + 4 * fh) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 128 + i * 32 + fr;
+            const int mc = min(m, p.M - 1);
+            if (aux && i + 1 < 4) load_aux(i + 1, auxbuf[(i + 1) & 1], m0, n0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nb = n0 + wn * 64 + j * 32;
+                u32x2 pk[4];
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int n = nb + 8 * rg + 4 * fh;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[i][j][rg * 4 + e] * p.alpha + bias4[j][rg][e];
+                        if (p.act == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                        else if (p.act == ACT_GELU) v[e] = gelu_f(v[e]);
+                    }
+                    if (p.relu_mask) {
+                        // the mask is the prefetched stream unless a residual is also present (then it is read here)
+                        const u32x2 mk = p.residual ? *(const u32x2*)(p.relu_mask + (size_t)mc * p.ldm + n) : auxbuf[i & 1][j][rg];
+                        if (!(bf_lo(mk[0]) > 0.f)) v[0] = 0.f;
+                        if (!(bf_hi(mk[0]) > 0.f)) v[1] = 0.f;
+                        if (!(bf_lo(mk[1]) > 0.f)) v[2] = 0.f;
+                        if (!(bf_hi(mk[1]) > 0.f)) v[3] = 0.f;
+                    }
+                    if (p.residual) {
+                        const u32x2 rs = auxbuf[i & 1][j][rg];
+                        v[0] += bf_lo(rs[0]); v[1] += bf_hi(rs[0]); v[2] += bf_lo(rs[1]); v[3] += bf_hi(rs[1]);
+                    }
+                    pk[rg][0] = pack_bf2(v[0], v[1]);
+                    pk[rg][1] = pack_bf2(v[2], v[3]);
+                }
+#pragma unroll
+                for (int rg = 0; rg < 4; rg += 2) {
+                    // half-wave exchange: lanes 0-31 end with columns 8rg..8rg+7, lanes 32-63 with 8rg+8..8rg+15 of row m
+                    const auto sx = __builtin_amdgcn_permlane32_swap(pk[rg][0], pk[rg + 1][0], false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(pk[rg][1], pk[rg + 1][1], false, false);
+                    const u32x4 w = {sx[0], sy[0], sx[1], sy[1]};
+                    if (m < p.M) *(u32x4*)(C + (size_t)m * p.ldc + nb + 8 * rg + 8 * fh) = w;
+                }
+            }
+        }
+        if (!has_next) break;
+        li = li_next; cur = nxt; m0 = m0n; n0 = n0n; first = false;
+    }
+}
+
+static int g_force_small_tile = 0;
+extern "C" int svla_gemm_force_small_tile(int on) { g_force_small_tile = on; return SVLA_OK; }
+
 extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, long ldb, const float* bias,
                                  const bf16_t* residual, long ldr, const bf16_t* relu_mask, long ldm, void* C, long ldc,
                                  int M, int N, int K, int act, int out_f32, float alpha, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || (N % BN) || (K % BK)) return SVLA_EINVAL;
     if ((lda % 8) || (ldb % 8) || (ldc % (out_f32 ? 4 : 8)) || (residual && (ldr % 8)) || (relu_mask && (ldm % 8))) return SVLA_EINVAL;
     GemmNtArgs p{A, lda, B, ldb, bias, residual, ldr, relu_mask, ldm, C, ldc, M, N, K, act, out_f32, alpha};
+    if (!out_f32 && (N % 256) == 0 && (long)((M + 255) / 256) * (N / 256) >= 256 && K >= 3 * BK && !g_force_small_tile) {
+        const size_t lds256 = (size_t)NST * 512 * BK * sizeof(bf16_t);  // 128 KiB
+        static bool attr256 = false;
+        if (!attr256) {
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt256_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
+            attr256 = true;
+        }
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            HIP_CHECK_RET(hipGetDevice(&dev));
+            HIP_CHECK_RET(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+            n_cu = (n_cu / 8) * 8;
+            if (n_cu < 8) n_cu = 8;
+        }
+        const int ntiles = ((M + 255) / 256) * (N / 256);
+        int grid = n_cu;                       // persistent: one 512-thread workgroup (128 KiB LDS) per CU
+        while (grid > 8 && (grid / 8) * 8 > ntiles) grid -= 8;
+        hipLaunchKernelGGL(gemm_nt256_bf16_kernel, dim3(grid), dim3(NT256_THREADS), lds256, (hipStream_t)stream, p);
+        return svla_launch_status();
+    }
     const int mt = (M + BM - 1) / BM, nt = N / BN;
-    const size_t lds = BM * (BN + 4) * sizeof(float);  // 66 KiB: max(operand double buffers 64 KiB, fp32 epilogue tile)
+    const size_t lds = BM * (BN + 4) * sizeof(float);  // 66 KiB: max(NST operand stages 64 KiB, fp32 epilogue tile)
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

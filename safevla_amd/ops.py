@@ -123,6 +123,10 @@ def gemm_nt(A, B, M, N, K, bias=None, residual=None, relu_mask=None, act=ACT_NON
     return out
 
 
+def gemm_force_small_tile(on: bool):
+    lib().call("svla_gemm_force_small_tile", int(bool(on)))
+
+
 def gemm_tn_acc(dY, X, dW, M, N, K, ldy=None, ldx=None, ldw=None):
     """dW[N,K] (fp32) += dY[M,N]^T @ X[M,K]."""
     _chk(dY, BF16, "dY")
