@@ -34,6 +34,16 @@ struct AttnArgs {
 __device__ __forceinline__ bf16x8 lds_row8(const bf16_t* base, int row, int col) {
     return *(const bf16x8*)(base + row * LDSROW + col);
 }
+// same with the per-lane part (row = lane&15, col = 8*(lane>>4)) pre-added to ``lane_base``: with unrolled tile loops the
+// remaining offset is a compile-time immediate of the ds_read
+__device__ __forceinline__ bf16x8 lds_row8i(const bf16_t* lane_base, int tile_row0, int col0) {
+    return *(const bf16x8*)(lane_base + tile_row0 * LDSROW + col0);
+}
+__device__ __forceinline__ bf16x8 lds_tr8i(const bf16_t* lane_base, int rA, int rB, int c0) {
+    const bf16x4 lo = lds_tr16_b64(lane_base + rA * LDSROW + c0);
+    const bf16x4 hi = lds_tr16_b64(lane_base + rB * LDSROW + c0);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
 // B-operand gather: 8 reduction slots = rows {rA + 4g + 0..3, rB + 4g + 0..3}, column c0 + (lane & 15)
 __device__ __forceinline__ bf16x8 lds_tr8(const bf16_t* base, int rA, int rB, int c0, int lane) {
     const int p = lane & 15, g = lane >> 4;
@@ -42,11 +52,13 @@ __device__ __forceinline__ bf16x8 lds_tr8(const bf16_t* base, int rA, int rB, in
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 __device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
-    bf16x8 r;
+    u32x4 w;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = (short)f2bf(v[i]);
-    return r;
+    for (int i = 0; i < 4; ++i) w[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
+    return __builtin_bit_cast(bf16x8, w);
 }
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
 
 // stage an [S, 64] head slice into LDS rows (zero-filled up to s_pad)
 __device__ __forceinline__ void stage_head(bf16_t* dst, const bf16_t* src, long ld, int S, int s_pad, int tid) {
@@ -66,7 +78,9 @@ __device__ __forceinline__ bool masked(const AttnArgs& p, int q, int key, const 
 }
 
 // ================================================================================================ forward
-template <int NKT>
+// GENERIC = false: no bias / traj / padding mask (the fusion encoder, >99 % of the attention work): only the ragged tail
+// of the last key tile is masked and the softmax runs in the exp2 domain with the scale folded in.
+template <int NKT, bool GENERIC>
 __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16;
@@ -87,6 +101,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
     __syncthreads();
     const unsigned char* kvp = p.kvalid ? kv_s : nullptr;
     const int ql = lane & 15, g = lane >> 4;
+    const bf16_t* Krow = Ks + ql * LDSROW + 8 * g;                                  // row-fragment lane base
+    const bf16_t* Vtr = Vs + (4 * g + (ql >> 2)) * LDSROW + 4 * (ql & 3);           // transpose-read lane base
     const int nqt = (S + 15) / 16;
     for (int qt = wid; qt < nqt; qt += ATT_THREADS / 64) {
         const int q = qt * 16 + ql;
@@ -98,21 +114,34 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
         }
         float sc[NKT][4];
         float mx = -INFINITY;
+        const float sl2 = p.scale * LOG2E;      // scores are kept in the log2 domain: p = exp2(s*scale*log2e - max)
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
             if (kt * 16 < S) {
-                a = mfma16(lds_row8(Ks, kt * 16 + ql, 8 * g), qf[0], a);
-                a = mfma16(lds_row8(Ks, kt * 16 + ql, 32 + 8 * g), qf[1], a);
+                a = mfma16(lds_row8i(Krow, kt * 16, 0), qf[0], a);
+                a = mfma16(lds_row8i(Krow, kt * 16, 32), qf[1], a);
             }
+            if constexpr (GENERIC) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int key = kt * 16 + 4 * g + e;
-                float s = a[e] * p.scale;
-                if (p.bias && q < S && key < S) s += p.bias[((size_t)h * S + q) * S + key];
-                if (masked(p, q < S ? q : 0, key, traj_s, kvp)) s = -INFINITY;
-                sc[kt][e] = s;
-                mx = fmaxf(mx, s);
+                for (int e = 0; e < 4; ++e) {
+                    const int key = kt * 16 + 4 * g + e;
+                    float s = a[e] * p.scale;
+                    if (p.bias && q < S && key < S) s += p.bias[((size_t)h * S + q) * S + key];
+                    s *= LOG2E;
+                    if (masked(p, q < S ? q : 0, key, traj_s, kvp)) s = -INFINITY;
+                    sc[kt][e] = s;
+                    mx = fmaxf(mx, s);
+                }
+            } else {
+                const bool tail = (kt + 1) * 16 > S;      // wave-uniform: only the last (ragged) key tile needs masking
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float s = a[e] * sl2;
+                    if (tail && kt * 16 + 4 * g + e >= S) s = -INFINITY;
+                    sc[kt][e] = s;
+                    mx = fmaxf(mx, s);
+                }
             }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -122,7 +151,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { sc[kt][e] = __expf(sc[kt][e] - mx); lsum += sc[kt][e]; }
+            for (int e = 0; e < 4; ++e) { sc[kt][e] = __builtin_amdgcn_exp2f(sc[kt][e] - mx); lsum += sc[kt][e]; }
         lsum += __shfl_xor(lsum, 16, 64);
         lsum += __shfl_xor(lsum, 32, 64);
         f32x4 o[4];
@@ -136,7 +165,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
                 const bf16x8 pa = pack8(pv);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
-                    o[dt] = mfma16(pa, lds_tr8(Vs, 32 * u, 32 * u + 16, dt * 16, lane), o[dt]);
+                    o[dt] = mfma16(pa, lds_tr8i(Vtr, 32 * u, 32 * u + 16, dt * 16), o[dt]);
             }
         }
         // o[dt][e]: query row qt*16 + 4g + e, column dt*16 + ql
@@ -151,7 +180,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
                     p.O[(tok0 + qo) * p.ldo + h * HD + dt * 16 + ql] = f2bf(o[dt][e] * inv);
             }
         }
-        if (p.LSE && g == 0 && q < S) p.LSE[((size_t)r * p.H + h) * S + q] = mx + __logf(lsum);
+        if (p.LSE && g == 0 && q < S) p.LSE[((size_t)r * p.H + h) * S + q] = (mx + __log2f(lsum)) * LN2;   // natural-log LSE
     }
 }
 
@@ -170,7 +199,7 @@ __device__ __forceinline__ float dot8(bf16x8 a, bf16x8 b) {
     return s;
 }
 
-template <int NKT>
+template <int NKT, bool GENERIC>
 __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dq_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16;
@@ -191,6 +220,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dq_kernel(AttnArgs p) {
     __syncthreads();
     const unsigned char* kvp = p.kvalid ? kv_s : nullptr;
     const int ql = lane & 15, g = lane >> 4;
+    const bf16_t* Krow = Ks + ql * LDSROW + 8 * g;
+    const bf16_t* Vrow = Vs + ql * LDSROW + 8 * g;
+    const bf16_t* Ktr = Ks + (4 * g + (ql >> 2)) * LDSROW + 4 * (ql & 3);
     const int ntile = (S + 15) / 16;
     for (int qt = wid; qt < ntile; qt += ATT_THREADS / 64) {
         const int q = qt * 16 + ql;
@@ -204,10 +236,11 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dq_kernel(AttnArgs p) {
         D_q += __shfl_xor(D_q, 16, 64);
         D_q += __shfl_xor(D_q, 32, 64);
         const float lse_q = qok ? p.LSE[((size_t)r * p.H + h) * S + q] : INFINITY;
+        const float sl2 = p.scale * LOG2E, lse2_q = lse_q * LOG2E;
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+#pragma unroll
         for (int u = 0; u < NKT / 2; ++u) {
             if (u * 32 < S) {
                 float dsv[8];
@@ -215,24 +248,32 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dq_kernel(AttnArgs p) {
                 for (int e2 = 0; e2 < 2; ++e2) {
                     const int kt = 2 * u + e2;
                     f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                    s = mfma16(lds_row8(Ks, kt * 16 + ql, 8 * g), qf0, s);
-                    s = mfma16(lds_row8(Ks, kt * 16 + ql, 32 + 8 * g), qf1, s);
-                    dp = mfma16(lds_row8(Vs, kt * 16 + ql, 8 * g), gf0, dp);
-                    dp = mfma16(lds_row8(Vs, kt * 16 + ql, 32 + 8 * g), gf1, dp);
+                    s = mfma16(lds_row8i(Krow, kt * 16, 0), qf0, s);
+                    s = mfma16(lds_row8i(Krow, kt * 16, 32), qf1, s);
+                    dp = mfma16(lds_row8i(Vrow, kt * 16, 0), gf0, dp);
+                    dp = mfma16(lds_row8i(Vrow, kt * 16, 32), gf1, dp);
+                    if constexpr (GENERIC) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int key = kt * 16 + 4 * g + e;
-                        float sv = s[e] * p.scale;
-                        if (p.bias && qok && key < S) sv += p.bias[((size_t)h * S + q) * S + key];
-                        const bool mk = !qok || masked(p, qok ? q : 0, key, traj_s, kvp);
-                        const float pr = mk ? 0.f : __expf(sv - lse_q);
-                        dsv[e2 * 4 + e] = pr * (dp[e] - D_q) * p.scale;
+                        for (int e = 0; e < 4; ++e) {
+                            const int key = kt * 16 + 4 * g + e;
+                            float sv = s[e] * p.scale;
+                            if (p.bias && qok && key < S) sv += p.bias[((size_t)h * S + q) * S + key];
+                            const bool mk = !qok || masked(p, qok ? q : 0, key, traj_s, kvp);
+                            const float pr = mk ? 0.f : __expf(sv - lse_q);
+                            dsv[e2 * 4 + e] = pr * (dp[e] - D_q) * p.scale;
+                        }
+                    } else {
+                        // no mask needed: padded keys have zero K rows (their dS never reaches dQ), padded queries have
+                        // lse = +inf => P = 0
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            dsv[e2 * 4 + e] = __builtin_amdgcn_exp2f(s[e] * sl2 - lse2_q) * (dp[e] - D_q) * p.scale;
                     }
                 }
                 const bf16x8 da = pack8(dsv);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
-                    dq[dt] = mfma16(da, lds_tr8(Ks, 32 * u, 32 * u + 16, dt * 16, lane), dq[dt]);
+                    dq[dt] = mfma16(da, lds_tr8i(Ktr, 32 * u, 32 * u + 16, dt * 16), dq[dt]);
             }
         }
 #pragma unroll
@@ -247,7 +288,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dq_kernel(AttnArgs p) {
     }
 }
 
-template <int NKT>
+template <int NKT, bool GENERIC>
 __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dkv_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16;
@@ -266,7 +307,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dkv_kernel(AttnArgs p) {
     for (int i = tid; i < SP; i += ATT_THREADS) {
         traj_s[i] = (p.traj && i < S) ? p.traj[tok0 + i] : -1;
         kv_s[i] = (p.kvalid && i < S) ? p.kvalid[tok0 + i] : 1;
-        lse_s[i] = i < S ? p.LSE[((size_t)r * p.H + h) * S + i] : INFINITY;  // +inf => P = 0 for padded queries
+        lse_s[i] = i < S ? p.LSE[((size_t)r * p.H + h) * S + i] * (GENERIC ? 1.f : LOG2E) : INFINITY;  // +inf => P = 0 for padded queries
     }
     for (int row = wid; row < SP; row += ATT_THREADS / 64) {  // D[q] = sum_d dO[q,d] * O[q,d]
         float v = 0.f;
@@ -278,6 +319,11 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dkv_kernel(AttnArgs p) {
     const unsigned char* kvp = p.kvalid ? kv_s : nullptr;
     const int ql = lane & 15, g = lane >> 4;
     const int ntile = (S + 15) / 16;
+    const float sl2 = p.scale * LOG2E;
+    const bf16_t* Qrow = Qs + ql * LDSROW + 8 * g;
+    const bf16_t* Grow = Gs + ql * LDSROW + 8 * g;
+    const bf16_t* Qtr = Qs + (4 * g + (ql >> 2)) * LDSROW + 4 * (ql & 3);
+    const bf16_t* Gtr = Gs + (4 * g + (ql >> 2)) * LDSROW + 4 * (ql & 3);
     for (int kt = wid; kt < ntile; kt += ATT_THREADS / 64) {
         const int keyl = kt * 16 + ql;  // this lane's key as the B-operand column
         const bool kok = keyl < S;
@@ -288,7 +334,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dkv_kernel(AttnArgs p) {
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll 2
+#pragma unroll
         for (int w = 0; w < NKT / 2; ++w) {
             if (w * 32 < S) {
                 float pv[8], dsv[8];
@@ -296,27 +342,38 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dkv_kernel(AttnArgs p) {
                 for (int e2 = 0; e2 < 2; ++e2) {
                     const int qt = 2 * w + e2;
                     f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                    s = mfma16(lds_row8(Qs, qt * 16 + ql, 8 * g), kf0, s);
-                    s = mfma16(lds_row8(Qs, qt * 16 + ql, 32 + 8 * g), kf1, s);
-                    dp = mfma16(lds_row8(Gs, qt * 16 + ql, 8 * g), vf0, dp);
-                    dp = mfma16(lds_row8(Gs, qt * 16 + ql, 32 + 8 * g), vf1, dp);
+                    s = mfma16(lds_row8i(Qrow, qt * 16, 0), kf0, s);
+                    s = mfma16(lds_row8i(Qrow, qt * 16, 32), kf1, s);
+                    dp = mfma16(lds_row8i(Grow, qt * 16, 0), vf0, dp);
+                    dp = mfma16(lds_row8i(Grow, qt * 16, 32), vf1, dp);
                     // s[e]: query qt*16 + 4g + e, key keyl
+                    if constexpr (GENERIC) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int q = qt * 16 + 4 * g + e;
-                        float sv = s[e] * p.scale;
-                        if (p.bias && q < S && kok) sv += p.bias[((size_t)h * S + q) * S + keyl];
-                        const bool mk = (q >= S) || masked(p, q < S ? q : 0, keyl, traj_s, kvp);
-                        const float pr = mk ? 0.f : __expf(sv - lse_s[q]);
-                        pv[e2 * 4 + e] = pr;
-                        dsv[e2 * 4 + e] = pr * (dp[e] - D_s[q]) * p.scale;
+                        for (int e = 0; e < 4; ++e) {
+                            const int q = qt * 16 + 4 * g + e;
+                            float sv = s[e] * p.scale;
+                            if (p.bias && q < S && kok) sv += p.bias[((size_t)h * S + q) * S + keyl];
+                            const bool mk = (q >= S) || masked(p, q < S ? q : 0, keyl, traj_s, kvp);
+                            const float pr = mk ? 0.f : __expf(sv - lse_s[q]);
+                            pv[e2 * 4 + e] = pr;
+                            dsv[e2 * 4 + e] = pr * (dp[e] - D_s[q]) * p.scale;
+                        }
+                    } else {
+                        // lse_s holds lse*log2e here (+inf for padded queries => P = 0); padded key columns are never stored
+                        const f32x4 l4 = *(const f32x4*)(lse_s + 4 * g + qt * 16), d4 = *(const f32x4*)(D_s + 4 * g + qt * 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float pr = __builtin_amdgcn_exp2f(s[e] * sl2 - l4[e]);
+                            pv[e2 * 4 + e] = pr;
+                            dsv[e2 * 4 + e] = pr * (dp[e] - d4[e]) * p.scale;
+                        }
                     }
                 }
                 const bf16x8 pa = pack8(pv), da = pack8(dsv);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    dv[dt] = mfma16(pa, lds_tr8(Gs, 32 * w, 32 * w + 16, dt * 16, lane), dv[dt]);
-                    dk[dt] = mfma16(da, lds_tr8(Qs, 32 * w, 32 * w + 16, dt * 16, lane), dk[dt]);
+                    dv[dt] = mfma16(pa, lds_tr8i(Gtr, 32 * w, 32 * w + 16, dt * 16), dv[dt]);
+                    dk[dt] = mfma16(da, lds_tr8i(Qtr, 32 * w, 32 * w + 16, dt * 16), dk[dt]);
                 }
             }
         }
@@ -338,8 +395,14 @@ template <int NKT>
 static int launch_fwd(const AttnArgs& p, int rows, hipStream_t st) {
     const size_t lds = (size_t)2 * NKT * 16 * LDSROW * sizeof(bf16_t) + NKT * 16 * (sizeof(int) + 1);
     static bool attr = false;
-    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-    hipLaunchKernelGGL(attn_fwd_kernel<NKT>, dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    const bool generic = p.mask_mode != MASK_NONE || p.bias || p.kvalid;
+    if (generic) hipLaunchKernelGGL((attn_fwd_kernel<NKT, true>), dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<NKT, false>), dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
     return svla_launch_status();
 }
 template <int NKT>
@@ -348,12 +411,20 @@ static int launch_bwd(const AttnArgs& p, int rows, hipStream_t st) {
     const size_t lds_kv = (size_t)2 * NKT * 16 * LDSROW * sizeof(bf16_t) + NKT * 16 * (2 * sizeof(float) + sizeof(int) + 1);
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<NKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<NKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<NKT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<NKT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv));
         attr = true;
     }
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<NKT>, dim3(rows * p.H), dim3(ATT_THREADS), lds_q, st, p);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NKT>, dim3(rows * p.H), dim3(ATT_THREADS), lds_kv, st, p);
+    const bool generic = p.mask_mode != MASK_NONE || p.bias || p.kvalid;
+    if (generic) {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<NKT, true>), dim3(rows * p.H), dim3(ATT_THREADS), lds_q, st, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKT, true>), dim3(rows * p.H), dim3(ATT_THREADS), lds_kv, st, p);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<NKT, false>), dim3(rows * p.H), dim3(ATT_THREADS), lds_q, st, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKT, false>), dim3(rows * p.H), dim3(ATT_THREADS), lds_kv, st, p);
+    }
     return svla_launch_status();
 }
 
