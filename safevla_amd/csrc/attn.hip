@@ -60,13 +60,23 @@ __device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 
-// stage an [S, 64] head slice into LDS rows (zero-filled up to s_pad)
-__device__ __forceinline__ void stage_head(bf16_t* dst, const bf16_t* src, long ld, int S, int s_pad, int tid) {
-    for (int q = tid; q < s_pad * 8; q += ATT_THREADS) {
+// stage an [S, 64] head slice into LDS rows (zero-filled up to SP rows): all global loads are issued before the first LDS
+// store so the HBM/L2 latency is paid once, not once per loop trip
+template <int SP>
+__device__ __forceinline__ void stage_head(bf16_t* dst, const bf16_t* src, long ld, int S, int tid) {
+    constexpr int IT = SP * 8 / ATT_THREADS;   // SP is a multiple of 32
+    u32x4 w[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int q = tid + i * ATT_THREADS;
         const int row = q >> 3, c = q & 7;
-        u32x4 w = {0, 0, 0, 0};
-        if (row < S) w = *(const u32x4*)(src + (size_t)row * ld + c * 8);
-        *(u32x4*)(dst + row * LDSROW + c * 8) = w;
+        w[i] = u32x4{0, 0, 0, 0};
+        if (row < S) w[i] = *(const u32x4*)(src + (size_t)row * ld + c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int q = tid + i * ATT_THREADS;
+        *(u32x4*)(dst + (q >> 3) * LDSROW + (q & 7) * 8) = w[i];
     }
 }
 
@@ -92,26 +102,36 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
     const int r = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const size_t tok0 = (size_t)r * p.S;
     const int S = p.S;
-    stage_head(Ks, p.K + tok0 * p.ld + h * HD, p.ld, S, SP, tid);
-    stage_head(Vs, p.V + tok0 * p.ld + h * HD, p.ld, S, SP, tid);
+    stage_head<SP>(Ks, p.K + tok0 * p.ld + h * HD, p.ld, S, tid);
+    stage_head<SP>(Vs, p.V + tok0 * p.ld + h * HD, p.ld, S, tid);
     for (int i = tid; i < SP; i += ATT_THREADS) {
         traj_s[i] = (p.traj && i < S) ? p.traj[tok0 + i] : -1;
         kv_s[i] = (p.kvalid && i < S) ? p.kvalid[tok0 + i] : 1;
     }
+    const int ql = lane & 15, g = lane >> 4;
+    const int nqt = (S + 15) / 16;
+    // Q fragments of all of this wave's query tiles (qt = wid, wid+4, ...): issued before the barrier so their latency
+    // overlaps the K/V staging instead of stalling every tile
+    constexpr int MAXQT = (NKT + 3) / 4;
+    bf16x8 qall[MAXQT][2];
+#pragma unroll
+    for (int t = 0; t < MAXQT; ++t) {
+        const int q = (wid + 4 * t) * 16 + ql;
+        const bool ok = q < S;
+        const bf16_t* qp = p.Q + (tok0 + (ok ? q : 0)) * p.ld + h * HD + 8 * g;
+        qall[t][0] = ok ? *(const bf16x8*)qp : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        qall[t][1] = ok ? *(const bf16x8*)(qp + 32) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
     __syncthreads();
     const unsigned char* kvp = p.kvalid ? kv_s : nullptr;
-    const int ql = lane & 15, g = lane >> 4;
     const bf16_t* Krow = Ks + ql * LDSROW + 8 * g;                                  // row-fragment lane base
     const bf16_t* Vtr = Vs + (4 * g + (ql >> 2)) * LDSROW + 4 * (ql & 3);           // transpose-read lane base
-    const int nqt = (S + 15) / 16;
-    for (int qt = wid; qt < nqt; qt += ATT_THREADS / 64) {
+#pragma unroll
+    for (int t = 0; t < MAXQT; ++t) {
+        const int qt = wid + 4 * t;
+        if (qt >= nqt) break;
         const int q = qt * 16 + ql;
-        bf16x8 qf[2] = {bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, bf16x8{0, 0, 0, 0, 0, 0, 0, 0}};
-        if (q < S) {
-            const bf16_t* qp = p.Q + (tok0 + q) * p.ld + h * HD + 8 * g;
-            qf[0] = *(const bf16x8*)qp;
-            qf[1] = *(const bf16x8*)(qp + 32);
-        }
+        const bf16x8 qf[2] = {qall[t][0], qall[t][1]};
         float sc[NKT][4];
         float mx = -INFINITY;
         const float sl2 = p.scale * LOG2E;      // scores are kept in the log2 domain: p = exp2(s*scale*log2e - max)
@@ -211,31 +231,46 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dq_kernel(AttnArgs p) {
     const int r = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const size_t tok0 = (size_t)r * p.S;
     const int S = p.S;
-    stage_head(Ks, p.K + tok0 * p.ld + h * HD, p.ld, S, SP, tid);
-    stage_head(Vs, p.V + tok0 * p.ld + h * HD, p.ld, S, SP, tid);
+    stage_head<SP>(Ks, p.K + tok0 * p.ld + h * HD, p.ld, S, tid);
+    stage_head<SP>(Vs, p.V + tok0 * p.ld + h * HD, p.ld, S, tid);
     for (int i = tid; i < SP; i += ATT_THREADS) {
         traj_s[i] = (p.traj && i < S) ? p.traj[tok0 + i] : -1;
         kv_s[i] = (p.kvalid && i < S) ? p.kvalid[tok0 + i] : 1;
     }
-    __syncthreads();
-    const unsigned char* kvp = p.kvalid ? kv_s : nullptr;
     const int ql = lane & 15, g = lane >> 4;
-    const bf16_t* Krow = Ks + ql * LDSROW + 8 * g;
-    const bf16_t* Vrow = Vs + ql * LDSROW + 8 * g;
-    const bf16_t* Ktr = Ks + (4 * g + (ql >> 2)) * LDSROW + 4 * (ql & 3);
-    const int ntile = (S + 15) / 16;
-    for (int qt = wid; qt < ntile; qt += ATT_THREADS / 64) {
-        const int q = qt * 16 + ql;
+    // Q / dO fragments, D partials and LSE of all of this wave's query tiles, issued ahead of the staging barrier
+    constexpr int MAXQT = (NKT + 3) / 4;
+    bf16x8 qall[MAXQT][4];
+    float dall[MAXQT], lall[MAXQT];
+#pragma unroll
+    for (int t = 0; t < MAXQT; ++t) {
+        const int q = (wid + 4 * t) * 16 + ql;
         const bool qok = q < S;
         const bf16_t* qp = p.Q + (tok0 + (qok ? q : 0)) * p.ld + h * HD + 8 * g;
         const bf16_t* gp = p.dO + (tok0 + (qok ? q : 0)) * p.lddo + h * HD + 8 * g;
         const bf16_t* op = p.O + (tok0 + (qok ? q : 0)) * p.ldo + h * HD + 8 * g;
-        const bf16x8 qf0 = gld8(qp, qok), qf1 = gld8(qp + 32, qok);
-        const bf16x8 gf0 = gld8(gp, qok), gf1 = gld8(gp + 32, qok);
-        float D_q = dot8(gf0, gld8(op, qok)) + dot8(gf1, gld8(op + 32, qok));
+        qall[t][0] = gld8(qp, qok); qall[t][1] = gld8(qp + 32, qok);
+        qall[t][2] = gld8(gp, qok); qall[t][3] = gld8(gp + 32, qok);
+        dall[t] = dot8(qall[t][2], gld8(op, qok)) + dot8(qall[t][3], gld8(op + 32, qok));
+        lall[t] = qok ? p.LSE[((size_t)r * p.H + h) * S + q] : INFINITY;
+    }
+    __syncthreads();
+    const unsigned char* kvp = p.kvalid ? kv_s : nullptr;
+    const bf16_t* Krow = Ks + ql * LDSROW + 8 * g;
+    const bf16_t* Vrow = Vs + ql * LDSROW + 8 * g;
+    const bf16_t* Ktr = Ks + (4 * g + (ql >> 2)) * LDSROW + 4 * (ql & 3);
+    const int ntile = (S + 15) / 16;
+#pragma unroll
+    for (int t = 0; t < MAXQT; ++t) {
+        const int qt = wid + 4 * t;
+        if (qt >= ntile) break;
+        const int q = qt * 16 + ql;
+        const bool qok = q < S;
+        const bf16x8 qf0 = qall[t][0], qf1 = qall[t][1], gf0 = qall[t][2], gf1 = qall[t][3];
+        float D_q = dall[t];
         D_q += __shfl_xor(D_q, 16, 64);
         D_q += __shfl_xor(D_q, 32, 64);
-        const float lse_q = qok ? p.LSE[((size_t)r * p.H + h) * S + q] : INFINITY;
+        const float lse_q = lall[t];
         const float sl2 = p.scale * LOG2E, lse2_q = lse_q * LOG2E;
         f32x4 dq[4];
 #pragma unroll
@@ -302,18 +337,47 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dkv_kernel(AttnArgs p) {
     const int r = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const size_t tok0 = (size_t)r * p.S;
     const int S = p.S;
-    stage_head(Qs, p.Q + tok0 * p.ld + h * HD, p.ld, S, SP, tid);
-    stage_head(Gs, p.dO + tok0 * p.lddo + h * HD, p.lddo, S, SP, tid);
+    // this wave's K/V B-operand fragments for all its key tiles, issued ahead of the staging barrier
+    constexpr int MAXKT = (NKT + 3) / 4;
+    bf16x8 kvall[MAXKT][4];
+#pragma unroll
+    for (int t = 0; t < MAXKT; ++t) {
+        const int keyl = (wid + 4 * t) * 16 + (lane & 15);
+        const bool kok = keyl < S;
+        const bf16_t* kp = p.K + (tok0 + (kok ? keyl : 0)) * p.ld + h * HD + 8 * (lane >> 4);
+        const bf16_t* vp = p.V + (tok0 + (kok ? keyl : 0)) * p.ld + h * HD + 8 * (lane >> 4);
+        kvall[t][0] = gld8(kp, kok); kvall[t][1] = gld8(kp + 32, kok);
+        kvall[t][2] = gld8(vp, kok); kvall[t][3] = gld8(vp + 32, kok);
+    }
+    stage_head<SP>(Qs, p.Q + tok0 * p.ld + h * HD, p.ld, S, tid);
+    stage_head<SP>(Gs, p.dO + tok0 * p.lddo + h * HD, p.lddo, S, tid);
     for (int i = tid; i < SP; i += ATT_THREADS) {
         traj_s[i] = (p.traj && i < S) ? p.traj[tok0 + i] : -1;
         kv_s[i] = (p.kvalid && i < S) ? p.kvalid[tok0 + i] : 1;
         lse_s[i] = i < S ? p.LSE[((size_t)r * p.H + h) * S + i] * (GENERIC ? 1.f : LOG2E) : INFINITY;  // +inf => P = 0 for padded queries
     }
-    for (int row = wid; row < SP; row += ATT_THREADS / 64) {  // D[q] = sum_d dO[q,d] * O[q,d]
-        float v = 0.f;
-        if (row < S) v = bf2f(p.dO[(tok0 + row) * p.lddo + h * HD + lane]) * bf2f(p.O[(tok0 + row) * p.ldo + h * HD + lane]);
-        v = wave_sum(v);
-        if (lane == 0) D_s[row] = v;
+    {   // D[q] = sum_d dO[q,d] * O[q,d]: 4 lanes per row (16 columns each), all rows' loads in flight at once
+        constexpr int IT = SP * 4 / ATT_THREADS;
+        float part[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int q = tid + i * ATT_THREADS;
+            const int row = q >> 2, c = (q & 3) * 16;
+            part[i] = 0.f;
+            if (row < S) {
+                const bf16_t* gp = p.dO + (tok0 + row) * p.lddo + h * HD + c;
+                const bf16_t* op = p.O + (tok0 + row) * p.ldo + h * HD + c;
+                part[i] = dot8(*(const bf16x8*)gp, *(const bf16x8*)op) + dot8(*(const bf16x8*)(gp + 8), *(const bf16x8*)(op + 8));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            float v = part[i];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            const int q = tid + i * ATT_THREADS;
+            if ((q & 3) == 0) D_s[q >> 2] = v;
+        }
     }
     __syncthreads();
     const unsigned char* kvp = p.kvalid ? kv_s : nullptr;
@@ -324,13 +388,13 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dkv_kernel(AttnArgs p) {
     const bf16_t* Grow = Gs + ql * LDSROW + 8 * g;
     const bf16_t* Qtr = Qs + (4 * g + (ql >> 2)) * LDSROW + 4 * (ql & 3);
     const bf16_t* Gtr = Gs + (4 * g + (ql >> 2)) * LDSROW + 4 * (ql & 3);
-    for (int kt = wid; kt < ntile; kt += ATT_THREADS / 64) {
+#pragma unroll
+    for (int t = 0; t < MAXKT; ++t) {
+        const int kt = wid + 4 * t;
+        if (kt >= ntile) break;
         const int keyl = kt * 16 + ql;  // this lane's key as the B-operand column
         const bool kok = keyl < S;
-        const bf16_t* kp = p.K + (tok0 + (kok ? keyl : 0)) * p.ld + h * HD + 8 * g;
-        const bf16_t* vp = p.V + (tok0 + (kok ? keyl : 0)) * p.ld + h * HD + 8 * g;
-        const bf16x8 kf0 = gld8(kp, kok), kf1 = gld8(kp + 32, kok);
-        const bf16x8 vf0 = gld8(vp, kok), vf1 = gld8(vp + 32, kok);
+        const bf16x8 kf0 = kvall[t][0], kf1 = kvall[t][1], vf0 = kvall[t][2], vf1 = kvall[t][3];
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
