@@ -68,9 +68,10 @@ int svla_gemm_nt_bf16(const svla_bf16* A, long lda, const svla_bf16* B, long ldb
                       int out_f32, float alpha, void* stream);
 /* Test hook: force the 128x128-tile kernel even where the 256x256 one would be chosen (same cited layers). */
 int svla_gemm_force_small_tile(int on);
-/* dW[N,K] (fp32) += dY[M,N]^T . X[M,K]: weight gradients (autograd of the same layers).  N,K % 128 == 0. */
-int svla_gemm_tn_f32acc(const svla_bf16* dY, long ldy, const svla_bf16* X, long ldx, float* dW, long ldw, int M, int N, int K,
-                        void* stream);
+/* dW[N,K] (fp32) += dY[M,N]^T . X[M,K]: weight gradients (autograd of the same layers); optional fused bias gradient
+ * db[N] += sum_m dY[m,:] (db may be NULL).  N,K % 128 == 0. */
+int svla_gemm_tn_f32acc(const svla_bf16* dY, long ldy, const svla_bf16* X, long ldx, float* dW, long ldw, float* db, int M, int N,
+                        int K, void* stream);
 /* db[N] += sum_m dY[m*row_stride, :] (bias gradients; row_stride > 1 picks one token of every [S, D] group). */
 int svla_colsum_bf16(const svla_bf16* dY, long ldy, int M, int N, int row_stride, float* db, void* stream);
 

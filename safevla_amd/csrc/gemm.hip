@@ -565,9 +565,155 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_tn_bf16_kernel(GemmTnArgs p)
             }
 }
 
-extern "C" int svla_gemm_tn_f32acc(const bf16_t* dY, long ldy, const bf16_t* X, long ldx, float* dW, long ldw, int M, int N,
-                                   int K, void* stream) {
+extern "C" int svla_colsum_bf16(const bf16_t* dY, long ldy, int M, int N, int row_stride, float* db, void* stream);
+
+// =================================================================================================
+// 256x256 output-tile weight-gradient kernel: dW[256 n x 256 k] += dY[chunk rows, n]^T . X[chunk rows, k] per workgroup
+// (8 waves = 2(n) x 4(k), wave tile 128 x 64), 32 reduction rows per stage, 4-stage LDS-DMA pipeline (same counted-vmcnt
+// scheme as gemm_nt256).  LDS rows are 512 B; the XOR swizzle of the 16-byte chunk index by (row & 3) << 2 is applied to
+// the DMA source address and to the ds_read_b64_tr_b16 gathers (conflict-free).  Optional fused bias gradient:
+// db[n] += sum_m dY[m, n], accumulated from the dY fragments already in registers by the k-tile-0 / k-wave-0 waves.
+#define TN256_ROWS 32
+__device__ __forceinline__ bf16x8 frag_tr256(const bf16_t* tile, int step, int col0, int lane) {
+    const int pl = lane & 15, q = lane >> 4;
+    const int colq = col0 + 16 * (q & 1) + 4 * (pl & 3);
+    const int r0 = step * 16 + 8 * (q >> 1) + (pl >> 2);
+    const int r1 = r0 + 4;
+    const bf16x4 lo = lds_tr16_b64(tile + r0 * 256 + (((colq >> 3) ^ ((r0 & 3) << 2)) << 3) + (colq & 7));
+    const bf16x4 hi = lds_tr16_b64(tile + r1 * 256 + (((colq >> 3) ^ ((r1 & 3) << 2)) << 3) + (colq & 7));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+struct GemmTn256Args {
+    const bf16_t* dY; long ldy;
+    const bf16_t* X; long ldx;
+    float* dW; long ldw;
+    float* db;
+    int M, N, K, chunk_rows;
+};
+
+__global__ void __launch_bounds__(NT256_THREADS, 2) gemm_tn256_bf16_kernel(GemmTn256Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Ys = (bf16_t*)smem;                          // [NST][32][256]
+    bf16_t* Xs = Ys + NST * TN256_ROWS * 256;            // [NST][32][256]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wn = wid >> 2, wk = wid & 3;
+    const int ntk = p.K / 256, ntile = (p.N / 256) * ntk;
+    const int tile = blockIdx.x % ntile, chunk = blockIdx.x / ntile;
+    const int n0 = (tile / ntk) * 256, k0 = (tile % ntk) * 256;
+    const int mbeg = chunk * p.chunk_rows;
+    const int mend = min(p.M, mbeg + p.chunk_rows);      // multiple of 32 (launcher)
+    const int nst = (mend - mbeg) / TN256_ROWS;
+    if (nst <= 0) return;
+
+    // DMA: one wave instruction = 1 KiB = 2 tile rows; 16 instructions per operand per stage, 2 dY + 2 X per wave
+    const bf16_t* gy[2];
+    const bf16_t* gx[2];
+    int ldsoff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rb = (wid * 2 + j) * 2;
+        const int row = rb + (lane >> 5);
+        const int c = (lane & 31) ^ ((row & 3) << 2);
+        gy[j] = p.dY + (size_t)(mbeg + row) * p.ldy + n0 + c * 8;
+        gx[j] = p.X + (size_t)(mbeg + row) * p.ldx + k0 + c * 8;
+        ldsoff[j] = __builtin_amdgcn_readfirstlane(rb * 256);
+    }
+    auto stage = [&](int st, int t) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gy[j] + (size_t)t * TN256_ROWS * p.ldy),
+                                             (__attribute__((address_space(3))) void*)(Ys + st * TN256_ROWS * 256 + ldsoff[j]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gx[j] + (size_t)t * TN256_ROWS * p.ldx),
+                                             (__attribute__((address_space(3))) void*)(Xs + st * TN256_ROWS * 256 + ldsoff[j]), 16, 0, 0);
+        }
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = p.db && k0 == 0 && wk == 0;
+
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nst) stage(s, s);
+    for (int t = 0; t < nst; ++t) {
+        const int rem = nst - 1 - t;
+        if (rem >= NST - 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + NST - 1 < nst) stage((t + NST - 1) % NST, t + NST - 1);
+        const bf16_t* Yb = Ys + (t % NST) * TN256_ROWS * 256;
+        const bf16_t* Xb = Xs + (t % NST) * TN256_ROWS * 256;
+#pragma unroll
+        for (int s2 = 0; s2 < TN256_ROWS / 16; ++s2) {
+            bf16x8 fy[4], fx[2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fy[u] = frag_tr256(Yb, s2, wn * 128 + u * 32, lane);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) fx[u] = frag_tr256(Xb, s2, wk * 64 + u * 32, lane);
+            if (do_bias) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[u] += bf2f((bf16_t)fy[u][e]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = mfma32(fy[i], fx[j], acc[i][j]);
+        }
+    }
+    // acc[i][j][reg]: n = n0 + wn*128 + i*32 + (reg&3) + 8*(reg>>2) + 4*(lane>>5);  k = k0 + wk*64 + j*32 + (lane&31)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int k = k0 + wk * 64 + j * 32 + (lane & 31);
+                atomicAdd(p.dW + (size_t)n * p.ldw + k, acc[i][j][r]);
+            }
+    if (do_bias) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float v = bsum[u] + __shfl_xor(bsum[u], 32, 64);   // the two half-waves hold the two 8-row halves
+            if (lane < 32) atomicAdd(p.db + n0 + wn * 128 + u * 32 + lane, v);
+        }
+    }
+}
+
+extern "C" int svla_gemm_tn_f32acc(const bf16_t* dY, long ldy, const bf16_t* X, long ldx, float* dW, long ldw, float* db, int M,
+                                   int N, int K, void* stream) {
     if (M <= 0 || (N % 128) || (K % 128) || (ldy % 8) || (ldx % 8)) return SVLA_EINVAL;
+    if ((N % 256) == 0 && (K % 256) == 0 && (M % TN256_ROWS) == 0 && M >= 65536 && !g_force_small_tile) {
+        const int ntile256 = (N / 256) * (K / 256);
+        int chunks = 256 / ntile256;                                  // <= one workgroup per CU (no second dispatch wave)
+        if (chunks < 1) chunks = 1;
+        int chunk_rows = ((M + chunks - 1) / chunks + TN256_ROWS - 1) / TN256_ROWS * TN256_ROWS;
+        chunks = (M + chunk_rows - 1) / chunk_rows;
+        GemmTn256Args q{dY, ldy, X, ldx, dW, ldw, db, M, N, K, chunk_rows};
+        const size_t lds256 = (size_t)NST * 2 * TN256_ROWS * 256 * sizeof(bf16_t);   // 128 KiB
+        static bool attr256 = false;
+        if (!attr256) {
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_tn256_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
+            attr256 = true;
+        }
+        hipLaunchKernelGGL(gemm_tn256_bf16_kernel, dim3(ntile256 * chunks), dim3(NT256_THREADS), lds256, (hipStream_t)stream, q);
+        return svla_launch_status();
+    }
+    if (db) {   // small-tile path: bias gradient as a separate column-sum pass
+        const int rc = svla_colsum_bf16(dY, ldy, M, N, 1, db, stream);
+        if (rc) return rc;
+    }
     const int ntile = (N / 128) * (K / 128);
     // aim for ~2048 workgroups; chunk is a multiple of the 64-row reduction tile
     int chunks = (2048 + ntile - 1) / ntile;

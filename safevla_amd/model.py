@@ -315,23 +315,19 @@ class Tower(nn.Module):
         for i in reversed(range(len(ve.fusion_xformer.layers))):
             l, a = ve.fusion_xformer.layers[i], c["fusion"][i]
             dh2 = ops.norm_bwd(dyf, a["h2"], l.norm2.weight, l.norm2.bias, a["n2"][0], a["n2"][1], M, g(l.norm2.weight), g(l.norm2.bias))
-            ops.gemm_tn_acc(dh2, a["f1"], dw[f"f{i}.l2"], M, D, 2048)
-            ops.colsum_acc(dh2, g(l.linear2.bias), M, D)
+            ops.gemm_tn_acc(dh2, a["f1"], dw[f"f{i}.l2"], M, D, 2048, db=g(l.linear2.bias))
             df1 = ops.gemm_nt(dh2, wt[f"f{i}.l2"], M, 2048, D, relu_mask=a["f1"])
-            ops.gemm_tn_acc(df1, a["x1"], dw[f"f{i}.l1"], M, 2048, D)
-            ops.colsum_acc(df1, g(l.linear1.bias), M, 2048)
+            ops.gemm_tn_acc(df1, a["x1"], dw[f"f{i}.l1"], M, 2048, D, db=g(l.linear1.bias))
             dx1 = ops.gemm_nt(df1, wt[f"f{i}.l1"], M, D, 2048, residual=dh2)
             del df1
             dh1 = ops.norm_bwd(dx1, a["h1"], l.norm1.weight, l.norm1.bias, a["n1"][0], a["n1"][1], M, g(l.norm1.weight), g(l.norm1.bias))
-            ops.gemm_tn_acc(dh1, a["ao"], dw[f"f{i}.out"], M, D, D)
-            ops.colsum_acc(dh1, g(l.self_attn.out_proj.bias), M, D)
+            ops.gemm_tn_acc(dh1, a["ao"], dw[f"f{i}.out"], M, D, D, db=g(l.self_attn.out_proj.bias))
             dao = ops.gemm_nt(dh1, wt[f"f{i}.out"], M, D, D)
             dqkv = torch.empty(M, 3 * D, device=dev, dtype=BF16)
             q = a["qkv"]
             ops.attn_bwd(q, q[:, D:], q[:, 2 * D:], 3 * D, a["ao"], D, a["lse"], dao, D, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D,
                          R, S, 8, 0.125)
-            ops.gemm_tn_acc(dqkv, a["x"], dw[f"f{i}.in"], M, 3 * D, D)
-            ops.colsum_acc(dqkv, g(l.self_attn.in_proj_bias), M, 3 * D)
+            ops.gemm_tn_acc(dqkv, a["x"], dw[f"f{i}.in"], M, 3 * D, D, db=g(l.self_attn.in_proj_bias))
             dyf = ops.gemm_nt(dqkv, wt[f"f{i}.in"], M, D, 3 * D, residual=dh1)
             c["fusion"][i] = None
         dx0 = dyf
@@ -343,20 +339,16 @@ class Tower(nn.Module):
         ops.cast_bf16(dtf, dtf_b)
         dta = ops.norm_bwd(dtf_b, c["ta"], ve.text_adapter[1].weight, ve.text_adapter[1].bias, c["ta_stats"][0], c["ta_stats"][1], U * L,
                            g(ve.text_adapter[1].weight), g(ve.text_adapter[1].bias), relu=True)
-        ops.gemm_tn_acc(dta, c["t5"], dw["ta"], U * L, D, 512)
-        ops.colsum_acc(dta, g(ve.text_adapter[0].bias), U * L, D)
+        ops.gemm_tn_acc(dta, c["t5"], dw["ta"], U * L, D, 512, db=g(ve.text_adapter[0].bias))
         # visual adapter + compressor (both cameras in one batch)
         da1 = ops.norm_bwd(dx0, c["a1"], ve.visual_adapter[1].weight, ve.visual_adapter[1].bias, c["va"][0], c["va"][1], M2,
                            g(ve.visual_adapter[1].weight), g(ve.visual_adapter[1].bias), relu=True, dtok=self._dcamtok,
                            tok_group=NPATCH, dymap=(2 * NPATCH, S, 1))
-        ops.gemm_tn_acc(da1, c["c2"], dw["va"], M2, D, D)
-        ops.colsum_acc(da1, g(ve.visual_adapter[0].bias), M2, D)
+        ops.gemm_tn_acc(da1, c["c2"], dw["va"], M2, D, D, db=g(ve.visual_adapter[0].bias))
         dc2 = ops.gemm_nt(da1, wt["va"], M2, D, D, relu_mask=c["c2"])
-        ops.gemm_tn_acc(dc2, c["c1"], dw["c2"], M2, D, D)
-        ops.colsum_acc(dc2, g(ve.visual_compressor[2].bias), M2, D)
+        ops.gemm_tn_acc(dc2, c["c1"], dw["c2"], M2, D, D, db=g(ve.visual_compressor[2].bias))
         dc1 = ops.gemm_nt(dc2, wt["c2"], M2, D, D, relu_mask=c["c1"])
-        ops.gemm_tn_acc(dc1, prep.tokens.view(M2, DINO), dw["c1"], M2, D, DINO)
-        ops.colsum_acc(dc1, g(ve.visual_compressor[0].bias), M2, D)
+        ops.gemm_tn_acc(dc1, prep.tokens.view(M2, DINO), dw["c1"], M2, D, DINO, db=g(ve.visual_compressor[0].bias))
 
 
 # ================================================================================================ frozen T5

@@ -127,13 +127,13 @@ def gemm_force_small_tile(on: bool):
     lib().call("svla_gemm_force_small_tile", int(bool(on)))
 
 
-def gemm_tn_acc(dY, X, dW, M, N, K, ldy=None, ldx=None, ldw=None):
-    """dW[N,K] (fp32) += dY[M,N]^T @ X[M,K]."""
+def gemm_tn_acc(dY, X, dW, M, N, K, ldy=None, ldx=None, ldw=None, db=None):
+    """dW[N,K] (fp32) += dY[M,N]^T @ X[M,K];  optional fused bias gradient db[N] += dY.sum(0)."""
     _chk(dY, BF16, "dY")
     _chk(X, BF16, "X")
     _chk(dW, F32, "dW")
     lib().call("svla_gemm_tn_f32acc", _p(dY), ldy if ldy is not None else dY.stride(-2), _p(X),
-               ldx if ldx is not None else X.stride(-2), _p(dW), ldw if ldw is not None else dW.stride(-2), M, N, K, _stream())
+               ldx if ldx is not None else X.stride(-2), _p(dW), ldw if ldw is not None else dW.stride(-2), _p(db), M, N, K, _stream())
 
 
 def colsum_acc(dY, db, M, N, ldy=None, row_stride=1):

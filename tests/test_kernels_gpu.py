@@ -233,13 +233,22 @@ def test_gemm_nt_epilogues(ops, M, N):
     assert (outw[:, :N] == 0).all()
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (1000, 128, 128), (5000, 512, 384), (3001, 1536, 512), (20000, 512, 2048)])
-def test_gemm_tn(ops, M, N, K):
+@pytest.mark.parametrize("small", [False, True])
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (1000, 128, 128), (5000, 512, 384), (3001, 1536, 512), (20000, 512, 2048),
+                                   (65536, 256, 256), (100000 // 32 * 32, 512, 512), (70016, 1536, 256)])
+def test_gemm_tn(ops, M, N, K, small):
+    """128x128 register-staged kernel (forced / small shapes) and the 256x256 LDS-DMA kernel, with the fused bias gradient"""
     dY, X = bf(rnd(M, N, seed=1)), bf(rnd(M, K, seed=2))
     dW = torch.ones(N, K, device=DEV)
-    ops.gemm_tn_acc(dY.to(DEV).bfloat16(), X.to(DEV).bfloat16(), dW, M, N, K)
+    db = torch.ones(N, device=DEV)
+    ops.gemm_force_small_tile(small)
+    try:
+        ops.gemm_tn_acc(dY.to(DEV).bfloat16(), X.to(DEV).bfloat16(), dW, M, N, K, db=db)
+    finally:
+        ops.gemm_force_small_tile(False)
     want = 1 + dY.double().t() @ X.double()
     close(dW, want, 2e-4, 2e-4 * math.sqrt(M), "dW")
+    close(db, 1 + dY.double().sum(0), 2e-4, 2e-4 * math.sqrt(M), "db")
 
 
 def test_colsum(ops):
