@@ -79,14 +79,17 @@ int svla_colsum_bf16(const svla_bf16* dY, long ldy, int M, int N, int row_stride
 /* softmax(scale * Q K^T [+ bias] [mask]) V per (row, head), head_dim 64, tokens of one row contiguous (row*S + s).
  * mask_mode 0: none (nn.MultiheadAttention in the fusion encoder, allenact_dino_transformer.py:545-552,702-708);
  * 1: block-causal on traj ids (allenact_dino_transformer.py:398-402 + llama/model.py:317-319).
- * bias [H,S,S] + kvalid [rows,S]: T5 self-attention.  LSE [rows,H,S] is saved for the backward. */
+ * bias [H,S,S] + kvalid [rows,S]: T5 self-attention.  LSE [rows,H,Sq] is saved for the backward.
+ * Sq > 0: only the first Sq query tokens of every row are computed (Q/O/dO/dQ hold Sq rows per batch row, Q/dQ row
+ * strides ldq/lddq) -- the last fusion layer only feeds sequence position 0 onwards (allenact_dino_transformer.py:708).
+ * Sq = 0: all S queries, Q laid out like K/V. */
 int svla_attn_fwd_bf16(const svla_bf16* Q, const svla_bf16* K, const svla_bf16* V, long ld, svla_bf16* O, long ldo, float* LSE,
                        int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj, const float* bias,
-                       const unsigned char* kvalid, void* stream);
+                       const unsigned char* kvalid, int Sq, long ldq, void* stream);
 int svla_attn_bwd_bf16(const svla_bf16* Q, const svla_bf16* K, const svla_bf16* V, long ld, const svla_bf16* O, long ldo,
                        const float* LSE, const svla_bf16* dO, long lddo, svla_bf16* dQ, svla_bf16* dK, svla_bf16* dV, long ldd,
                        int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj, const float* bias,
-                       const unsigned char* kvalid, void* stream);
+                       const unsigned char* kvalid, int Sq, long ldq, long lddq, void* stream);
 
 /* ---- observation / embedding glue ---------------------------------------------------------------------------- */
 /* (R,C,7,12) fp32 channels-first DINO features -> bf16 tokens [R, ncam, P, C] (input layout of the 1x1-conv compressor,
@@ -105,6 +108,9 @@ int svla_decoder_embed_fwd(const svla_bf16* xf, long xf_row_stride, const float*
 int svla_decoder_embed_bwd(const svla_bf16* dout, const int64_t* prev_actions, const float* masks, const int64_t* hand, int T,
                            int B, int n_actions, svla_bf16* dxf, long dxf_row_stride, float* d_act_tab, float* d_hand_tab,
                            void* stream);
+/* dst[r,:] += src[r,:] on 512-wide rows with independent row strides: adds the position-0 gradients of the last fusion layer
+ * (allenact_dino_transformer.py:708 keeps only x[:, 0]) into the [R,S,512] input gradient. */
+int svla_rows_add_bf16(svla_bf16* dst, long dst_ld, const svla_bf16* src, long src_ld, int rows, int D, void* stream);
 /* llama FeedForward gate silu(a)*b (llama/model.py:359-360) on [a | b] rows. */
 int svla_swiglu_fwd(const svla_bf16* ab, long M, int Hd, svla_bf16* g, void* stream);
 int svla_swiglu_bwd(const svla_bf16* ab, const svla_bf16* dg, long M, int Hd, svla_bf16* dab, void* stream);

@@ -29,6 +29,8 @@ struct AttnArgs {
     const unsigned char* kvalid;          // [rows, S] key padding mask or null
     int S, H, mask_mode;
     float scale;
+    int Sq;                               // query rows per batch row present in Q / O / dO / dQ / LSE (<= S; S = all)
+    long ldq, lddq;                       // token row strides of Q and dQ (the K/V tensors use ld / ldd)
 };
 
 __device__ __forceinline__ bf16x8 lds_row8(const bf16_t* base, int row, int col) {
@@ -109,7 +111,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
         kv_s[i] = (p.kvalid && i < S) ? p.kvalid[tok0 + i] : 1;
     }
     const int ql = lane & 15, g = lane >> 4;
-    const int nqt = (S + 15) / 16;
+    const int Sq = p.Sq;
+    const size_t qtok0 = (size_t)r * Sq;
+    const int nqt = (Sq + 15) / 16;
     // Q fragments of all of this wave's query tiles (qt = wid, wid+4, ...): issued before the barrier so their latency
     // overlaps the K/V staging instead of stalling every tile
     constexpr int MAXQT = (NKT + 3) / 4;
@@ -117,8 +121,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int t = 0; t < MAXQT; ++t) {
         const int q = (wid + 4 * t) * 16 + ql;
-        const bool ok = q < S;
-        const bf16_t* qp = p.Q + (tok0 + (ok ? q : 0)) * p.ld + h * HD + 8 * g;
+        const bool ok = q < Sq;
+        const bf16_t* qp = p.Q + (qtok0 + (ok ? q : 0)) * p.ldq + h * HD + 8 * g;
         qall[t][0] = ok ? *(const bf16x8*)qp : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         qall[t][1] = ok ? *(const bf16x8*)(qp + 32) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
@@ -147,9 +151,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
                 for (int e = 0; e < 4; ++e) {
                     const int key = kt * 16 + 4 * g + e;
                     float s = a[e] * p.scale;
-                    if (p.bias && q < S && key < S) s += p.bias[((size_t)h * S + q) * S + key];
+                    if (p.bias && q < Sq && key < S) s += p.bias[((size_t)h * S + q) * S + key];
                     s *= LOG2E;
-                    if (masked(p, q < S ? q : 0, key, traj_s, kvp)) s = -INFINITY;
+                    if (masked(p, q < Sq ? q : 0, key, traj_s, kvp)) s = -INFINITY;
                     sc[kt][e] = s;
                     mx = fmaxf(mx, s);
                 }
@@ -194,13 +198,13 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
         for (int e = 0; e < 4; ++e) {
             const float inv = __shfl(inv_own, 4 * g + e, 64);
             const int qo = qt * 16 + 4 * g + e;
-            if (qo < S) {
+            if (qo < Sq) {
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
-                    p.O[(tok0 + qo) * p.ldo + h * HD + dt * 16 + ql] = f2bf(o[dt][e] * inv);
+                    p.O[(qtok0 + qo) * p.ldo + h * HD + dt * 16 + ql] = f2bf(o[dt][e] * inv);
             }
         }
-        if (p.LSE && g == 0 && q < S) p.LSE[((size_t)r * p.H + h) * S + q] = (mx + __log2f(lsum)) * LN2;   // natural-log LSE
+        if (p.LSE && g == 0 && q < Sq) p.LSE[((size_t)r * p.H + h) * Sq + q] = (mx + __log2f(lsum)) * LN2;   // natural-log LSE
     }
 }
 
@@ -238,6 +242,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dq_kernel(AttnArgs p) {
         kv_s[i] = (p.kvalid && i < S) ? p.kvalid[tok0 + i] : 1;
     }
     const int ql = lane & 15, g = lane >> 4;
+    const int Sq = p.Sq;
+    const size_t qtok0 = (size_t)r * Sq;
     // Q / dO fragments, D partials and LSE of all of this wave's query tiles, issued ahead of the staging barrier
     constexpr int MAXQT = (NKT + 3) / 4;
     bf16x8 qall[MAXQT][4];
@@ -245,27 +251,27 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
     for (int t = 0; t < MAXQT; ++t) {
         const int q = (wid + 4 * t) * 16 + ql;
-        const bool qok = q < S;
-        const bf16_t* qp = p.Q + (tok0 + (qok ? q : 0)) * p.ld + h * HD + 8 * g;
-        const bf16_t* gp = p.dO + (tok0 + (qok ? q : 0)) * p.lddo + h * HD + 8 * g;
-        const bf16_t* op = p.O + (tok0 + (qok ? q : 0)) * p.ldo + h * HD + 8 * g;
+        const bool qok = q < Sq;
+        const bf16_t* qp = p.Q + (qtok0 + (qok ? q : 0)) * p.ldq + h * HD + 8 * g;
+        const bf16_t* gp = p.dO + (qtok0 + (qok ? q : 0)) * p.lddo + h * HD + 8 * g;
+        const bf16_t* op = p.O + (qtok0 + (qok ? q : 0)) * p.ldo + h * HD + 8 * g;
         qall[t][0] = gld8(qp, qok); qall[t][1] = gld8(qp + 32, qok);
         qall[t][2] = gld8(gp, qok); qall[t][3] = gld8(gp + 32, qok);
         dall[t] = dot8(qall[t][2], gld8(op, qok)) + dot8(qall[t][3], gld8(op + 32, qok));
-        lall[t] = qok ? p.LSE[((size_t)r * p.H + h) * S + q] : INFINITY;
+        lall[t] = qok ? p.LSE[((size_t)r * p.H + h) * Sq + q] : INFINITY;
     }
     __syncthreads();
     const unsigned char* kvp = p.kvalid ? kv_s : nullptr;
     const bf16_t* Krow = Ks + ql * LDSROW + 8 * g;
     const bf16_t* Vrow = Vs + ql * LDSROW + 8 * g;
     const bf16_t* Ktr = Ks + (4 * g + (ql >> 2)) * LDSROW + 4 * (ql & 3);
-    const int ntile = (S + 15) / 16;
+    const int ntile = (Sq + 15) / 16;
 #pragma unroll
     for (int t = 0; t < MAXQT; ++t) {
         const int qt = wid + 4 * t;
         if (qt >= ntile) break;
         const int q = qt * 16 + ql;
-        const bool qok = q < S;
+        const bool qok = q < Sq;
         const bf16x8 qf0 = qall[t][0], qf1 = qall[t][1], gf0 = qall[t][2], gf1 = qall[t][3];
         float D_q = dall[t];
         D_q += __shfl_xor(D_q, 16, 64);
@@ -314,10 +320,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int qo = qt * 16 + 4 * g + e;
-            if (qo < S) {
+            if (qo < Sq) {
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
-                    p.dQ[(tok0 + qo) * p.ldd + h * HD + dt * 16 + ql] = f2bf(dq[dt][e]);
+                    p.dQ[(qtok0 + qo) * p.lddq + h * HD + dt * 16 + ql] = f2bf(dq[dt][e]);
             }
         }
     }
@@ -349,12 +355,14 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dkv_kernel(AttnArgs p) {
         kvall[t][0] = gld8(kp, kok); kvall[t][1] = gld8(kp + 32, kok);
         kvall[t][2] = gld8(vp, kok); kvall[t][3] = gld8(vp + 32, kok);
     }
-    stage_head<SP>(Qs, p.Q + tok0 * p.ld + h * HD, p.ld, S, tid);
-    stage_head<SP>(Gs, p.dO + tok0 * p.lddo + h * HD, p.lddo, S, tid);
+    const int Sq = p.Sq;
+    const size_t qtok0 = (size_t)r * Sq;
+    stage_head<SP>(Qs, p.Q + qtok0 * p.ldq + h * HD, p.ldq, Sq, tid);
+    stage_head<SP>(Gs, p.dO + qtok0 * p.lddo + h * HD, p.lddo, Sq, tid);
     for (int i = tid; i < SP; i += ATT_THREADS) {
         traj_s[i] = (p.traj && i < S) ? p.traj[tok0 + i] : -1;
         kv_s[i] = (p.kvalid && i < S) ? p.kvalid[tok0 + i] : 1;
-        lse_s[i] = i < S ? p.LSE[((size_t)r * p.H + h) * S + i] * (GENERIC ? 1.f : LOG2E) : INFINITY;  // +inf => P = 0 for padded queries
+        lse_s[i] = i < Sq ? p.LSE[((size_t)r * p.H + h) * Sq + i] * (GENERIC ? 1.f : LOG2E) : INFINITY;  // +inf => P = 0 for padded queries
     }
     {   // D[q] = sum_d dO[q,d] * O[q,d]: 4 lanes per row (16 columns each), all rows' loads in flight at once
         constexpr int IT = SP * 4 / ATT_THREADS;
@@ -364,9 +372,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dkv_kernel(AttnArgs p) {
             const int q = tid + i * ATT_THREADS;
             const int row = q >> 2, c = (q & 3) * 16;
             part[i] = 0.f;
-            if (row < S) {
-                const bf16_t* gp = p.dO + (tok0 + row) * p.lddo + h * HD + c;
-                const bf16_t* op = p.O + (tok0 + row) * p.ldo + h * HD + c;
+            if (row < Sq) {
+                const bf16_t* gp = p.dO + (qtok0 + row) * p.lddo + h * HD + c;
+                const bf16_t* op = p.O + (qtok0 + row) * p.ldo + h * HD + c;
                 part[i] = dot8(*(const bf16x8*)gp, *(const bf16x8*)op) + dot8(*(const bf16x8*)(gp + 8), *(const bf16x8*)(op + 8));
             }
         }
@@ -400,7 +408,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dkv_kernel(AttnArgs p) {
         for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int w = 0; w < NKT / 2; ++w) {
-            if (w * 32 < S) {
+            if (w * 32 < Sq) {
                 float pv[8], dsv[8];
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {
@@ -417,7 +425,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dkv_kernel(AttnArgs p) {
                             const int q = qt * 16 + 4 * g + e;
                             float sv = s[e] * p.scale;
                             if (p.bias && q < S && kok) sv += p.bias[((size_t)h * S + q) * S + keyl];
-                            const bool mk = (q >= S) || masked(p, q < S ? q : 0, keyl, traj_s, kvp);
+                            const bool mk = (q >= Sq) || masked(p, q < Sq ? q : 0, keyl, traj_s, kvp);
                             const float pr = mk ? 0.f : __expf(sv - lse_s[q]);
                             pv[e2 * 4 + e] = pr;
                             dsv[e2 * 4 + e] = pr * (dp[e] - D_s[q]) * p.scale;
@@ -494,12 +502,14 @@ static int launch_bwd(const AttnArgs& p, int rows, hipStream_t st) {
 
 extern "C" int svla_attn_fwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t* V, long ld, bf16_t* O, long ldo, float* LSE,
                                   int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj,
-                                  const float* bias, const unsigned char* kvalid, void* stream) {
+                                  const float* bias, const unsigned char* kvalid, int Sq, long ldq, void* stream) {
     if (head_dim != HD || rows <= 0 || S <= 0 || S > 448 || (ld % 8) || H <= 0) return SVLA_EINVAL;
     if (mask_mode == MASK_BLOCK_CAUSAL && !traj) return SVLA_EINVAL;
+    if (Sq < 0 || Sq > S || (Sq > 0 && (ldq % 8))) return SVLA_EINVAL;
     AttnArgs p{};
     p.Q = Q; p.K = K; p.V = V; p.ld = ld; p.O = O; p.ldo = ldo; p.LSE = LSE; p.traj = traj; p.bias = bias; p.kvalid = kvalid;
     p.S = S; p.H = H; p.mask_mode = mask_mode; p.scale = scale;
+    p.Sq = Sq > 0 ? Sq : S; p.ldq = Sq > 0 ? ldq : ld;
     hipStream_t st = (hipStream_t)stream;
     if (S <= 64) return launch_fwd<4>(p, rows, st);
     if (S <= 128) return launch_fwd<8>(p, rows, st);
@@ -511,10 +521,12 @@ extern "C" int svla_attn_fwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t
 extern "C" int svla_attn_bwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t* V, long ld, const bf16_t* O, long ldo,
                                   const float* LSE, const bf16_t* dO, long lddo, bf16_t* dQ, bf16_t* dK, bf16_t* dV, long ldd,
                                   int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj,
-                                  const float* bias, const unsigned char* kvalid, void* stream) {
+                                  const float* bias, const unsigned char* kvalid, int Sq, long ldq, long lddq, void* stream) {
     if (head_dim != HD || rows <= 0 || S <= 0 || S > 256 || (ld % 8) || (lddo % 8) || H <= 0) return SVLA_EINVAL;
     if (mask_mode == MASK_BLOCK_CAUSAL && !traj) return SVLA_EINVAL;
+    if (Sq < 0 || Sq > S || (Sq > 0 && ((ldq % 8) || (lddq % 8)))) return SVLA_EINVAL;
     AttnArgs p{};
+    p.Sq = Sq > 0 ? Sq : S; p.ldq = Sq > 0 ? ldq : ld; p.lddq = Sq > 0 ? lddq : ldd;
     p.Q = Q; p.K = K; p.V = V; p.ld = ld; p.O = (bf16_t*)O; p.ldo = ldo; p.LSE = (float*)LSE; p.dO = dO; p.lddo = lddo;
     p.dQ = dQ; p.dK = dK; p.dV = dV; p.ldd = ldd; p.traj = traj; p.bias = bias; p.kvalid = kvalid;
     p.S = S; p.H = H; p.mask_mode = mask_mode; p.scale = scale;

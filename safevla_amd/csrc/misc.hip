@@ -350,3 +350,19 @@ extern "C" int svla_row_hash_u8(const unsigned char* rows, long n_rows, int row_
     hipLaunchKernelGGL(row_hash_kernel, dim3((int)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rows, n_rows, row_bytes, out);
     return svla_launch_status();
 }
+
+// dst[r, :] += src[r, :] for 512-wide bf16 rows with independent row strides (token-0 rows of a [R, S, 512] gradient)
+__global__ void rows_add_kernel(bf16_t* __restrict__ dst, long dst_ld, const bf16_t* __restrict__ src, long src_ld, int rows) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= rows) return;
+    u32x4 a = *(const u32x4*)(dst + (size_t)wave * dst_ld + lane * 8);
+    const u32x4 b = *(const u32x4*)(src + (size_t)wave * src_ld + lane * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = pack_bf2(bf_lo(a[e]) + bf_lo(b[e]), bf_hi(a[e]) + bf_hi(b[e]));
+    *(u32x4*)(dst + (size_t)wave * dst_ld + lane * 8) = a;
+}
+extern "C" int svla_rows_add_bf16(bf16_t* dst, long dst_ld, const bf16_t* src, long src_ld, int rows, int D, void* stream) {
+    if (rows <= 0 || D != 512 || (dst_ld % 8) || (src_ld % 8)) return SVLA_EINVAL;
+    hipLaunchKernelGGL(rows_add_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dst, dst_ld, src, src_ld, rows);
+    return svla_launch_status();
+}

@@ -114,6 +114,7 @@ class Tower(nn.Module):
         self.device_ = device
         self.max_steps = max_steps
         self.time_step_counter = 0
+        self.prune_last = True      # dead-output elimination in the last fusion layer (exact; see run_forward)
         dec = arena.declare
         ve = self.visual_encoder = _NS()
         dec(ve, "fusion_token", (D,), "tok")
@@ -229,7 +230,26 @@ class Tower(nn.Module):
         c.update(c1=c1, c2=c2, a1=a1, va=(va_mean, va_rstd), t5=t5, ta=ta, ta_stats=(ta_mean, ta_rstd))
         xf = x.view(M, D)
         fl = []
+        nfl = len(ve.fusion_xformer.layers)
+        xf_stride = S * D
         for i, l in enumerate(ve.fusion_xformer.layers):
+            if i == nfl - 1 and self.prune_last:
+                # Only sequence position 0 of the last fusion layer is consumed (allenact_dino_transformer.py:708 x[:, 0]):
+                # K/V are still projected for all tokens, but Q / attention / out_proj / norm1 / FFN / norm2 run on the R
+                # position-0 rows only.  Identical outputs and gradients; ~84 % less work in this layer.
+                b_in = l.self_attn.in_proj_bias
+                kv = ops.gemm_nt(xf, w[f"f{i}.in"][D:], M, 2 * D, D, bias=b_in[D:])
+                q0 = ops.gemm_nt(xf, w[f"f{i}.in"][:D], R, D, D, bias=b_in[:D], lda=S * D)
+                ao, lse = ops.attn_fwd(q0, kv, kv[:, D:], 2 * D, R, S, 8, 0.125, save_lse=need_grad, Sq=1, ldq=D)
+                h1 = ops.gemm_nt(ao, w[f"f{i}.out"], R, D, D, bias=l.self_attn.out_proj.bias, residual=xf, ldr=S * D)
+                x1, m1, r1 = ops.norm_fwd(h1, l.norm1.weight, l.norm1.bias, 1e-5, R, save_stats=need_grad)
+                f1 = ops.gemm_nt(x1, w[f"f{i}.l1"], R, 2048, D, bias=l.linear1.bias, act=ops.ACT_RELU)
+                h2 = ops.gemm_nt(f1, w[f"f{i}.l2"], R, D, 2048, bias=l.linear2.bias, residual=x1)
+                xo, m2, r2 = ops.norm_fwd(h2, l.norm2.weight, l.norm2.bias, 1e-5, R, save_stats=need_grad)
+                if need_grad:
+                    fl.append(dict(pruned=True, x=xf, kv=kv, q0=q0, ao=ao, lse=lse, h1=h1, x1=x1, n1=(m1, r1), f1=f1, h2=h2, n2=(m2, r2)))
+                xf, xf_stride = xo, D
+                continue
             qkv = ops.gemm_nt(xf, w[f"f{i}.in"], M, 3 * D, D, bias=l.self_attn.in_proj_bias)
             ao, lse = ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, R, S, 8, 0.125, save_lse=need_grad)
             h1 = ops.gemm_nt(ao, w[f"f{i}.out"], M, D, D, bias=l.self_attn.out_proj.bias, residual=xf)
@@ -238,12 +258,12 @@ class Tower(nn.Module):
             h2 = ops.gemm_nt(f1, w[f"f{i}.l2"], M, D, 2048, bias=l.linear2.bias, residual=x1)
             xo, m2, r2 = ops.norm_fwd(h2, l.norm2.weight, l.norm2.bias, 1e-5, M, save_stats=need_grad)
             if need_grad:
-                fl.append(dict(x=xf, qkv=qkv, ao=ao, lse=lse, h1=h1, x1=x1, n1=(m1, r1), f1=f1, h2=h2, n2=(m2, r2)))
+                fl.append(dict(pruned=False, x=xf, qkv=qkv, ao=ao, lse=lse, h1=h1, x1=x1, n1=(m1, r1), f1=f1, h2=h2, n2=(m2, r2)))
             xf = xo
         c["fusion"] = fl
         # decoder over the rollout time axis, rows (b*T + t)
         j = torch.empty(R, D, device=self.device_, dtype=BF16)
-        ops.decoder_embed_fwd(xf, S * D, self.last_actions_embed.weight, self.object_in_hand_embed.weight,
+        ops.decoder_embed_fwd(xf, xf_stride, self.last_actions_embed.weight, self.object_in_hand_embed.weight,
                               self.time_encoder.div_term, prep.prev_actions, prep.masks, prep.hand, prep.time_step, T, B, j)
         xd = j
         dl = []
@@ -308,12 +328,41 @@ class Tower(nn.Module):
             ops.gemm_tn_acc(dqkv, a["n1"], dw[f"d{i}.qkv"], R, 3 * D, D)
             dn1 = ops.gemm_nt(dqkv, wt[f"d{i}.qkv"], R, D, 3 * D)
             dx = ops.norm_bwd(dn1, a["x"], l.attention_norm.weight, None, None, a["r1"], R, g(l.attention_norm.weight), None, rms=True, dres=dh)
-        dxf = torch.zeros(R, S, D, device=dev, dtype=BF16)
-        ops.decoder_embed_bwd(dx, prep.prev_actions, prep.masks, prep.hand, T, B, dxf, S * D, g(self.last_actions_embed.weight),
-                              g(self.object_in_hand_embed.weight))
-        dyf = dxf.view(M, D)
+        pruned = bool(c["fusion"]) and c["fusion"][-1]["pruned"]
+        if pruned:
+            dxf = torch.empty(R, D, device=dev, dtype=BF16)        # gradient of the position-0 outputs only
+            ops.decoder_embed_bwd(dx, prep.prev_actions, prep.masks, prep.hand, T, B, dxf, D, g(self.last_actions_embed.weight),
+                                  g(self.object_in_hand_embed.weight))
+            dyf = dxf
+        else:
+            dxf = torch.zeros(R, S, D, device=dev, dtype=BF16)
+            ops.decoder_embed_bwd(dx, prep.prev_actions, prep.masks, prep.hand, T, B, dxf, S * D, g(self.last_actions_embed.weight),
+                                  g(self.object_in_hand_embed.weight))
+            dyf = dxf.view(M, D)
         for i in reversed(range(len(ve.fusion_xformer.layers))):
             l, a = ve.fusion_xformer.layers[i], c["fusion"][i]
+            if a["pruned"]:
+                dh2 = ops.norm_bwd(dyf, a["h2"], l.norm2.weight, l.norm2.bias, a["n2"][0], a["n2"][1], R, g(l.norm2.weight), g(l.norm2.bias))
+                ops.gemm_tn_acc(dh2, a["f1"], dw[f"f{i}.l2"], R, D, 2048, db=g(l.linear2.bias))
+                df1 = ops.gemm_nt(dh2, wt[f"f{i}.l2"], R, 2048, D, relu_mask=a["f1"])
+                ops.gemm_tn_acc(df1, a["x1"], dw[f"f{i}.l1"], R, 2048, D, db=g(l.linear1.bias))
+                dx1 = ops.gemm_nt(df1, wt[f"f{i}.l1"], R, D, 2048, residual=dh2)
+                dh1 = ops.norm_bwd(dx1, a["h1"], l.norm1.weight, l.norm1.bias, a["n1"][0], a["n1"][1], R, g(l.norm1.weight), g(l.norm1.bias))
+                ops.gemm_tn_acc(dh1, a["ao"], dw[f"f{i}.out"], R, D, D, db=g(l.self_attn.out_proj.bias))
+                dao = ops.gemm_nt(dh1, wt[f"f{i}.out"], R, D, D)
+                dq0 = torch.empty(R, D, device=dev, dtype=BF16)
+                dkv = torch.empty(M, 2 * D, device=dev, dtype=BF16)
+                kv = a["kv"]
+                ops.attn_bwd(a["q0"], kv, kv[:, D:], 2 * D, a["ao"], D, a["lse"], dao, D, dq0, dkv, dkv[:, D:], 2 * D, R, S, 8, 0.125,
+                             Sq=1, ldq=D, lddq=D)
+                gb = g(l.self_attn.in_proj_bias)
+                ops.gemm_tn_acc(dkv, a["x"], dw[f"f{i}.in"][D:], M, 2 * D, D, db=gb[D:])
+                ops.gemm_tn_acc(dq0, a["x"], dw[f"f{i}.in"][:D], R, D, D, ldx=S * D, db=gb[:D])
+                dyf = ops.gemm_nt(dkv, wt[f"f{i}.in"][:, D:], M, D, 2 * D)                       # dX through K and V, all tokens
+                t0 = ops.gemm_nt(dq0, wt[f"f{i}.in"][:, :D], R, D, D, residual=dh1)             # position 0: Q path + residual path
+                ops.rows_add(dyf, S * D, t0, D, R)
+                c["fusion"][i] = None
+                continue
             dh2 = ops.norm_bwd(dyf, a["h2"], l.norm2.weight, l.norm2.bias, a["n2"][0], a["n2"][1], M, g(l.norm2.weight), g(l.norm2.bias))
             ops.gemm_tn_acc(dh2, a["f1"], dw[f"f{i}.l2"], M, D, 2048, db=g(l.linear2.bias))
             df1 = ops.gemm_nt(dh2, wt[f"f{i}.l2"], M, 2048, D, relu_mask=a["f1"])

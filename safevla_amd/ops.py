@@ -142,21 +142,23 @@ def colsum_acc(dY, db, M, N, ldy=None, row_stride=1):
 
 # ------------------------------------------------------------------------------------------------ attention
 def attn_fwd(q, k, v, ld, rows, S, H, scale, out=None, ldo=None, mask_mode=MASK_NONE, traj=None, bias=None, kvalid=None,
-             save_lse=True):
-    """q/k/v: bf16 views whose element (token, h*64+d) sits at token*ld + h*64 + d."""
+             save_lse=True, Sq=0, ldq=0):
+    """q/k/v: bf16 views whose element (token, h*64+d) sits at token*ld + h*64 + d.  Sq > 0: only the first Sq queries of
+    every row (q then holds Sq rows per batch row with row stride ldq)."""
+    nq = Sq if Sq > 0 else S
     if out is None:
-        out = torch.empty(rows * S, H * 64, device=q.device, dtype=BF16)
+        out = torch.empty(rows * nq, H * 64, device=q.device, dtype=BF16)
     ldo = ldo if ldo is not None else out.stride(-2)
-    lse = torch.empty(rows, H, S, device=q.device, dtype=F32) if save_lse else None
+    lse = torch.empty(rows, H, nq, device=q.device, dtype=F32) if save_lse else None
     lib().call("svla_attn_fwd_bf16", _p(q), _p(k), _p(v), ld, _p(out), ldo, _p(lse), rows, S, H, 64, float(scale), mask_mode,
-               _p(traj), _p(bias), _p(kvalid), _stream())
+               _p(traj), _p(bias), _p(kvalid), int(Sq), int(ldq), _stream())
     return out, lse
 
 
 def attn_bwd(q, k, v, ld, o, ldo, lse, do, lddo, dq, dk, dv, ldd, rows, S, H, scale, mask_mode=MASK_NONE, traj=None,
-             bias=None, kvalid=None):
+             bias=None, kvalid=None, Sq=0, ldq=0, lddq=0):
     lib().call("svla_attn_bwd_bf16", _p(q), _p(k), _p(v), ld, _p(o), ldo, _p(lse), _p(do), lddo, _p(dq), _p(dk), _p(dv), ldd,
-               rows, S, H, 64, float(scale), mask_mode, _p(traj), _p(bias), _p(kvalid), _stream())
+               rows, S, H, 64, float(scale), mask_mode, _p(traj), _p(bias), _p(kvalid), int(Sq), int(ldq), int(lddq), _stream())
 
 
 # ------------------------------------------------------------------------------------------------ glue
@@ -185,6 +187,10 @@ def decoder_embed_fwd(xf, xf_row_stride, act_tab, hand_tab, div_term, prev_actio
 def decoder_embed_bwd(dout, prev_actions, masks, hand, T, B, dxf, dxf_row_stride, d_act_tab, d_hand_tab, n_actions=20):
     lib().call("svla_decoder_embed_bwd", _p(dout), _p(prev_actions), _p(masks), _p(hand), T, B, n_actions, _p(dxf),
                dxf_row_stride, _p(d_act_tab), _p(d_hand_tab), _stream())
+
+
+def rows_add(dst, dst_ld, src, src_ld, rows):
+    lib().call("svla_rows_add_bf16", _p(dst), dst_ld, _p(src), src_ld, rows, 512, _stream())
 
 
 def swiglu_fwd(ab, M, Hd, out=None):

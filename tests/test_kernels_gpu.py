@@ -305,6 +305,41 @@ def test_attn_nomask(ops, S):
     _attn_case(ops, 3, S, 8)
 
 
+@pytest.mark.parametrize("Sq", [1, 5, 20])
+def test_attn_query_subset(ops, Sq):
+    """Sq > 0: only the first Sq queries of every row (last fusion layer: only sequence position 0 is consumed)."""
+    rows, S, H = 4, 181, 8
+    kv = bf(rnd(rows * S, 2 * H * 64, seed=1))
+    qs = bf(rnd(rows * Sq, H * 64, seed=2))
+    d_kv, d_q = kv.to(DEV).bfloat16(), qs.to(DEV).bfloat16()
+    k, v = [kv[:, i * H * 64 : (i + 1) * H * 64].view(rows, S, H, 64).transpose(1, 2).clone().requires_grad_(True) for i in range(2)]
+    q = qs.view(rows, Sq, H, 64).transpose(1, 2).clone().requires_grad_(True)
+    want = attn_ref(q, k, v, 0.125)
+    out, lse = ops.attn_fwd(d_q, d_kv, d_kv[:, H * 64 :], 2 * H * 64, rows, S, H, 0.125, Sq=Sq, ldq=H * 64)
+    assert out.shape == (rows * Sq, H * 64) and lse.shape == (rows, H, Sq)
+    close(out.float().view(rows, Sq, H, 64), want.transpose(1, 2), 1e-2, 1e-2, "O subset")
+    do = bf(rnd(rows * Sq, H * 64, seed=3))
+    want.backward(do.view(rows, Sq, H, 64).transpose(1, 2))
+    dq = torch.zeros_like(d_q)
+    dkv = torch.zeros_like(d_kv)
+    ops.attn_bwd(d_q, d_kv, d_kv[:, H * 64 :], 2 * H * 64, out, H * 64, lse, do.to(DEV).bfloat16(), H * 64, dq, dkv, dkv[:, H * 64 :],
+                 2 * H * 64, rows, S, H, 0.125, Sq=Sq, ldq=H * 64, lddq=H * 64)
+    close(dq.float().view(rows, Sq, H, 64), q.grad.transpose(1, 2), 2e-2, 2e-2 * q.grad.abs().max().item() + 1e-3, "dQ subset")
+    for i, (n, t) in enumerate((("dK", k), ("dV", v))):
+        w = t.grad.transpose(1, 2)
+        close(dkv[:, i * H * 64 : (i + 1) * H * 64].float().view(rows, S, H, 64), w, 2e-2, 2e-2 * w.abs().max().item() + 1e-3, n + " subset")
+
+
+def test_rows_add(ops):
+    R, S = 37, 11
+    dst, src = bf(rnd(R, S, 512, seed=1)), bf(rnd(R, 512, seed=2))
+    d = dst.to(DEV).bfloat16()
+    ops.rows_add(d, S * 512, src.to(DEV).bfloat16(), 512, R)
+    want = dst.clone()
+    want[:, 0] = bf(dst[:, 0] + src)
+    assert torch.equal(d.float().cpu(), want)
+
+
 def test_attn_block_causal(ops):
     for S, rows in ((128, 4), (256, 2), (32, 3)):
         g = torch.Generator().manual_seed(S)

@@ -70,11 +70,16 @@ def test_t5_encoder_vs_oracle(model):
     assert err < 0.04 * want[valid].abs().max().item(), (err, want[valid].abs().max().item())
 
 
+@pytest.mark.parametrize("prune_last", [True, False])
 @pytest.mark.parametrize("tag", ["g5_samelen", "g5_mixedlen"])
-def test_three_towers_forward_backward_vs_reference(model, tag):
+def test_three_towers_forward_backward_vs_reference(model, tag, prune_last):
+    """prune_last: the last fusion layer computed only for the consumed sequence position 0 (default) vs. in full --
+    both must reproduce the reference's outputs and gradients."""
     from oracle.detfill import grad_probe
     from safevla_amd.losses import SafePPOLogGrad, SafePPOValue
 
+    for t in model.towers:
+        t.prune_last = prune_last
     g = _load(tag + ".npz")
     obs = {k[4:]: torch.from_numpy(v).to(DEV) for k, v in g.items() if k.startswith("obs:")}
     batch = {k[6:]: torch.from_numpy(v).to(DEV) for k, v in g.items() if k.startswith("batch:")}
@@ -112,6 +117,8 @@ def test_three_towers_forward_backward_vs_reference(model, tag):
     # exactly the reference's set of parameters receives gradient
     have = {n for n, p in named.items() if p.grad is not None and float(p.grad.abs().sum()) > 0}
     assert have == {str(n) for n in g["grad_names"]}, have ^ {str(n) for n in g["grad_names"]}
+    for t in model.towers:
+        t.prune_last = True
 
 
 def test_forward_is_deterministic_and_no_grad_path(model):
