@@ -241,6 +241,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p)
 // PERSISTENT: one workgroup per CU walks a list of tiles; the K-steps of consecutive tiles form one continuous DMA stream
 // (the first three K-steps of the next tile are in flight while the current tile's epilogue stores run), so the
 // per-tile prologue latency disappears and only the register epilogue itself is un-overlapped.
+// ABL: timing-only ablations of the main loop (1: no MFMA, 2: no vmcnt wait / barrier, 3: no fragment ds_reads, 4: no DMA)
+template <int ABL>
 __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256_bf16_kernel(GemmNtArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* As = (bf16_t*)smem;                  // [NST][256][BK]
@@ -326,37 +328,55 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256_bf16_kernel(GemmN
             // younger DMA groups allowed to stay in flight behind step (tile, kt): 2 while the stream continues.
             // After an epilogue (loads/stores on the same counter) drain everything once: vmcnt(0).
             const int rem = has_next ? 2 : nk - 1 - kt;
-            if (kt == 0 && !first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (rem >= NST - 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if constexpr (ABL != 2) {
+                if (kt == 0 && !first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (rem >= NST - 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
             asm volatile("" ::: "memory");
             if (kt == nk - 2 && aux) load_aux(0, auxbuf[0], m0, n0);   // epilogue operand of the first 32-row slab, hidden under the last K-steps
             const int ka = kt + NST - 1;
-            if (ka < nk) stage((g + NST - 1) % NST, cur, ka * BK);
-            else if (has_next) stage((g + NST - 1) % NST, nxt, (ka - nk) * BK);
+            if constexpr (ABL != 4) {
+                if (ka < nk) stage((g + NST - 1) % NST, cur, ka * BK);
+                else if (has_next) stage((g + NST - 1) % NST, nxt, (ka - nk) * BK);
+            }
             const int st = g % NST;
             const bf16_t* Ab = As + st * 256 * BK;
             const bf16_t* Bb = Bs + st * 256 * BK;
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
                 bf16x8 fa[4], fb[2];
+                if constexpr (ABL == 3) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int r_ = wm * 128 + t * 32 + fr;
-                    fa[t] = *(const bf16x8*)(Ab + r_ * BK + swz_nt(r_, kk * 2 + fh) * 8);
+                    for (int t = 0; t < 4; ++t) { fa[t] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; asm volatile("" : "+v"(fa[t])); }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) { fb[t] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; asm volatile("" : "+v"(fb[t])); }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int r_ = wm * 128 + t * 32 + fr;
+                        fa[t] = *(const bf16x8*)(Ab + r_ * BK + swz_nt(r_, kk * 2 + fh) * 8);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int r_ = wn * 64 + t * 32 + fr;
+                        fb[t] = *(const bf16x8*)(Bb + r_ * BK + swz_nt(r_, kk * 2 + fh) * 8);
+                    }
                 }
+                if constexpr (ABL == 1) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int r_ = wn * 64 + t * 32 + fr;
-                    fb[t] = *(const bf16x8*)(Bb + r_ * BK + swz_nt(r_, kk * 2 + fh) * 8);
+                    for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(fa[t]));
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) asm volatile("" ::"v"(fb[t]));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = mfma32(fb[j], fa[i], acc[i][j]);
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = mfma32(fb[j], fa[i], acc[i][j]);
             }
         }
 
@@ -417,8 +437,13 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256_bf16_kernel(GemmN
     }
 }
 
-static int g_force_small_tile = 0;
-extern "C" int svla_gemm_force_small_tile(int on) { g_force_small_tile = on; return SVLA_OK; }
+static int g_force_small_tile = 0, g_ablate = 0;
+// on = 0/1: normal dispatch / force the 128x128 kernels; on = 10 + k: timing-only ablation k of the 256-tile main loop
+extern "C" int svla_gemm_force_small_tile(int on) {
+    if (on >= 10) { g_ablate = on - 10; g_force_small_tile = 0; }
+    else { g_ablate = 0; g_force_small_tile = on; }
+    return SVLA_OK;
+}
 
 extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, long ldb, const float* bias,
                                  const bf16_t* residual, long ldr, const bf16_t* relu_mask, long ldm, void* C, long ldc,
@@ -430,7 +455,11 @@ extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, lon
         const size_t lds256 = (size_t)NST * 512 * BK * sizeof(bf16_t);  // 128 KiB
         static bool attr256 = false;
         if (!attr256) {
-            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt256_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt256_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt256_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt256_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt256_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt256_bf16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
             attr256 = true;
         }
         static int n_cu = 0;
@@ -444,7 +473,13 @@ extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, lon
         const int ntiles = ((M + 255) / 256) * (N / 256);
         int grid = n_cu;                       // persistent: one 512-thread workgroup (128 KiB LDS) per CU
         while (grid > 8 && (grid / 8) * 8 > ntiles) grid -= 8;
-        hipLaunchKernelGGL(gemm_nt256_bf16_kernel, dim3(grid), dim3(NT256_THREADS), lds256, (hipStream_t)stream, p);
+        switch (g_ablate) {   // timing-only experiments (tools/ablate_gemm.py); 0 = the product kernel
+            case 1: hipLaunchKernelGGL(gemm_nt256_bf16_kernel<1>, dim3(grid), dim3(NT256_THREADS), lds256, (hipStream_t)stream, p); break;
+            case 2: hipLaunchKernelGGL(gemm_nt256_bf16_kernel<2>, dim3(grid), dim3(NT256_THREADS), lds256, (hipStream_t)stream, p); break;
+            case 3: hipLaunchKernelGGL(gemm_nt256_bf16_kernel<3>, dim3(grid), dim3(NT256_THREADS), lds256, (hipStream_t)stream, p); break;
+            case 4: hipLaunchKernelGGL(gemm_nt256_bf16_kernel<4>, dim3(grid), dim3(NT256_THREADS), lds256, (hipStream_t)stream, p); break;
+            default: hipLaunchKernelGGL(gemm_nt256_bf16_kernel<0>, dim3(grid), dim3(NT256_THREADS), lds256, (hipStream_t)stream, p);
+        }
         return svla_launch_status();
     }
     const int mt = (M + BM - 1) / BM, nt = N / BN;
