@@ -41,8 +41,8 @@ class GemmTimer:
     """HIP-event timing of every MFMA-kernel launch (on torch's current stream = the launch stream) during one update."""
 
     def __init__(self, ops):
-        self.ops, self.rec = ops, {"gemm_nt": [], "gemm_tn": [], "attn_fwd": [], "attn_bwd": []}
-        self.orig = {k: getattr(ops, k if k != "gemm_tn" else "gemm_tn_acc") for k in self.rec}
+        self.ops, self.rec = ops, {"gemm_nt256": [], "gemm_nt": [], "gemm_tn": [], "attn_fwd": [], "attn_bwd": []}
+        self.orig = {"gemm_nt": ops.gemm_nt, "gemm_tn": ops.gemm_tn_acc, "attn_fwd": ops.attn_fwd, "attn_bwd": ops.attn_bwd}
 
     def _wrap(self, key, fn, flops):
         def wrapped(*a, **kw):
@@ -50,7 +50,12 @@ class GemmTimer:
             e0.record()
             out = fn(*a, **kw)
             e1.record()
-            self.rec[key].append((e0, e1, flops(*a, **kw)))
+            k2 = key
+            if key == "gemm_nt":   # same dispatch rule as svla_gemm_nt_bf16: big row-streaming shapes run the persistent 256x256 kernel
+                M, N, K = a[2], a[3], a[4]
+                if not kw.get("out_f32") and N % 256 == 0 and ((M + 255) // 256) * (N // 256) >= 256 and K >= 96:
+                    k2 = "gemm_nt256"
+            self.rec[k2].append((e0, e1, flops(*a, **kw)))
             return out
 
         return wrapped
@@ -81,7 +86,7 @@ class GemmTimer:
         return out
 
 
-def cpu_baseline(T=8, B=4, L=12):
+def cpu_baseline(T=32, B=4, L=12):
     """fp32 CPU port (oracle) of the same update on a bounded sample: one epoch = 3-tower forward, SafePPOLogGrad +
     SafePPOValue, backward, clip 0.5, Adam; env-steps/s = T*B / (4 epochs)."""
     import numpy as np
@@ -183,14 +188,21 @@ def main():
         with GemmTimer(ops) as gt:
             step()
         allk = gt.summary()
-        g = allk["gemm_nt"]
+        g = allk["gemm_nt256"]
         executed = sum(v["flops"] for v in allk.values())
-        roof = {"bound": "mfma", "kernel": "gemm_nt256_bf16_kernel / gemm_nt_bf16_kernel (svla_gemm_nt_bf16)", "achieved": round(g["tflops"], 1),
-                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(g["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+        traffic = None   # HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/, collected offline)
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"]
+            traffic = round([v for k, v in pm.items() if "gemm_nt256" in k][0]["hbm_bytes_per_launch"])
+        except Exception:
+            pass
+        roof = {"bound": "mfma", "kernel": "gemm_nt256_bf16_kernel (svla_gemm_nt_bf16, persistent 256x256 tile)", "achieved": round(g["tflops"], 1),
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(g["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/r01_pmc_hbm_traffic.json)",
                 "launches_per_update": g["launches"], "avg_launch_ms": round(g["avg_ms"], 4), "flops_per_launch": g["flops"] / max(1, g["launches"]),
                 "share_of_update": round(g["total_s"] / (ms * 1e-3), 3),
                 "other_mfma_kernels": {k: {"achieved_tflops": round(v["tflops"], 1), "launches": v["launches"], "avg_launch_ms": round(v["avg_ms"], 4),
-                                           "share_of_update": round(v["total_s"] / (ms * 1e-3), 3)} for k, v in allk.items() if k != "gemm_nt"},
+                                           "share_of_update": round(v["total_s"] / (ms * 1e-3), 3)} for k, v in allk.items() if k != "gemm_nt256"},
                 "executed_mfma_tflop_per_update": round(executed / 1e12, 1),
                 "executed_mfma_tflops_sustained": round(executed / (ms * 1e-3) / 1e12, 1)}
     if world > 1:
