@@ -86,7 +86,7 @@ class GemmTimer:
         return out
 
 
-def cpu_baseline(T=32, B=4, L=12):
+def cpu_baseline(T=32, B=8, L=12):
     """fp32 CPU port (oracle) of the same update on a bounded sample: one epoch = 3-tower forward, SafePPOLogGrad +
     SafePPOValue, backward, clip 0.5, Adam; env-steps/s = T*B / (4 epochs)."""
     import numpy as np
