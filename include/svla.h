@@ -120,6 +120,20 @@ int svla_row_hash_u8(const unsigned char* rows, long n_rows, int row_bytes, int6
 /* T5 shared-embedding gather (HF T5EncoderModel called at allenact_dino_transformer.py:603). */
 int svla_embed_gather_f32_bf16(const float* table, const int64_t* ids, long n, int D, svla_bf16* out, void* stream);
 
+/* ---- frozen ViT preprocessor (rollout time) ------------------------------------------------------------------- */
+/* DataAugmentationPreprocessor.process without augmentation: (x/255 - mean)/std
+ * (architecture/allenact_preprocessors/dino_preprocessors.py:224-239; DINO_RGB_MEANS/STDS :42-43). */
+int svla_normalize_u8_f32(const unsigned char* x, long n, const float* mean3, const float* std3, float* y, void* stream);
+/* The same normalisation fused with the W crop [3:-3] and the 14x14/14 patch-embedding im2col of DinoViTEmbedder.forward
+ * (dino_preprocessors.py:27-35): u8 HWC frames -> bf16 rows [B, gh*gw, KP], k = c*P*P + ky*P + kx, zero padded to KP. */
+int svla_patchify_u8_bf16(const unsigned char* frames, int B, int H, int W, int crop_x, int P, int gh, int gw, int KP,
+                          const float* mean3, const float* std3, svla_bf16* out, void* stream);
+/* cls token + position embedding (DINOv2 prepare_tokens [3P torch.hub facebookresearch/dinov2], dino_preprocessors.py:106). */
+int svla_vit_tokens(const svla_bf16* patch, const float* cls, const float* pos, int B, int NP, int C, svla_bf16* y, void* stream);
+/* x_norm_patchtokens -> (B,C,16,27) -> AdaptiveAvgPool2d((7,12)) (dino_preprocessors.py:24,31-35); bf16 tokens and/or fp32 CHW. */
+int svla_adaptive_pool_tokens(const svla_bf16* x, int B, int skip, int gh, int gw, int C, int oh, int ow, int cam, int ncam,
+                              svla_bf16* tok_out, float* chw_out, void* stream);
+
 /* ---- optimiser (Adam lr 2e-5, max_grad_norm 0.5: training/online/dinov2_vits_tsfm_base.py:331-334) ------------- */
 int svla_sumsq_f32(const float* g, long n, double* out, void* stream);
 int svla_adam_step_f32(float* p, const float* g, float* m, float* v, svla_bf16* p_bf16, long n, float lr, float beta1,

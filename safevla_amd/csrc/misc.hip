@@ -366,3 +366,109 @@ extern "C" int svla_rows_add_bf16(bf16_t* dst, long dst_ld, const bf16_t* src, l
     hipLaunchKernelGGL(rows_add_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dst, dst_ld, src, src_ld, rows);
     return svla_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Frozen-ViT preprocessor input (architecture/allenact_preprocessors/dino_preprocessors.py:224-239 normalise,
+// :27-35 crop 3:-3 + 14x14/14 patch embedding): uint8 HWC frames -> normalised bf16 im2col rows [B, gh*gw, KP]
+// with k = c*P*P + ky*P + kx (the flattened conv-weight order), zero padded to KP.  One block per (frame, patch row):
+// the P image rows are staged in LDS with coalesced byte loads, outputs are written as coalesced dword pairs.
+__global__ void patchify_u8_kernel(const unsigned char* __restrict__ frames, int H, int W, int crop_x, int P, int gh, int gw,
+                                   int KP, float m0, float m1, float m2, float s0, float s1, float s2, bf16_t* __restrict__ out) {
+    extern __shared__ unsigned char rows[];   // [P][gw*P*3]
+    const int b = blockIdx.x / gh, gy = blockIdx.x % gh;
+    const int rowbytes = gw * P * 3;
+    const unsigned char* src = frames + ((size_t)b * H + gy * P) * W * 3 + crop_x * 3;
+    for (int i = threadIdx.x; i < P * rowbytes; i += blockDim.x) rows[i] = src[(size_t)(i / rowbytes) * W * 3 + (i % rowbytes)];
+    __syncthreads();
+    const float mean[3] = {m0, m1, m2}, inv[3] = {1.f / s0, 1.f / s1, 1.f / s2};
+    const int K = 3 * P * P;
+    bf16_t* dst = out + ((size_t)b * gh * gw + (size_t)gy * gw) * KP;
+    for (int i = threadIdx.x; i < gw * (KP / 2); i += blockDim.x) {
+        const int gx = i / (KP / 2), k0 = (i % (KP / 2)) * 2;
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = k0 + e;
+            if (k < K) {
+                const int c = k / (P * P), ky = (k % (P * P)) / P, kx = k % P;
+                const float px = (float)rows[ky * rowbytes + (gx * P + kx) * 3 + c];
+                v[e] = (px / 255.0f - mean[c]) * inv[c];
+            } else v[e] = 0.f;
+        }
+        *(uint32_t*)(dst + (size_t)gx * KP + k0) = pack_bf2(v[0], v[1]);
+    }
+}
+extern "C" int svla_patchify_u8_bf16(const unsigned char* frames, int B, int H, int W, int crop_x, int P, int gh, int gw, int KP,
+                                     const float* mean3, const float* std3, bf16_t* out, void* stream) {
+    if (B <= 0 || gh * P > H || crop_x + gw * P > W || KP < 3 * P * P || (KP % 2) || !mean3 || !std3) return SVLA_EINVAL;
+    const size_t lds = (size_t)P * gw * P * 3;
+    hipLaunchKernelGGL(patchify_u8_kernel, dim3(B * gh), dim3(256), lds, (hipStream_t)stream, frames, H, W, crop_x, P, gh, gw, KP,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], out);
+    return svla_launch_status();
+}
+
+// DataAugmentationPreprocessor.process without augmentation (dino_preprocessors.py:224-239): u8 HWC -> (x/255 - mean)/std fp32 HWC
+__global__ void normalize_u8_kernel(const unsigned char* __restrict__ x, long n, float m0, float m1, float m2, float s0, float s1,
+                                    float s2, float* __restrict__ y) {
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % 3);
+        y[i] = ((float)x[i] / 255.0f - mean[c]) / sd[c];
+    }
+}
+extern "C" int svla_normalize_u8_f32(const unsigned char* x, long n, const float* mean3, const float* std3, float* y, void* stream) {
+    if (n <= 0 || (n % 3)) return SVLA_EINVAL;
+    long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(normalize_u8_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, n, mean3[0], mean3[1], mean3[2],
+                       std3[0], std3[1], std3[2], y);
+    return svla_launch_status();
+}
+
+// x_norm_patchtokens [B, skip + gh*gw, C] (bf16) -> AdaptiveAvgPool2d((oh, ow)) over the gh x gw patch grid
+// (dino_preprocessors.py:31-35): writes bf16 tokens [B, ncam, oh*ow, C] slot ``cam`` and/or fp32 channels-first (B, C, oh, ow).
+__global__ void adaptive_pool_kernel(const bf16_t* __restrict__ x, int skip, int gh, int gw, int C, int oh, int ow, int cam, int ncam,
+                                     bf16_t* __restrict__ tok_out, float* __restrict__ chw_out) {
+    const int b = blockIdx.x / (oh * ow), o = blockIdx.x % (oh * ow);
+    const int oy = o / ow, ox = o % ow;
+    const int y0 = (oy * gh) / oh, y1 = ((oy + 1) * gh + oh - 1) / oh;
+    const int x0 = (ox * gw) / ow, x1 = ((ox + 1) * gw + ow - 1) / ow;
+    const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+    const bf16_t* src = x + (size_t)b * (skip + gh * gw) * C + (size_t)skip * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int yy = y0; yy < y1; ++yy)
+            for (int xx = x0; xx < x1; ++xx) s += bf2f(src[(size_t)(yy * gw + xx) * C + c]);
+        s *= inv;
+        if (tok_out) tok_out[(((size_t)b * ncam + cam) * oh * ow + o) * C + c] = f2bf(s);
+        if (chw_out) chw_out[(((size_t)b * C + c) * oh + oy) * ow + ox] = s;
+    }
+}
+extern "C" int svla_adaptive_pool_tokens(const bf16_t* x, int B, int skip, int gh, int gw, int C, int oh, int ow, int cam, int ncam,
+                                         bf16_t* tok_out, float* chw_out, void* stream) {
+    if (B <= 0 || cam >= ncam || (!tok_out && !chw_out)) return SVLA_EINVAL;
+    hipLaunchKernelGGL(adaptive_pool_kernel, dim3(B * oh * ow), dim3(128), 0, (hipStream_t)stream, x, skip, gh, gw, C, oh, ow, cam, ncam,
+                       tok_out, chw_out);
+    return svla_launch_status();
+}
+
+// y[b, 0, :] = cls + pos[0]; y[b, 1 + p, :] = patch[b, p, :] + pos[1 + p]   (DINOv2 prepare_tokens: cls token + position embedding)
+__global__ void vit_tokens_kernel(const bf16_t* __restrict__ patch, const float* __restrict__ cls, const float* __restrict__ pos,
+                                  int B, int NP, int C, bf16_t* __restrict__ y) {
+    const long n = (long)B * (NP + 1) * (C / 2);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (C / 2)) * 2;
+        const long t = i / (C / 2);
+        const int tok = (int)(t % (NP + 1));
+        const long b = t / (NP + 1);
+        float a0, a1;
+        if (tok == 0) { a0 = cls[c]; a1 = cls[c + 1]; }
+        else { const uint32_t w = *(const uint32_t*)(patch + ((size_t)b * NP + tok - 1) * C + c); a0 = bf_lo(w); a1 = bf_hi(w); }
+        *(uint32_t*)(y + (size_t)t * C + c) = pack_bf2(a0 + pos[(size_t)tok * C + c], a1 + pos[(size_t)tok * C + c + 1]);
+    }
+}
+extern "C" int svla_vit_tokens(const bf16_t* patch, const float* cls, const float* pos, int B, int NP, int C, bf16_t* y, void* stream) {
+    if (B <= 0 || (C % 2)) return SVLA_EINVAL;
+    long blocks = ((long)B * (NP + 1) * (C / 2) + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(vit_tokens_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, patch, cls, pos, B, NP, C, y);
+    return svla_launch_status();
+}

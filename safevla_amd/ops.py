@@ -241,3 +241,29 @@ def cast_bf16(src, dst):
 def transpose_cast_bf16(src, dst):
     rows, cols = src.shape
     lib().call("svla_transpose_cast_f32_bf16", _p(src), rows, cols, _p(dst), _stream())
+
+
+# ------------------------------------------------------------------------------------------------ frozen ViT preprocessor
+def normalize_u8(x_u8, mean3, std3):
+    y = torch.empty(x_u8.shape, device=x_u8.device, dtype=F32)
+    m, s_ = [float(v) for v in mean3], [float(v) for v in std3]
+    import ctypes
+    lib().call("svla_normalize_u8_f32", _p(x_u8), x_u8.numel(), (ctypes.c_float * 3)(*m), (ctypes.c_float * 3)(*s_), _p(y), _stream())
+    return y
+
+
+def patchify_u8(frames_u8, mean3, std3, out, crop_x=3, P=14, gh=16, gw=27):
+    """frames_u8 [B,H,W,3] -> out bf16 [B, gh*gw, KP] normalised im2col rows."""
+    import ctypes
+    B, H, W, _ = frames_u8.shape
+    KP = out.shape[-1]
+    lib().call("svla_patchify_u8_bf16", _p(frames_u8), B, H, W, crop_x, P, gh, gw, KP, (ctypes.c_float * 3)(*[float(v) for v in mean3]),
+               (ctypes.c_float * 3)(*[float(v) for v in std3]), _p(out), _stream())
+
+
+def vit_tokens(patch, cls, pos, B, NP, C, out):
+    lib().call("svla_vit_tokens", _p(patch), _p(cls), _p(pos), B, NP, C, _p(out), _stream())
+
+
+def adaptive_pool_tokens(x, B, skip, gh, gw, C, oh, ow, cam=0, ncam=1, tok_out=None, chw_out=None):
+    lib().call("svla_adaptive_pool_tokens", _p(x), B, skip, gh, gw, C, oh, ow, cam, ncam, _p(tok_out), _p(chw_out), _stream())

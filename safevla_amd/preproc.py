@@ -1,0 +1,162 @@
+"""Frozen-ViT sensor preprocessors (rollout time), mirroring the reference's preprocessor contract
+``process(obs: Dict[str, Tensor]) -> Tensor`` with attributes ``input_uuids`` / ``uuid``:
+
+  * ``DataAugmentationPreprocessor``  /root/reference/architecture/allenact_preprocessors/dino_preprocessors.py:166-239
+    (u8 HWC -> /255, -mean, /std; augmentation is a host-configured torchvision op list and is off for synthetic runs)
+  * ``DinoViTPreprocessor`` / ``DinoViTEmbedder``  dino_preprocessors.py:20-125: crop W 384 -> 378, DINOv2 ViT-S/14
+    ``forward_features(...)["x_norm_patchtokens"]`` -> (B,384,16,27) -> AdaptiveAvgPool2d((7,12)).
+
+The DINOv2 network itself is third-party (``torch.hub facebookresearch/dinov2``, not in the reference tree, no network
+here): its published ViT-S/14 forward is restated (pre-LN blocks with qkv/proj biases, LayerScale, GELU MLP, final LayerNorm,
+bicubic position-embedding interpolation) with the hub model's ``state_dict`` names, random-init geometry. PARITY UNPINNED
+against DINOv2 proper; pinned against the fp32 oracle restatement (oracle/ref_vit.py).
+
+MI355X path: normalise + crop + im2col fused in one kernel, patch embedding and all block linears on the bf16 MFMA GEMM
+(LayerScale folded into the frozen weights at sync time), fused attention at S = 433, output written directly in the rollout
+storage's bf16 token layout [B, ncam, 84, 384] (and/or the reference's fp32 (B,384,7,12)).
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .model import _NS
+
+DINO_RGB_MEANS = (0.48145466, 0.4578275, 0.40821073)
+DINO_RGB_STDS = (0.26862954, 0.26130258, 0.27577711)
+BF16 = torch.bfloat16
+
+
+class DataAugmentationPreprocessor:
+    def __init__(self, rgb_input_uuid: str, output_uuid: str, device="cuda", normalize=True, mean=DINO_RGB_MEANS, stdev=DINO_RGB_STDS,
+                 height=224, width=384, use_augmentation=False, **kw):
+        if use_augmentation:
+            raise NotImplementedError("torchvision augmentation lists are simulator-side configuration (off for synthetic runs)")
+        self.input_uuids, self.uuid, self.device = [rgb_input_uuid], output_uuid, torch.device(device)
+        self.mean, self.stdev, self.normalize = mean, stdev, normalize
+
+    def to(self, device):
+        self.device = torch.device(device)
+        return self
+
+    def process(self, obs: Dict[str, torch.Tensor], *a, **k) -> torch.Tensor:
+        x = obs[self.input_uuids[0]].to(self.device)
+        assert x.dtype == torch.uint8 and x.shape[-1] == 3
+        return ops.normalize_u8(x.contiguous(), self.mean if self.normalize else (0, 0, 0), self.stdev if self.normalize else (1, 1, 1))
+
+
+class DinoViT(nn.Module):
+    """DINOv2 ViT-S/14 geometry with the hub model's parameter names."""
+
+    def __init__(self, device, dim=384, depth=12, heads=6, patch=14, native_grid=37):
+        super().__init__()
+        self.dim, self.depth, self.heads, self.patch, self.native_grid = dim, depth, heads, patch, native_grid
+        d = torch.device(device)
+        P = lambda *s, sc=0.02: nn.Parameter((torch.randn(*s) * sc).to(d), requires_grad=False)
+        self.cls_token = P(1, 1, dim)
+        self.pos_embed = P(1, 1 + native_grid * native_grid, dim)
+        self.mask_token = P(1, dim)
+        self.patch_embed = _NS(); self.patch_embed.proj = _NS()
+        self.patch_embed.proj.weight = P(dim, 3, patch, patch, sc=1.0 / math.sqrt(3 * patch * patch))
+        self.patch_embed.proj.bias = P(dim)
+        self.blocks = nn.ModuleList()
+        for _ in range(depth):
+            b = _NS()
+            b.norm1 = _NS(); b.norm1.weight = nn.Parameter(torch.ones(dim, device=d), requires_grad=False); b.norm1.bias = P(dim)
+            b.attn = _NS(); b.attn.qkv = _NS(); b.attn.proj = _NS()
+            b.attn.qkv.weight = P(3 * dim, dim, sc=1.0 / math.sqrt(dim)); b.attn.qkv.bias = P(3 * dim)
+            b.attn.proj.weight = P(dim, dim, sc=1.0 / math.sqrt(dim)); b.attn.proj.bias = P(dim)
+            b.ls1 = _NS(); b.ls1.gamma = nn.Parameter(torch.full((dim,), 1.0, device=d), requires_grad=False)
+            b.norm2 = _NS(); b.norm2.weight = nn.Parameter(torch.ones(dim, device=d), requires_grad=False); b.norm2.bias = P(dim)
+            b.mlp = _NS(); b.mlp.fc1 = _NS(); b.mlp.fc2 = _NS()
+            b.mlp.fc1.weight = P(4 * dim, dim, sc=1.0 / math.sqrt(dim)); b.mlp.fc1.bias = P(4 * dim)
+            b.mlp.fc2.weight = P(dim, 4 * dim, sc=1.0 / math.sqrt(4 * dim)); b.mlp.fc2.bias = P(dim)
+            b.ls2 = _NS(); b.ls2.gamma = nn.Parameter(torch.full((dim,), 1.0, device=d), requires_grad=False)
+            self.blocks.append(b)
+        self.norm = _NS(); self.norm.weight = nn.Parameter(torch.ones(dim, device=d), requires_grad=False); self.norm.bias = P(dim)
+        self._rt = None
+
+    def interpolated_pos(self, gh: int, gw: int) -> torch.Tensor:
+        """[1 + gh*gw, dim] fp32: class position + bicubic resize of the native_grid^2 patch positions (DINOv2 interpolate_pos_encoding)."""
+        pe = self.pos_embed[0].float()
+        g = self.native_grid
+        patch = pe[1:].reshape(1, g, g, self.dim).permute(0, 3, 1, 2)
+        patch = F.interpolate(patch, size=(gh, gw), mode="bicubic", align_corners=False)
+        return torch.cat([pe[:1], patch.permute(0, 2, 3, 1).reshape(gh * gw, self.dim)], 0).contiguous()
+
+    def sync(self, gh=16, gw=27, KP=608):
+        rt = dict(gh=gh, gw=gw, KP=KP)
+        w = self.patch_embed.proj.weight.reshape(self.dim, -1).float()
+        wp = torch.zeros(self.dim, KP, device=w.device)
+        wp[:, : w.shape[1]] = w
+        rt["pe_w"] = wp.to(BF16).contiguous()
+        rt["pe_b"] = self.patch_embed.proj.bias.float().contiguous()
+        rt["pos"] = self.interpolated_pos(gh, gw)
+        rt["cls"] = self.cls_token.reshape(-1).float().contiguous()
+        blocks = []
+        for b in self.blocks:   # LayerScale folded into the frozen projections: gamma * (W x + b)
+            g1, g2 = b.ls1.gamma.float(), b.ls2.gamma.float()
+            blocks.append(dict(qkv=b.attn.qkv.weight.to(BF16).contiguous(), qkv_b=b.attn.qkv.bias.float().contiguous(),
+                               proj=(g1[:, None] * b.attn.proj.weight.float()).to(BF16).contiguous(), proj_b=(g1 * b.attn.proj.bias.float()).contiguous(),
+                               fc1=b.mlp.fc1.weight.to(BF16).contiguous(), fc1_b=b.mlp.fc1.bias.float().contiguous(),
+                               fc2=(g2[:, None] * b.mlp.fc2.weight.float()).to(BF16).contiguous(), fc2_b=(g2 * b.mlp.fc2.bias.float()).contiguous()))
+        rt["blocks"] = blocks
+        self._rt = rt
+
+    @torch.no_grad()
+    def patch_tokens(self, frames_u8: torch.Tensor, mean=DINO_RGB_MEANS, std=DINO_RGB_STDS) -> torch.Tensor:
+        """frames_u8 [B,224,384,3] uint8 -> x_norm tokens [B, 1+432, 384] bf16 (class token first)."""
+        if self._rt is None:
+            self.sync()
+        rt = self._rt
+        B, H, W, _ = frames_u8.shape
+        assert (H, W) == (224, 384), f"Expected shape is 224x384; got {(H, W)}"
+        gh, gw, KP, C = rt["gh"], rt["gw"], rt["KP"], self.dim
+        NP, S = gh * gw, gh * gw + 1
+        dev = frames_u8.device
+        cols = torch.empty(B * NP, KP, device=dev, dtype=BF16)
+        ops.patchify_u8(frames_u8.contiguous(), mean, std, cols, crop_x=3, P=self.patch, gh=gh, gw=gw)
+        pt = ops.gemm_nt(cols, rt["pe_w"], B * NP, C, KP, bias=rt["pe_b"])
+        x = torch.empty(B * S, C, device=dev, dtype=BF16)
+        ops.vit_tokens(pt, rt["cls"], rt["pos"], B, NP, C, x)
+        n = B * S
+        for b, w in zip(self.blocks, rt["blocks"]):
+            h, _, _ = ops.norm_fwd(x, b.norm1.weight, b.norm1.bias, 1e-6, n, D=C, save_stats=False)
+            qkv = ops.gemm_nt(h, w["qkv"], n, 3 * C, C, bias=w["qkv_b"])
+            ao, _ = ops.attn_fwd(qkv, qkv[:, C:], qkv[:, 2 * C:], 3 * C, B, S, self.heads, 0.125, save_lse=False)
+            x = ops.gemm_nt(ao, w["proj"], n, C, C, bias=w["proj_b"], residual=x)
+            h, _, _ = ops.norm_fwd(x, b.norm2.weight, b.norm2.bias, 1e-6, n, D=C, save_stats=False)
+            f = ops.gemm_nt(h, w["fc1"], n, 4 * C, C, bias=w["fc1_b"], act=ops.ACT_GELU)
+            x = ops.gemm_nt(f, w["fc2"], n, C, 4 * C, bias=w["fc2_b"], residual=x)
+        out, _, _ = ops.norm_fwd(x, self.norm.weight, self.norm.bias, 1e-6, n, D=C, save_stats=False)
+        return out.view(B, S, C)
+
+
+class DinoViTPreprocessor:
+    """Raw uint8 frames -> pooled DINOv2 features.  ``process`` returns the reference's fp32 (B,384,7,12); ``process_tokens``
+    writes the storage-native bf16 tokens [B, ncam, 84, 384]."""
+
+    def __init__(self, rgb_input_uuid: str, output_uuid: str, dino_model_type: str = "dinov2_vits14", device="cuda", **kw):
+        assert dino_model_type == "dinov2_vits14", "only the shipped ViT-S/14 geometry is built"
+        self.input_uuids, self.uuid, self.device = [rgb_input_uuid], output_uuid, torch.device(device)
+        self.vit = DinoViT(self.device)
+
+    def to(self, device):
+        return self
+
+    @torch.no_grad()
+    def process(self, obs: Dict[str, torch.Tensor], *a, **k) -> torch.Tensor:
+        fr = obs[self.input_uuids[0]].to(self.device)
+        x = self.vit.patch_tokens(fr)
+        B = fr.shape[0]
+        out = torch.empty(B, self.vit.dim, 7, 12, device=self.device, dtype=torch.float32)
+        ops.adaptive_pool_tokens(x, B, 1, 16, 27, self.vit.dim, 7, 12, chw_out=out)
+        return out
+
+    @torch.no_grad()
+    def process_tokens(self, frames_u8: torch.Tensor, out_tokens: torch.Tensor, cam: int, ncam: int = 2):
+        x = self.vit.patch_tokens(frames_u8.to(self.device))
+        ops.adaptive_pool_tokens(x, frames_u8.shape[0], 1, 16, 27, self.vit.dim, 7, 12, cam=cam, ncam=ncam, tok_out=out_tokens)

@@ -1,0 +1,60 @@
+"""Frozen-ViT preprocessor (rollout-time part of the policy forward): HIP path vs the fp32 oracle restatement."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def pre():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from safevla_amd.preproc import DinoViTPreprocessor
+
+    torch.manual_seed(0)
+    p = DinoViTPreprocessor("rgb_raw", "rgb_dinov2", device=DEV)
+    with torch.no_grad():   # non-trivial LayerScale / norm weights so that every parameter matters
+        for b in p.vit.blocks:
+            b.ls1.gamma.copy_(0.5 + 0.5 * torch.rand(384, device=DEV))
+            b.ls2.gamma.copy_(0.5 + 0.5 * torch.rand(384, device=DEV))
+            b.norm1.weight.copy_(1 + 0.1 * torch.randn(384, device=DEV))
+        p.vit.pos_embed.mul_(10.0)
+    p.vit.sync()
+    return p
+
+
+def test_normalize_matches_reference_formula(pre):
+    from oracle import ref_vit
+    from safevla_amd.preproc import DataAugmentationPreprocessor
+
+    fr = torch.from_numpy(np.random.RandomState(0).randint(0, 256, (3, 224, 384, 3), dtype=np.uint8))
+    got = DataAugmentationPreprocessor("rgb_raw", "rgb", device=DEV).process({"rgb_raw": fr})
+    assert torch.allclose(got.cpu(), ref_vit.normalize(fr), rtol=1e-6, atol=1e-6)
+
+
+def test_vit_features_vs_oracle(pre):
+    from oracle import ref_vit
+
+    fr = torch.from_numpy(np.random.RandomState(1).randint(0, 256, (2, 224, 384, 3), dtype=np.uint8))
+    sd = {k: v.detach().float().cpu() for k, v in pre.vit.state_dict().items()}
+    want_tok, want_pool = ref_vit.vit_features(sd, fr)
+    got_tok = pre.vit.patch_tokens(fr.to(DEV)).float().cpu()
+    e = (got_tok - want_tok).abs().max().item() / want_tok.abs().max().item()
+    assert e < 4e-2, e
+    got = pre.process({"rgb_raw": fr}).cpu()
+    assert got.shape == (2, 384, 7, 12) and got.dtype == torch.float32
+    e2 = (got - want_pool).abs().max().item() / want_pool.abs().max().item()
+    assert e2 < 4e-2, e2
+    tok = torch.zeros(2, 2, 84, 384, device=DEV, dtype=torch.bfloat16)
+    pre.process_tokens(fr, tok, cam=1)
+    assert (tok[:, 0] == 0).all()
+    assert torch.allclose(tok[:, 1].float().cpu(), got.flatten(2).permute(0, 2, 1), atol=2e-2, rtol=2e-2)
+
+
+def test_state_dict_has_dinov2_names(pre):
+    names = set(pre.vit.state_dict())
+    for k in ("cls_token", "pos_embed", "patch_embed.proj.weight", "blocks.0.attn.qkv.weight", "blocks.11.ls2.gamma", "blocks.5.mlp.fc1.bias", "norm.weight"):
+        assert k in names, k
+    assert pre.vit.state_dict()["pos_embed"].shape == (1, 1370, 384)
