@@ -82,10 +82,11 @@ int svla_colsum_bf16(const svla_bf16* dY, long ldy, int M, int N, int row_stride
  * bias [H,S,S] + kvalid [rows,S]: T5 self-attention.  LSE [rows,H,Sq] is saved for the backward.
  * Sq > 0: only the first Sq query tokens of every row are computed (Q/O/dO/dQ hold Sq rows per batch row, Q/dQ row
  * strides ldq/lddq) -- the last fusion layer only feeds sequence position 0 onwards (allenact_dino_transformer.py:708).
- * Sq = 0: all S queries, Q laid out like K/V. */
+ * Sq = 0: all S queries, Q laid out like K/V.  kv_rows > 0 (forward only): K/V hold kv_rows token rows per batch row of
+ * which the first S are used -- the llama KV cache of the acting path (llama/model.py:224-239,279-293). */
 int svla_attn_fwd_bf16(const svla_bf16* Q, const svla_bf16* K, const svla_bf16* V, long ld, svla_bf16* O, long ldo, float* LSE,
                        int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj, const float* bias,
-                       const unsigned char* kvalid, int Sq, long ldq, void* stream);
+                       const unsigned char* kvalid, int Sq, long ldq, int kv_rows, void* stream);
 int svla_attn_bwd_bf16(const svla_bf16* Q, const svla_bf16* K, const svla_bf16* V, long ld, const svla_bf16* O, long ldo,
                        const float* LSE, const svla_bf16* dO, long lddo, svla_bf16* dQ, svla_bf16* dK, svla_bf16* dV, long ldd,
                        int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj, const float* bias,

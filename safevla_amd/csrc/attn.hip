@@ -29,6 +29,7 @@ struct AttnArgs {
     const unsigned char* kvalid;          // [rows, S] key padding mask or null
     int S, H, mask_mode;
     float scale;
+    int kv_rows;                          // K/V (dK/dV) token rows allocated per batch row (>= S; KV caches), default S
     int Sq;                               // query rows per batch row present in Q / O / dO / dQ / LSE (<= S; S = all)
     long ldq, lddq;                       // token row strides of Q and dQ (the K/V tensors use ld / ldd)
 };
@@ -102,13 +103,13 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
     unsigned char* kv_s = (unsigned char*)(traj_s + SP);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = blockIdx.x / p.H, h = blockIdx.x % p.H;
-    const size_t tok0 = (size_t)r * p.S;
+    const size_t tok0 = (size_t)r * p.kv_rows, mtok0 = (size_t)r * p.S;
     const int S = p.S;
     stage_head<SP>(Ks, p.K + tok0 * p.ld + h * HD, p.ld, S, tid);
     stage_head<SP>(Vs, p.V + tok0 * p.ld + h * HD, p.ld, S, tid);
     for (int i = tid; i < SP; i += ATT_THREADS) {
-        traj_s[i] = (p.traj && i < S) ? p.traj[tok0 + i] : -1;
-        kv_s[i] = (p.kvalid && i < S) ? p.kvalid[tok0 + i] : 1;
+        traj_s[i] = (p.traj && i < S) ? p.traj[mtok0 + i] : -1;
+        kv_s[i] = (p.kvalid && i < S) ? p.kvalid[mtok0 + i] : 1;
     }
     const int ql = lane & 15, g = lane >> 4;
     const int Sq = p.Sq;
@@ -502,20 +503,22 @@ static int launch_bwd(const AttnArgs& p, int rows, hipStream_t st) {
 
 extern "C" int svla_attn_fwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t* V, long ld, bf16_t* O, long ldo, float* LSE,
                                   int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj,
-                                  const float* bias, const unsigned char* kvalid, int Sq, long ldq, void* stream) {
-    if (head_dim != HD || rows <= 0 || S <= 0 || S > 448 || (ld % 8) || H <= 0) return SVLA_EINVAL;
+                                  const float* bias, const unsigned char* kvalid, int Sq, long ldq, int kv_rows, void* stream) {
+    if (head_dim != HD || rows <= 0 || S <= 0 || S > 512 || (ld % 8) || H <= 0 || (kv_rows > 0 && kv_rows < S)) return SVLA_EINVAL;
     if (mask_mode == MASK_BLOCK_CAUSAL && !traj) return SVLA_EINVAL;
     if (Sq < 0 || Sq > S || (Sq > 0 && (ldq % 8))) return SVLA_EINVAL;
     AttnArgs p{};
     p.Q = Q; p.K = K; p.V = V; p.ld = ld; p.O = O; p.ldo = ldo; p.LSE = LSE; p.traj = traj; p.bias = bias; p.kvalid = kvalid;
     p.S = S; p.H = H; p.mask_mode = mask_mode; p.scale = scale;
     p.Sq = Sq > 0 ? Sq : S; p.ldq = Sq > 0 ? ldq : ld;
+    p.kv_rows = kv_rows > 0 ? kv_rows : S;
     hipStream_t st = (hipStream_t)stream;
     if (S <= 64) return launch_fwd<4>(p, rows, st);
     if (S <= 128) return launch_fwd<8>(p, rows, st);
     if (S <= 192) return launch_fwd<12>(p, rows, st);
     if (S <= 256) return launch_fwd<16>(p, rows, st);
-    return launch_fwd<28>(p, rows, st);
+    if (S <= 448) return launch_fwd<28>(p, rows, st);
+    return launch_fwd<32>(p, rows, st);
 }
 
 extern "C" int svla_attn_bwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t* V, long ld, const bf16_t* O, long ldo,
@@ -526,7 +529,7 @@ extern "C" int svla_attn_bwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t
     if (mask_mode == MASK_BLOCK_CAUSAL && !traj) return SVLA_EINVAL;
     if (Sq < 0 || Sq > S || (Sq > 0 && ((ldq % 8) || (lddq % 8)))) return SVLA_EINVAL;
     AttnArgs p{};
-    p.Sq = Sq > 0 ? Sq : S; p.ldq = Sq > 0 ? ldq : ld; p.lddq = Sq > 0 ? lddq : ldd;
+    p.Sq = Sq > 0 ? Sq : S; p.ldq = Sq > 0 ? ldq : ld; p.lddq = Sq > 0 ? lddq : ldd; p.kv_rows = S;
     p.Q = Q; p.K = K; p.V = V; p.ld = ld; p.O = (bf16_t*)O; p.ldo = ldo; p.LSE = (float*)LSE; p.dO = dO; p.lddo = lddo;
     p.dQ = dQ; p.dK = dK; p.dV = dV; p.ldd = ldd; p.traj = traj; p.bias = bias; p.kvalid = kvalid;
     p.S = S; p.H = H; p.mask_mode = mask_mode; p.scale = scale;

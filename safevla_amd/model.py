@@ -211,8 +211,20 @@ class Tower(nn.Module):
         return self.arena.slab(p, self.arena.flat_g)
 
     # ---- forward ----------------------------------------------------------------------------------------------
+    # ---- acting path state (llama KV caches, llama/model.py:224-247; counter semantics allenact_dino_transformer.py:376-406)
+    def _ensure_caches(self, B: int):
+        if getattr(self, "_kv", None) is None or self._kv[0].shape[0] < B:
+            self._kv = [torch.zeros(B, self.max_steps, 2 * D, device=self.device_, dtype=BF16) for _ in self.decoder.layers]
+
+    def cache_select(self, keep: list):
+        if getattr(self, "_kv", None) is not None:
+            idx = torch.as_tensor(keep, device=self.device_, dtype=torch.long)
+            self._kv = [c[idx].contiguous() for c in self._kv]
+
     def run_forward(self, prep: "Prep", need_grad: bool):
         T, B, R, S, L, U = prep.T, prep.B, prep.R, prep.S, prep.L, prep.U
+        if T > 1 or self.time_step_counter >= self.max_steps:
+            self.time_step_counter = 0
         ve, w = self.visual_encoder, self._w
         M2, M = R * 2 * NPATCH, R * S
         c = {}  # saved activations
@@ -267,7 +279,29 @@ class Tower(nn.Module):
                               self.time_encoder.div_term, prep.prev_actions, prep.masks, prep.hand, prep.time_step, T, B, j)
         xd = j
         dl = []
-        for i, l in enumerate(self.decoder.layers):
+        if T == 1:
+            # acting: one new token per env against the KV cache; env b attends to cache slots >= max(counter - time_step_b, 0)
+            # (its current episode), allenact_dino_transformer.py:388-397
+            t = self.time_step_counter
+            self._ensure_caches(B)
+            start = torch.clamp(t - prep.time_step, min=0)
+            kvalid = (torch.arange(t + 1, device=self.device_)[None, :] >= start[:, None]).to(torch.uint8).contiguous()
+            for i, l in enumerate(self.decoder.layers):
+                n1, _, _ = ops.norm_fwd(xd, l.attention_norm.weight, None, 1e-5, B, rms=True, save_stats=False)
+                qkv = ops.gemm_nt(n1, w[f"d{i}.qkv"], B, 3 * D, D)
+                cache = self._kv[i]
+                cache[:B, t].copy_(qkv[:, D:])
+                cv = cache.view(-1, 2 * D)
+                ao, _ = ops.attn_fwd(qkv, cv, cv[:, D:], 2 * D, B, t + 1, 8, 0.125, kvalid=kvalid, save_lse=False, Sq=1, ldq=3 * D,
+                                     kv_rows=self.max_steps)
+                h = ops.gemm_nt(ao, w[f"d{i}.wo"], B, D, D, residual=xd)
+                n2, _, _ = ops.norm_fwd(h, l.ffn_norm.weight, None, 1e-5, B, rms=True, save_stats=False)
+                ab = ops.gemm_nt(n2, w[f"d{i}.w13"], B, 3072, D)
+                gg = ops.swiglu_fwd(ab, B, 1536)
+                xd = ops.gemm_nt(gg, w[f"d{i}.w2"], B, D, 1536, residual=h)
+            self.time_step_counter += 1
+        else:
+          for i, l in enumerate(self.decoder.layers):
             n1, _, r1 = ops.norm_fwd(xd, l.attention_norm.weight, None, 1e-5, R, rms=True, save_stats=need_grad)
             qkv = ops.gemm_nt(n1, w[f"d{i}.qkv"], R, 3 * D, D)
             ao, lse = ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B, T, 8, 0.125, mask_mode=ops.MASK_BLOCK_CAUSAL,
@@ -540,8 +574,10 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
     def recurrent_memory_specification(self):
         return None
 
-    def sampler_select(self, keep: list):  # KV caches live in the acting engine (safevla_amd/acting.py)
-        pass
+    def sampler_select(self, keep: list):
+        """AllenAct hook: keep only the listed samplers' KV-cache rows (allenact_dino_transformer.py:197-199)."""
+        for t in self.towers:
+            t.cache_select(keep)
 
     def trainable_parameters(self):
         return [p for p in self.parameters() if p.requires_grad]
@@ -622,6 +658,8 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
     # ---- reference forward API -------------------------------------------------------------------------------------
     def forward(self, observations, memory, prev_actions, masks):
         prep = self.prepare(observations, prev_actions, masks)
+        if prep.T == 1 and torch.is_grad_enabled():
+            raise RuntimeError("single-step (acting) forwards run under torch.no_grad(), as in the reference's rollout collection")
         logits, _ = _TowerFn.apply(self._anchor, self, prep, True, False)
         _, values = _TowerFn.apply(self._anchor, self.critic_tsfm, prep, False, True)
         _, c_values = _TowerFn.apply(self._anchor, self.c_critic_tsfm, prep, False, True)

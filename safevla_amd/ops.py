@@ -142,7 +142,7 @@ def colsum_acc(dY, db, M, N, ldy=None, row_stride=1):
 
 # ------------------------------------------------------------------------------------------------ attention
 def attn_fwd(q, k, v, ld, rows, S, H, scale, out=None, ldo=None, mask_mode=MASK_NONE, traj=None, bias=None, kvalid=None,
-             save_lse=True, Sq=0, ldq=0):
+             save_lse=True, Sq=0, ldq=0, kv_rows=0):
     """q/k/v: bf16 views whose element (token, h*64+d) sits at token*ld + h*64 + d.  Sq > 0: only the first Sq queries of
     every row (q then holds Sq rows per batch row with row stride ldq)."""
     nq = Sq if Sq > 0 else S
@@ -151,7 +151,7 @@ def attn_fwd(q, k, v, ld, rows, S, H, scale, out=None, ldo=None, mask_mode=MASK_
     ldo = ldo if ldo is not None else out.stride(-2)
     lse = torch.empty(rows, H, nq, device=q.device, dtype=F32) if save_lse else None
     lib().call("svla_attn_fwd_bf16", _p(q), _p(k), _p(v), ld, _p(out), ldo, _p(lse), rows, S, H, 64, float(scale), mask_mode,
-               _p(traj), _p(bias), _p(kvalid), int(Sq), int(ldq), _stream())
+               _p(traj), _p(bias), _p(kvalid), int(Sq), int(ldq), int(kv_rows), _stream())
     return out, lse
 
 

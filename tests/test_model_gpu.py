@@ -130,3 +130,32 @@ def test_forward_is_deterministic_and_no_grad_path(model):
         b, _ = model(obs, None, pa, mk)
     assert torch.equal(a.distributions.raw_logits, b.distributions.raw_logits)
     assert torch.equal(a.values, b.values) and torch.equal(a.c_values, b.c_values)
+
+
+def test_acting_path_kv_cache_vs_reference(model):
+    """nsteps == 1 with the llama KV cache and the episode-window mask (reference acting path) vs the reference's own
+    step-by-step outputs, and vs this model's full-sequence update path (equal for equal token lengths)."""
+    g, gu = _load("g5_acting.npz"), _load("g5_samelen.npz")
+    obs = {k[4:]: torch.from_numpy(v).to(DEV) for k, v in gu.items() if k.startswith("obs:")}
+    pa, mk = torch.from_numpy(gu["prev_actions"]).to(DEV), torch.from_numpy(gu["masks"]).to(DEV)
+    T = pa.shape[0]
+    for t in model.towers:
+        t.time_step_counter = 0
+        t._kv = None
+    lg, vs, cs = [], [], []
+    with torch.no_grad():
+        for t in range(T):
+            o, _ = model({k: v[t:t + 1] for k, v in obs.items()}, None, pa[t:t + 1], mk[t:t + 1])
+            lg.append(o.distributions.logits); vs.append(o.values); cs.append(o.c_values)
+    lg, vs, cs = torch.cat(lg).cpu().numpy(), torch.cat(vs).cpu().numpy(), torch.cat(cs).cpu().numpy()
+    rel = lambda a, b: np.abs(a - b).max() / (np.abs(b).max() + 1e-12)
+    assert rel(lg, g["logits"]) < 3e-2 and rel(vs, g["values"]) < 3e-2 and rel(cs, g["c_values"]) < 3e-2, (rel(lg, g["logits"]), rel(vs, g["values"]))
+    assert all(t.time_step_counter == T for t in model.towers)
+    with torch.no_grad():
+        full, _ = model(obs, None, pa, mk)            # T > 1 resets the counters
+    assert all(t.time_step_counter == 0 for t in model.towers)
+    assert rel(lg, full.distributions.logits.cpu().numpy()) < 3e-2
+    model.sampler_select([0, 2])
+    assert model._kv[0].shape[0] == 2
+    for t in model.towers:
+        t._kv = None
