@@ -138,3 +138,37 @@ def test_full_update_lambda_adam_clip(setup):
     # restore weights for other tests
     model.arena.flat_p.copy_(p0)
     model.sync_weights(frozen=False)
+
+
+def test_checkpoint_roundtrip_and_il_handoff(setup, tmp_path):
+    from safevla_amd.checkpoint import init_towers_from_il, load_checkpoint, save_checkpoint
+    from safevla_amd.engine import PPOLagConfig, PPOLagEngine
+
+    model, g = setup
+    eng = PPOLagEngine(model, PPOLagConfig())
+    eng.opt_step = 7
+    p0 = model.arena.flat_p.clone()
+    path = str(tmp_path / "ck.pt")
+    save_checkpoint(path, model, eng, total_steps=1234)
+    model.arena.flat_p.mul_(0.5)
+    eng.opt_step = 0
+    load_checkpoint(path, model, eng)
+    assert torch.equal(model.arena.flat_p, p0) and eng.opt_step == 7
+    assert torch.equal(model.arena.flat_bf16, p0.to(torch.bfloat16))           # mirrors refreshed by load_state_dict
+    # Lightning IL checkpoint: "model." prefix, actor.weight -> actor.linear.weight, loaded into every tower
+    il = {"state_dict": {"model.actor.weight": torch.full((20, 512), 0.25), "model.actor.bias": torch.full((20,), -1.0),
+                         "model.decoder.norm.weight": torch.full((512,), 3.0), "model.visual_encoder.image_encoder.model.x": torch.zeros(1)}}
+    init_towers_from_il(model, il)
+    for t in model.towers:
+        assert (t.actor.linear.weight == 0.25).all() and (t.actor.linear.bias == -1).all() and (t.decoder.norm.weight == 3).all()
+    model.arena.flat_p.copy_(p0)
+    model.sync_weights(frozen=False)
+
+
+def test_train_entry_point_smoke(tmp_path):
+    from safevla_amd import train
+
+    rc = train.main(["train", "--num_train_processes", "2", "--num_steps", "8", "--total_steps", "16", "--cost_limit", "2.31964",
+                     "--output_dir", str(tmp_path), "--tag", "smoke", "--save_interval", "16"])
+    assert rc == 0
+    assert any(f.endswith(".pt") for f in os.listdir(tmp_path))
