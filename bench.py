@@ -184,9 +184,17 @@ def main():
     algo = flops_per_update(R, S, args.L, U, cfg.update_repeats)
 
     roof = None
-    if rank == 0 and not args.no_roofline:
-        with GemmTimer(ops) as gt:
+    gt = None
+    if not args.no_roofline:
+        # one extra, instrumented update: EVERY rank runs it (it contains the gradient / cost all-reduces), rank 0 times its
+        # MFMA-kernel launches with HIP events
+        if rank == 0:
+            with GemmTimer(ops) as gt:
+                step()
+        else:
             step()
+        parallel.barrier()
+    if rank == 0 and gt is not None:
         allk = gt.summary()
         g = allk["gemm_nt256"]
         executed = sum(v["flops"] for v in allk.values())
@@ -205,8 +213,6 @@ def main():
                                            "share_of_update": round(v["total_s"] / (ms * 1e-3), 3)} for k, v in allk.items() if k != "gemm_nt256"},
                 "executed_mfma_tflop_per_update": round(executed / 1e12, 1),
                 "executed_mfma_tflops_sustained": round(executed / (ms * 1e-3) / 1e12, 1)}
-    if world > 1:
-        parallel.barrier()
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(L=args.L)

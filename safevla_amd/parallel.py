@@ -44,10 +44,13 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" IS RCCL on ROCm
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+            # "nccl" IS RCCL on ROCm.  SVLA_DIST_BACKEND=gloo lets several ranks share one GPU (1-GPU test boxes).
+            backend = os.environ.get("SVLA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if torch.cuda.is_available():
+        local = local % torch.cuda.device_count()
     return rank, local, world
 
 
