@@ -12,6 +12,7 @@
 // address + on the ds_read_b128 fragment loads (bank-conflict free), XCD-aware tile order so
 // the N-tiles that share an A panel run back-to-back on one XCD's L2, LDS-staged epilogue with 16-byte stores.
 #include "common.h"
+#include <cstdlib>
 
 #define BM 128
 #define BN 128
@@ -40,6 +41,7 @@ struct GemmNtArgs {
     void* C; long ldc;
     int M, N, K, act, out_f32;
     float alpha;
+    int dbg;          // timing-only ablations of the 256-tile kernel (tools/ab_gemm.py): 1 = no C stores, 2 = no epilogue
 };
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
@@ -231,69 +233,93 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p)
 }
 
 // =================================================================================================
-// 256x256 tile variant (8 waves = 2(M) x 4(N), wave tile 128x64 = 4x2 MFMA 32x32 tiles) for the big row-streaming
-// GEMMs.  Why: a 128x128 tile needs 32 KiB of operands per 64-deep K step per 512 MFMA cycles = the CU's whole
-// 64 B/clk L1->LDS path (measured: 47 % of wave time parked, 24 % MFMA busy); 256x256 halves the bytes per FLOP and the
-// LDS reads per MFMA (6 fragments per 8 MFMAs).  Same 4-stage LDS-DMA pipeline with counted vmcnt; the epilogue goes
-// straight from registers: bias/activation/mask/residual in fp32 on the accumulator layout (4 consecutive columns per
-// lane), one bf16 rounding, v_permlane32_swap pairs the two half-waves into 16-byte row segments.
+// 256x256 tile kernel (8 waves = 2(M) x 4(N), wave tile 128x64 = 4x2 MFMA 32x32 tiles) for the big row-streaming GEMMs.
+// Why 256x256: a 128x128 tile needs 32 KiB of operands per 64-deep K step per 512 MFMA cycles = the CU's whole L1->LDS
+// path (measured: 47 % of wave time parked, 24 % MFMA busy); 256x256 halves the bytes per FLOP and the LDS reads per MFMA
+// (6 fragments per 8 MFMAs).
+// PERSISTENT: one workgroup per CU walks a list of tiles; the K-tiles of consecutive tiles form one continuous LDS-DMA
+// stream, so the first K-tile of the next output tile is in flight while the current tile's epilogue runs.
 #define NT256_THREADS 512
-// PERSISTENT: one workgroup per CU walks a list of tiles; the K-steps of consecutive tiles form one continuous DMA stream
-// (the first three K-steps of the next tile are in flight while the current tile's epilogue stores run), so the
-// per-tile prologue latency disappears and only the register epilogue itself is un-overlapped.
-// ABL: timing-only ablations of the main loop (1: no MFMA, 2: no vmcnt wait / barrier, 3: no fragment ds_reads, 4: no DMA)
-template <int ABL>
-__global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256_bf16_kernel(GemmNtArgs p) {
+// BK = 64: LDS rows are 128 bytes, so every LDS-DMA instruction moves 8 FULL 128-byte lines (a BK = 32 image fetches half
+// lines, 16 rows x 64 B per instruction, and the other half of each line one K-step later: measured -11 % at K = 2048,
+// -30 % on 8192^3).  NS64 = 2 operand buffers of 64 KiB + 8 wave-private 4 KiB epilogue buffers = 160 KiB of LDS.
+// Epilogue: bias/activation/mask/residual in fp32 on the accumulator layout, one bf16 rounding, then each 32 x 64 slab is
+// transposed through the wave's LDS buffer so that every global store instruction writes 8 full 128-byte lines.
+#define BK64 64
+#define NS64 2
+__device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+// ACT / AUX (bit 0: +residual, bit 1: ReLU mask) are compile-time: a runtime-selected epilogue unrolled over the 32 accumulator
+// pieces is ~100 KiB of code (128 inlined erff bodies ...) that evicts the main loop from the instruction cache once per tile.
+template <int ACT, int AUX>
+__global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(GemmNtArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* As = (bf16_t*)smem;                  // [NST][256][BK]
-    bf16_t* Bs = As + NST * 256 * BK;            // [NST][256][BK]
+    bf16_t* As = (bf16_t*)smem;                    // [NS64][256][64]
+    bf16_t* Bs = As + NS64 * 256 * BK64;           // [NS64][256][64]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 2, wn = wid & 3;
     const int ntn = p.N / 256, MT = (p.M + 255) / 256;
-    // XCD-aware persistent schedule: workgroup w runs on XCD w % 8 (observed dispatch rule, used for L2 locality only).
-    // XCD x owns m-tiles x, x+8, ...; its workgroups take (m-tile, n-tile) pairs in order, so the n-tiles of one A panel
-    // run at the same time on the same XCD's L2.
     const int xcd = blockIdx.x & 7, lw = blockIdx.x >> 3, lstride = gridDim.x >> 3;
-    const int n_local = ((MT - xcd + 7) / 8) * ntn;      // tiles owned by this XCD (MT >= 8 guaranteed by the launcher)
+    const int n_local = ((MT - xcd + 7) / 8) * ntn;
+    if (lw >= n_local) return;
+    const int my_tiles = (n_local - lw + lstride - 1) / lstride;
+    const int nk = p.K / BK64;
+    const int total = my_tiles * nk;
 
-    int ldsoff[2];
-    int srow[2], schunk[2];
+    int ldsoff[4], srow[4], schunk[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int rbase = (wid * 2 + j) * 16;
-        srow[j] = rbase + (lane >> 2);
-        schunk[j] = ((lane & 3) ^ ((srow[j] >> 2) & 3)) * 8;
-        ldsoff[j] = __builtin_amdgcn_readfirstlane(rbase * BK);
+    for (int j = 0; j < 4; ++j) {
+        const int rbase = (wid * 4 + j) * 8;
+        srow[j] = rbase + (lane >> 3);
+        schunk[j] = ((lane & 7) ^ ((srow[j] >> 1) & 7)) * 8;
+        ldsoff[j] = __builtin_amdgcn_readfirstlane(rbase * BK64);
     }
-    struct Src { const bf16_t* a[2]; const bf16_t* b[2]; };
-    auto tile_src = [&](int li, int& m0, int& n0) -> Src {
+    auto tile_origin = [&](int ti, int& m0, int& n0) {
+        const int li = lw + ti * lstride;
         m0 = ((li / ntn) * 8 + xcd) * 256;
         n0 = (li % ntn) * 256;
-        Src s;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            s.a[j] = p.A + (size_t)min(m0 + srow[j], p.M - 1) * p.lda + schunk[j];
-            s.b[j] = p.B + (size_t)(n0 + srow[j]) * p.ldb + schunk[j];
-        }
-        return s;
     };
-    auto stage = [&](int st, const Src& s, int k0) {
+    uint32_t offB[4], offA[4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s.a[j] + k0),
-                                             (__attribute__((address_space(3))) void*)(As + st * 256 * BK + ldsoff[j]), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s.b[j] + k0),
-                                             (__attribute__((address_space(3))) void*)(Bs + st * 256 * BK + ldsoff[j]), 16, 0, 0);
+    for (int j = 0; j < 4; ++j) offB[j] = (uint32_t)((srow[j] * p.ldb + schunk[j]) * 2);
+    const char* a_base = nullptr;
+    const char* b_base = nullptr;
+    auto set_dma_tile = [&](int ti) {
+        int m0d, n0d;
+        tile_origin(ti, m0d, n0d);
+        m0d = __builtin_amdgcn_readfirstlane(m0d);
+        n0d = __builtin_amdgcn_readfirstlane(n0d);
+        a_base = (const char*)p.A + (size_t)m0d * p.lda * 2;
+        b_base = (const char*)p.B + (size_t)n0d * p.ldb * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) offA[j] = (uint32_t)(((min(m0d + srow[j], p.M - 1) - m0d) * p.lda + schunk[j]) * 2);
+    };
+    int d = 0, d_kt = 0, d_tile = 0;
+    set_dma_tile(0);
+    auto issue_next = [&]() {
+        if (d >= total) return;
+        const int st = d % NS64;
+        const uint32_t kb = (uint32_t)(d_kt * BK64 * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + (offA[j] + kb)),
+                                             (__attribute__((address_space(3))) void*)(As + st * 256 * BK64 + ldsoff[j]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + (offB[j] + kb)),
+                                             (__attribute__((address_space(3))) void*)(Bs + st * 256 * BK64 + ldsoff[j]), 16, 0, 0);
+        }
+        ++d;
+        if (++d_kt == nk) {
+            d_kt = 0;
+            if (++d_tile < my_tiles) set_dma_tile(d_tile);
         }
     };
+
     f32x16 acc[4][2];
-    const int nk = p.K / BK;     // >= 3 (launcher)
     const int fr = lane & 31, fh = lane >> 5;
     bf16_t* C = (bf16_t*)p.C;
-
-    // one prefetched epilogue operand stream ("aux" = residual, else the ReLU mask), double-buffered per 32-row slab
-    const bf16_t* aux = p.residual ? p.residual : p.relu_mask;
-    const long ldaux = p.residual ? p.ldr : p.ldm;
+    constexpr bool HAS_RES = (AUX & 1) != 0, HAS_MASK = (AUX & 2) != 0;
+    const bf16_t* aux = HAS_RES ? p.residual : (HAS_MASK ? p.relu_mask : nullptr);
+    const long ldaux = HAS_RES ? p.ldr : p.ldm;
     u32x2 auxbuf[2][2][4];
     auto load_aux = [&](int i, u32x2 (&buf)[2][4], int tm0, int tn0) {
         const int mc = min(tm0 + wm * 128 + i * 32 + fr, p.M - 1);
@@ -304,20 +330,16 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256_bf16_kernel(GemmN
                 buf[j][rg] = *(const u32x2*)(aux + (size_t)mc * ldaux + tn0 + wn * 64 + j * 32 + 8 * rg + 4 * fh);
     };
 
-    int li = lw;
-    if (li >= n_local) return;
-    int m0, n0;
-    Src cur = tile_src(li, m0, n0);
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s) stage(s, cur, s * BK);
-    int g = 0;           // global K-step counter: LDS stage of step g is g % NST
-    bool first = true;
-    while (true) {
-        const int li_next = li + lstride;
-        const bool has_next = li_next < n_local;
-        int m0n = 0, n0n = 0;
-        Src nxt = cur;
-        if (has_next) nxt = tile_src(li_next, m0n, n0n);
+    // epilogue staging (wave-private 4 KiB): write (row fr, 8-byte piece), read (row lane>>3 [+8 it], 16-byte chunk lane&7)
+    char* Es = smem + (size_t)NS64 * 512 * BK64 * 2 + (size_t)__builtin_amdgcn_readfirstlane(wid) * 4096;
+    const int e_wr = fr * 128 + fh * 8, e_sw = fr & 7;
+    const int e_rd = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);
+    for (int s = 0; s < NS64 - 1; ++s) issue_next();
+    int g = 0;
+    bool prev_full = true;
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        int m0, n0;
+        tile_origin(ti, m0, n0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -325,123 +347,136 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256_bf16_kernel(GemmN
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int kt = 0; kt < nk; ++kt, ++g) {
-            // younger DMA groups allowed to stay in flight behind step (tile, kt): 2 while the stream continues.
-            // After an epilogue (loads/stores on the same counter) drain everything once: vmcnt(0).
-            const int rem = has_next ? 2 : nk - 1 - kt;
-            if constexpr (ABL != 2) {
-                if (kt == 0 && !first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (rem >= NST - 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            // stage g is the only DMA group in flight (NS64 = 2), except for the previous tile's 16 epilogue stores issued
+            // after it: those may keep draining (VM counter retires in order)
+            if (NS64 == 2) {
+                if (ti > 0 && kt == 0 && prev_full) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
             }
+            __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt == nk - 2 && aux) load_aux(0, auxbuf[0], m0, n0);   // epilogue operand of the first 32-row slab, hidden under the last K-steps
-            const int ka = kt + NST - 1;
-            if constexpr (ABL != 4) {
-                if (ka < nk) stage((g + NST - 1) % NST, cur, ka * BK);
-                else if (has_next) stage((g + NST - 1) % NST, nxt, (ka - nk) * BK);
-            }
-            const int st = g % NST;
-            const bf16_t* Ab = As + st * 256 * BK;
-            const bf16_t* Bb = Bs + st * 256 * BK;
+            if (AUX != 0 && kt == nk - 1) load_aux(0, auxbuf[0], m0, n0);
+            issue_next();
+            const int st = g % NS64;
+            const bf16_t* Ab = As + st * 256 * BK64;
+            const bf16_t* Bb = Bs + st * 256 * BK64;
 #pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
+            for (int kk = 0; kk < BK64 / 16; ++kk) {
                 bf16x8 fa[4], fb[2];
-                if constexpr (ABL == 3) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) { fa[t] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; asm volatile("" : "+v"(fa[t])); }
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) { fb[t] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; asm volatile("" : "+v"(fb[t])); }
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int r_ = wm * 128 + t * 32 + fr;
-                        fa[t] = *(const bf16x8*)(Ab + r_ * BK + swz_nt(r_, kk * 2 + fh) * 8);
-                    }
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int r_ = wn * 64 + t * 32 + fr;
-                        fb[t] = *(const bf16x8*)(Bb + r_ * BK + swz_nt(r_, kk * 2 + fh) * 8);
-                    }
+                for (int t = 0; t < 4; ++t) {
+                    const int r_ = wm * 128 + t * 32 + fr;
+                    fa[t] = *(const bf16x8*)(Ab + r_ * BK64 + swz64(r_, kk * 2 + fh) * 8);
                 }
-                if constexpr (ABL == 1) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(fa[t]));
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) asm volatile("" ::"v"(fb[t]));
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[i][j] = mfma32(fb[j], fa[i], acc[i][j]);
+                for (int t = 0; t < 2; ++t) {
+                    const int r_ = wn * 64 + t * 32 + fr;
+                    fb[t] = *(const bf16x8*)(Bb + r_ * BK64 + swz64(r_, kk * 2 + fh) * 8);
                 }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = mfma32(fb[j], fa[i], acc[i][j]);
             }
         }
-
-        // ---- epilogue from registers.  acc[i][j][4*rg + e]: row m = m0 + wm*128 + i*32 + fr,
-        //                                col n = n0 + wn*64 + j*32 + 8*rg + 4*fh + e
-        f32x4 bias4[2][4];
+        if (p.dbg & 2) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg)
-                bias4[j][rg] = p.bias ? *(const f32x4*)(p.bias + n0 + wn * 64 + j * 32 + 8 * rg + 4 * fh) : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+        } else {
+            f32x4 bias4[2][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 128 + i * 32 + fr;
-            const int mc = min(m, p.M - 1);
-            if (aux && i + 1 < 4) load_aux(i + 1, auxbuf[(i + 1) & 1], m0, n0);
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int nb = n0 + wn * 64 + j * 32;
-                u32x2 pk[4];
+                for (int rg = 0; rg < 4; ++rg)
+                    bias4[j][rg] = p.bias ? *(const f32x4*)(p.bias + n0 + wn * 64 + j * 32 + 8 * rg + 4 * fh) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int n = nb + 8 * rg + 4 * fh;
-                    float v[4];
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wm * 128 + i * 32 + fr;
+                const int mc = min(m, p.M - 1);
+                if (AUX != 0 && i + 1 < 4) load_aux(i + 1, auxbuf[(i + 1) & 1], m0, n0);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[i][j][rg * 4 + e] * p.alpha + bias4[j][rg][e];
-                        if (p.act == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
-                        else if (p.act == ACT_GELU) v[e] = gelu_f(v[e]);
+                for (int j = 0; j < 2; ++j) {
+                    const int nb = n0 + wn * 64 + j * 32;
+                    u32x2 pk[4];
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int n = nb + 8 * rg + 4 * fh;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[i][j][rg * 4 + e] * p.alpha + bias4[j][rg][e];
+                            if (ACT == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                            else if (ACT == ACT_GELU) v[e] = gelu_f(v[e]);
+                        }
+                        if (HAS_MASK) {
+                            const u32x2 mk = HAS_RES ? *(const u32x2*)(p.relu_mask + (size_t)mc * p.ldm + n) : auxbuf[i & 1][j][rg];
+                            if (!(bf_lo(mk[0]) > 0.f)) v[0] = 0.f;
+                            if (!(bf_hi(mk[0]) > 0.f)) v[1] = 0.f;
+                            if (!(bf_lo(mk[1]) > 0.f)) v[2] = 0.f;
+                            if (!(bf_hi(mk[1]) > 0.f)) v[3] = 0.f;
+                        }
+                        if (HAS_RES) {
+                            const u32x2 rs = auxbuf[i & 1][j][rg];
+                            v[0] += bf_lo(rs[0]); v[1] += bf_hi(rs[0]); v[2] += bf_lo(rs[1]); v[3] += bf_hi(rs[1]);
+                        }
+                        pk[rg][0] = pack_bf2(v[0], v[1]);
+                        pk[rg][1] = pack_bf2(v[2], v[3]);
+                        *(u32x2*)(Es + e_wr + (((j * 4 + rg) ^ e_sw) << 4)) = pk[rg];
                     }
-                    if (p.relu_mask) {
-                        // the mask is the prefetched stream unless a residual is also present (then it is read here)
-                        const u32x2 mk = p.residual ? *(const u32x2*)(p.relu_mask + (size_t)mc * p.ldm + n) : auxbuf[i & 1][j][rg];
-                        if (!(bf_lo(mk[0]) > 0.f)) v[0] = 0.f;
-                        if (!(bf_hi(mk[0]) > 0.f)) v[1] = 0.f;
-                        if (!(bf_lo(mk[1]) > 0.f)) v[2] = 0.f;
-                        if (!(bf_hi(mk[1]) > 0.f)) v[3] = 0.f;
-                    }
-                    if (p.residual) {
-                        const u32x2 rs = auxbuf[i & 1][j][rg];
-                        v[0] += bf_lo(rs[0]); v[1] += bf_hi(rs[0]); v[2] += bf_lo(rs[1]); v[3] += bf_hi(rs[1]);
-                    }
-                    pk[rg][0] = pack_bf2(v[0], v[1]);
-                    pk[rg][1] = pack_bf2(v[2], v[3]);
                 }
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int rg = 0; rg < 4; rg += 2) {
-                    // half-wave exchange: lanes 0-31 end with columns 8rg..8rg+7, lanes 32-63 with 8rg+8..8rg+15 of row m
-                    const auto sx = __builtin_amdgcn_permlane32_swap(pk[rg][0], pk[rg + 1][0], false, false);
-                    const auto sy = __builtin_amdgcn_permlane32_swap(pk[rg][1], pk[rg + 1][1], false, false);
-                    const u32x4 w = {sx[0], sy[0], sx[1], sy[1]};
-                    if (m < p.M) *(u32x4*)(C + (size_t)m * p.ldc + nb + 8 * rg + 8 * fh) = w;
+                for (int it = 0; it < 4; ++it) {
+                    const u32x4 w = *(const u32x4*)(Es + it * 1024 + e_rd);
+                    const int mr = m0 + wm * 128 + i * 32 + it * 8 + (lane >> 3);
+                    if (p.dbg & 1) { asm volatile("" ::"v"(w)); }
+                    else if (mr < p.M) *(u32x4*)(C + (size_t)mr * p.ldc + n0 + wn * 64 + (lane & 7) * 8) = w;
                 }
+                __builtin_amdgcn_wave_barrier();
             }
         }
-        if (!has_next) break;
-        li = li_next; cur = nxt; m0 = m0n; n0 = n0n; first = false;
+        prev_full = m0 + 256 <= p.M;
     }
 }
 
-static int g_force_small_tile = 0, g_ablate = 0;
-// on = 0/1: normal dispatch / force the 128x128 kernels; on = 10 + k: timing-only ablation k of the 256-tile main loop
+template <int ACT, int AUX>
+static int launch_nt256_inst(const GemmNtArgs& p, int grid, hipStream_t stream) {
+    const size_t lds = (size_t)NS64 * 512 * BK64 * 2 + 32768;   // 160 KiB
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt256k64_bf16_kernel<ACT, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_nt256k64_bf16_kernel<ACT, AUX>), dim3(grid), dim3(NT256_THREADS), lds, stream, p);
+    return svla_launch_status();
+}
+static int launch_nt256(const GemmNtArgs& p, int grid, hipStream_t stream) {
+    const int aux = (p.residual ? 1 : 0) | (p.relu_mask ? 2 : 0);
+    switch (p.act * 4 + aux) {
+        case 0: return launch_nt256_inst<0, 0>(p, grid, stream);
+        case 1: return launch_nt256_inst<0, 1>(p, grid, stream);
+        case 2: return launch_nt256_inst<0, 2>(p, grid, stream);
+        case 3: return launch_nt256_inst<0, 3>(p, grid, stream);
+        case 4: return launch_nt256_inst<1, 0>(p, grid, stream);
+        case 5: return launch_nt256_inst<1, 1>(p, grid, stream);
+        case 6: return launch_nt256_inst<1, 2>(p, grid, stream);
+        case 7: return launch_nt256_inst<1, 3>(p, grid, stream);
+        case 8: return launch_nt256_inst<2, 0>(p, grid, stream);
+        case 9: return launch_nt256_inst<2, 1>(p, grid, stream);
+        case 10: return launch_nt256_inst<2, 2>(p, grid, stream);
+        case 11: return launch_nt256_inst<2, 3>(p, grid, stream);
+        default: return SVLA_EINVAL;
+    }
+}
+
+static int g_force_small_tile = 0, g_dbg = 0;
+// on = 0/1: normal dispatch / force the 128x128 kernels; on = 10 + f: timing-only ablation flags f of the 256-tile kernel
 extern "C" int svla_gemm_force_small_tile(int on) {
-    if (on >= 10) { g_ablate = on - 10; g_force_small_tile = 0; }
-    else { g_ablate = 0; g_force_small_tile = on; }
+    if (on >= 10) { g_dbg = on - 10; g_force_small_tile = 0; }
+    else { g_dbg = 0; g_force_small_tile = on; }
     return SVLA_OK;
 }
 
@@ -449,19 +484,10 @@ extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, lon
                                  const bf16_t* residual, long ldr, const bf16_t* relu_mask, long ldm, void* C, long ldc,
                                  int M, int N, int K, int act, int out_f32, float alpha, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || (N % BN) || (K % BK)) return SVLA_EINVAL;
+    if (act < ACT_NONE || act > ACT_GELU) return SVLA_EINVAL;
     if ((lda % 8) || (ldb % 8) || (ldc % (out_f32 ? 4 : 8)) || (residual && (ldr % 8)) || (relu_mask && (ldm % 8))) return SVLA_EINVAL;
-    GemmNtArgs p{A, lda, B, ldb, bias, residual, ldr, relu_mask, ldm, C, ldc, M, N, K, act, out_f32, alpha};
-    if (!out_f32 && (N % 256) == 0 && (long)((M + 255) / 256) * (N / 256) >= 256 && K >= 3 * BK && !g_force_small_tile) {
-        const size_t lds256 = (size_t)NST * 512 * BK * sizeof(bf16_t);  // 128 KiB
-        static bool attr256 = false;
-        if (!attr256) {
-            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt256_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
-            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt256_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
-            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt256_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
-            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt256_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
-            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt256_bf16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
-            attr256 = true;
-        }
+    GemmNtArgs p{A, lda, B, ldb, bias, residual, ldr, relu_mask, ldm, C, ldc, M, N, K, act, out_f32, alpha, g_dbg};
+    if (!out_f32 && (N % 256) == 0 && (K % BK64) == 0 && K >= 2 * BK64 && (long)((M + 255) / 256) * (N / 256) >= 256 && !g_force_small_tile) {
         static int n_cu = 0;
         if (!n_cu) {
             int dev = 0;
@@ -471,16 +497,9 @@ extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, lon
             if (n_cu < 8) n_cu = 8;
         }
         const int ntiles = ((M + 255) / 256) * (N / 256);
-        int grid = n_cu;                       // persistent: one 512-thread workgroup (128 KiB LDS) per CU
+        int grid = n_cu;                       // persistent: one 512-thread workgroup (160 KiB LDS) per CU
         while (grid > 8 && (grid / 8) * 8 > ntiles) grid -= 8;
-        switch (g_ablate) {   // timing-only experiments (tools/ablate_gemm.py); 0 = the product kernel
-            case 1: hipLaunchKernelGGL(gemm_nt256_bf16_kernel<1>, dim3(grid), dim3(NT256_THREADS), lds256, (hipStream_t)stream, p); break;
-            case 2: hipLaunchKernelGGL(gemm_nt256_bf16_kernel<2>, dim3(grid), dim3(NT256_THREADS), lds256, (hipStream_t)stream, p); break;
-            case 3: hipLaunchKernelGGL(gemm_nt256_bf16_kernel<3>, dim3(grid), dim3(NT256_THREADS), lds256, (hipStream_t)stream, p); break;
-            case 4: hipLaunchKernelGGL(gemm_nt256_bf16_kernel<4>, dim3(grid), dim3(NT256_THREADS), lds256, (hipStream_t)stream, p); break;
-            default: hipLaunchKernelGGL(gemm_nt256_bf16_kernel<0>, dim3(grid), dim3(NT256_THREADS), lds256, (hipStream_t)stream, p);
-        }
-        return svla_launch_status();
+        return launch_nt256(p, grid, (hipStream_t)stream);
     }
     const int mt = (M + BM - 1) / BM, nt = N / BN;
     const size_t lds = BM * (BN + 4) * sizeof(float);  // 66 KiB: max(NST operand stages 64 KiB, fp32 epilogue tile)

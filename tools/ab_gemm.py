@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""256-tile NT GEMM: bit-compare with the 128-tile kernel over all epilogue flavours, then time (optionally with the
+timing-only ablation flags f of svla_gemm_force_small_tile(10 + f): 1 = no C stores, 2 = no epilogue)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from safevla_amd import ops
+from safevla_amd._lib import lib
+variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0").split(",")]
+sel = lambda v: lib().call("svla_gemm_force_small_tile", 10 + v)
+
+# ---- correctness: every epilogue flavour, ragged M, several K
+torch.manual_seed(0)
+for (M, n, k) in [(256 * 300 + 77, 512, 512), (256 * 270, 1536, 128), (256 * 700 + 1, 256, 384), (256 * 256 + 255, 2048, 2048)]:
+    A = torch.randn(M, k, device="cuda").to(torch.bfloat16); B = (torch.randn(n, k, device="cuda") * 0.05).to(torch.bfloat16)
+    bias = torch.randn(n, device="cuda"); res = torch.randn(M, n, device="cuda").to(torch.bfloat16)
+    mask = torch.randn(M, n, device="cuda").to(torch.bfloat16)
+    for name, kw in [("plain", {}), ("bias+relu", dict(bias=bias, act=1)), ("bias+gelu", dict(bias=bias, act=2)), ("bias+res", dict(bias=bias, residual=res)),
+                     ("mask", dict(relu_mask=mask)), ("mask+res", dict(relu_mask=mask, residual=res, alpha=0.5)), ("relu+res", dict(bias=bias, act=1, residual=res)), ("gelu+res", dict(bias=bias, act=2, residual=res))]:
+        lib().call("svla_gemm_force_small_tile", 1); ref = ops.gemm_nt(A, B, M, n, k, **kw); torch.cuda.synchronize()
+        for v in [0]:
+            for rep in range(3):
+                sel(v); out = torch.full_like(ref, float("nan")); ops.gemm_nt(A, B, M, n, k, out=out, **kw); torch.cuda.synchronize()
+                bad = (out.view(torch.int16) != ref.view(torch.int16)).sum().item()
+                if bad: print(f"MISMATCH v{v} M={M} N={n} K={k} {name}: {bad} elements differ (rep {rep})", flush=True); break
+    del A, B, res, mask
+    print(f"checked M={M} N={n} K={k}", flush=True)
+sel(0)
+
+M = 8192 * 181
+for (n, k) in [(512, 512), (1536, 512), (2048, 512), (512, 2048)]:
+    A = torch.randn(M, k, device="cuda").to(torch.bfloat16); B = torch.randn(n, k, device="cuda").to(torch.bfloat16)
+    out = torch.empty(M, n, device="cuda", dtype=torch.bfloat16)
+    res = {}
+    for rep in range(3):
+        for abl in variants:
+            sel(abl)
+            for _ in range(2): ops.gemm_nt(A, B, M, n, k, out=out)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10): ops.gemm_nt(A, B, M, n, k, out=out)
+            e1.record(); torch.cuda.synchronize()
+            res.setdefault(abl, []).append(e0.elapsed_time(e1) / 10)
+    sel(0)
+    print(f"N={n} K={k}: " + "  ".join(f"v{a}: {min(t):.3f} ms ({2*M*n*k/min(t)/1e9:.0f} TF)" for a, t in res.items()), flush=True)
+    del A, B, out
