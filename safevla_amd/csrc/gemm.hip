@@ -320,16 +320,16 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
     constexpr bool HAS_RES = (AUX & 1) != 0, HAS_MASK = (AUX & 2) != 0;
     const bf16_t* aux = HAS_RES ? p.residual : (HAS_MASK ? p.relu_mask : nullptr);
     const long ldaux = HAS_RES ? p.ldr : p.ldm;
-    u32x2 auxbuf[2][2][4];
-    auto load_aux = [&](int i, u32x2 (&buf)[2][4], int tm0, int tn0) {
-        const int mc = min(tm0 + wm * 128 + i * 32 + fr, p.M - 1);
+    // the residual / mask slab is fetched row-major (8 full 128-byte lines per instruction), one slab ahead, and turned into the
+    // accumulator layout through the wave's LDS buffer (the inverse of the output transposition)
+    u32x4 auxrm[2][4];
+    auto load_aux = [&](int i, u32x4 (&buf)[4], int tm0, int tn0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg)
-                buf[j][rg] = *(const u32x2*)(aux + (size_t)mc * ldaux + tn0 + wn * 64 + j * 32 + 8 * rg + 4 * fh);
+        for (int it = 0; it < 4; ++it) {
+            const int mr = min(tm0 + wm * 128 + i * 32 + it * 8 + (lane >> 3), p.M - 1);
+            buf[it] = *(const u32x4*)(aux + (size_t)mr * ldaux + tn0 + wn * 64 + (lane & 7) * 8);
+        }
     };
-
     // epilogue staging (wave-private 4 KiB): write (row fr, 8-byte piece), read (row lane>>3 [+8 it], 16-byte chunk lane&7)
     char* Es = smem + (size_t)NS64 * 512 * BK64 * 2 + (size_t)__builtin_amdgcn_readfirstlane(wid) * 4096;
     const int e_wr = fr * 128 + fh * 8, e_sw = fr & 7;
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
             }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (AUX != 0 && kt == nk - 1) load_aux(0, auxbuf[0], m0, n0);
+            if (AUX != 0 && kt == nk - 1) load_aux(0, auxrm[0], m0, n0);
             issue_next();
             const int st = g % NS64;
             const bf16_t* Ab = As + st * 256 * BK64;
@@ -396,7 +396,12 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + wm * 128 + i * 32 + fr;
                 const int mc = min(m, p.M - 1);
-                if (AUX != 0 && i + 1 < 4) load_aux(i + 1, auxbuf[(i + 1) & 1], m0, n0);
+                if (AUX != 0 && i + 1 < 4) load_aux(i + 1, auxrm[(i + 1) & 1], m0, n0);
+                if (AUX != 0) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) *(u32x4*)(Es + it * 1024 + e_rd) = auxrm[i & 1][it];
+                    __builtin_amdgcn_wave_barrier();
+                }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int nb = n0 + wn * 64 + j * 32;
@@ -412,14 +417,14 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
                             else if (ACT == ACT_GELU) v[e] = gelu_f(v[e]);
                         }
                         if (HAS_MASK) {
-                            const u32x2 mk = HAS_RES ? *(const u32x2*)(p.relu_mask + (size_t)mc * p.ldm + n) : auxbuf[i & 1][j][rg];
+                            const u32x2 mk = HAS_RES ? *(const u32x2*)(p.relu_mask + (size_t)mc * p.ldm + n) : *(const u32x2*)(Es + e_wr + (((j * 4 + rg) ^ e_sw) << 4));
                             if (!(bf_lo(mk[0]) > 0.f)) v[0] = 0.f;
                             if (!(bf_hi(mk[0]) > 0.f)) v[1] = 0.f;
                             if (!(bf_lo(mk[1]) > 0.f)) v[2] = 0.f;
                             if (!(bf_hi(mk[1]) > 0.f)) v[3] = 0.f;
                         }
                         if (HAS_RES) {
-                            const u32x2 rs = auxbuf[i & 1][j][rg];
+                            const u32x2 rs = *(const u32x2*)(Es + e_wr + (((j * 4 + rg) ^ e_sw) << 4));
                             v[0] += bf_lo(rs[0]); v[1] += bf_hi(rs[0]); v[2] += bf_lo(rs[1]); v[3] += bf_hi(rs[1]);
                         }
                         pk[rg][0] = pack_bf2(v[0], v[1]);
