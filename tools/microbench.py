@@ -38,6 +38,9 @@ if "tn" in which:
         ms = t_ms(lambda: ops.gemm_tn_acc(dY, X, dW, m, n, k))
         byt = (m * k + m * n) * 2
         print(f"gemm_tn {tag:6s} M={m} N={n} K={k}: {ms:8.3f} ms  {2*m*n*k/ms/1e9:8.1f} TF  {byt/ms/1e6:7.1f} GB/s(min)")
+        db = torch.zeros(n, device=dev)
+        ms = t_ms(lambda: ops.gemm_tn_acc(dY, X, dW, m, n, k, db=db))
+        print(f"   +fused bias grad: {ms:8.3f} ms  {2*m*n*k/ms/1e9:8.1f} TF")
         del dY, X
 if "attn" in which:
     qkv = rb(M, 1536)
