@@ -13,7 +13,8 @@
 #include "common.h"
 
 #define HD 64
-#define LDSROW 72   // padded LDS row in elements (144 B): conflict-free 16-byte row reads
+#define LDSROW 64   // LDS row = 128 B (one head slice row), 16-byte chunks XOR-swizzled: 48 KiB for two [192, 64] operands,
+                    // so THREE workgroups fit a CU's 160 KiB (the kernels are latency-bound: 1 -> 2 workgroups/CU = 1.74x)
 #define ATT_THREADS 256
 
 enum { MASK_NONE = 0, MASK_BLOCK_CAUSAL = 1 };
@@ -34,24 +35,35 @@ struct AttnArgs {
     long ldq, lddq;                       // token row strides of Q and dQ (the K/V tensors use ld / ldd)
 };
 
-__device__ __forceinline__ bf16x8 lds_row8(const bf16_t* base, int row, int col) {
-    return *(const bf16x8*)(base + row * LDSROW + col);
+// physical 16-byte chunk of logical chunk c in row r: c ^ ((r >> 1) & 7).  16 consecutive rows x one logical chunk hit 16
+// distinct 16-byte bank slots (conflict-free ds_read_b128); a transposed 64-lane read (16 rows x 32 B) takes its 2 cycles.
+__device__ __forceinline__ int att_swz(int row) { return (row >> 1) & 7; }
+
+// Lane bases of the two access patterns (tile rows are multiples of 16, so the swizzle term depends on the lane only and the
+// tile offset stays a compile-time immediate of the ds_read):
+//   row fragment  : row = tile + (lane & 15), logical chunk (lane >> 4) [+4 for columns 32..63]
+//   transposed    : row = tile + 4 (lane >> 4) + ((lane & 15) >> 2), columns dt*16 + 4 ((lane & 15) & 3) .. +3
+struct RowBase { const bf16_t* lo; const bf16_t* hi; };
+__device__ __forceinline__ RowBase att_row_base(const bf16_t* tile, int lane) {
+    const int ql = lane & 15, g = lane >> 4, f = att_swz(ql);
+    return RowBase{tile + ql * LDSROW + ((g ^ f) << 3), tile + ql * LDSROW + (((g + 4) ^ f) << 3)};
 }
-// same with the per-lane part (row = lane&15, col = 8*(lane>>4)) pre-added to ``lane_base``: with unrolled tile loops the
-// remaining offset is a compile-time immediate of the ds_read
-__device__ __forceinline__ bf16x8 lds_row8i(const bf16_t* lane_base, int tile_row0, int col0) {
-    return *(const bf16x8*)(lane_base + tile_row0 * LDSROW + col0);
+struct TrBase { const bf16_t* d[4]; };
+__device__ __forceinline__ TrBase att_tr_base(const bf16_t* tile, int lane) {
+    const int ql = lane & 15, g = lane >> 4;
+    const int row = 4 * g + (ql >> 2), f = att_swz(row);
+    TrBase t;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) t.d[dt] = tile + row * LDSROW + (((2 * dt + ((ql & 3) >> 1)) ^ f) << 3) + 4 * (ql & 1);
+    return t;
 }
-__device__ __forceinline__ bf16x8 lds_tr8i(const bf16_t* lane_base, int rA, int rB, int c0) {
-    const bf16x4 lo = lds_tr16_b64(lane_base + rA * LDSROW + c0);
-    const bf16x4 hi = lds_tr16_b64(lane_base + rB * LDSROW + c0);
-    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+__device__ __forceinline__ bf16x8 lds_row8i(const bf16_t* lane_base, int tile_row0) {
+    return *(const bf16x8*)(lane_base + tile_row0 * LDSROW);
 }
-// B-operand gather: 8 reduction slots = rows {rA + 4g + 0..3, rB + 4g + 0..3}, column c0 + (lane & 15)
-__device__ __forceinline__ bf16x8 lds_tr8(const bf16_t* base, int rA, int rB, int c0, int lane) {
-    const int p = lane & 15, g = lane >> 4;
-    const bf16x4 lo = lds_tr16_b64(base + (rA + 4 * g + (p >> 2)) * LDSROW + c0 + 4 * (p & 3));
-    const bf16x4 hi = lds_tr16_b64(base + (rB + 4 * g + (p >> 2)) * LDSROW + c0 + 4 * (p & 3));
+// B/A-operand gather: 8 reduction slots = rows {rA + 4g + 0..3, rB + 4g + 0..3}, column dt*16 + (lane & 15)
+__device__ __forceinline__ bf16x8 lds_tr8i(const bf16_t* lane_base_dt, int rA, int rB) {
+    const bf16x4 lo = lds_tr16_b64(lane_base_dt + rA * LDSROW);
+    const bf16x4 hi = lds_tr16_b64(lane_base_dt + rB * LDSROW);
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 __device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
@@ -79,7 +91,7 @@ __device__ __forceinline__ void stage_head(bf16_t* dst, const bf16_t* src, long 
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         const int q = tid + i * ATT_THREADS;
-        *(u32x4*)(dst + (q >> 3) * LDSROW + (q & 7) * 8) = w[i];
+        *(u32x4*)(dst + (q >> 3) * LDSROW + (((q & 7) ^ att_swz(q >> 3)) << 3)) = w[i];
     }
 }
 
@@ -129,8 +141,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
     }
     __syncthreads();
     const unsigned char* kvp = p.kvalid ? kv_s : nullptr;
-    const bf16_t* Krow = Ks + ql * LDSROW + 8 * g;                                  // row-fragment lane base
-    const bf16_t* Vtr = Vs + (4 * g + (ql >> 2)) * LDSROW + 4 * (ql & 3);           // transpose-read lane base
+    const RowBase Krow = att_row_base(Ks, lane);
+    const TrBase Vtr = att_tr_base(Vs, lane);
 #pragma unroll
     for (int t = 0; t < MAXQT; ++t) {
         const int qt = wid + 4 * t;
@@ -144,8 +156,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
         for (int kt = 0; kt < NKT; ++kt) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
             if (kt * 16 < S) {
-                a = mfma16(lds_row8i(Krow, kt * 16, 0), qf[0], a);
-                a = mfma16(lds_row8i(Krow, kt * 16, 32), qf[1], a);
+                a = mfma16(lds_row8i(Krow.lo, kt * 16), qf[0], a);
+                a = mfma16(lds_row8i(Krow.hi, kt * 16), qf[1], a);
             }
             if constexpr (GENERIC) {
 #pragma unroll
@@ -190,19 +202,16 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
                 const bf16x8 pa = pack8(pv);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
-                    o[dt] = mfma16(pa, lds_tr8i(Vtr, 32 * u, 32 * u + 16, dt * 16), o[dt]);
+                    o[dt] = mfma16(lds_tr8i(Vtr.d[dt], 32 * u, 32 * u + 16), pa, o[dt]);   // O^T: rows = head dims, cols = queries
             }
         }
-        // o[dt][e]: query row qt*16 + 4g + e, column dt*16 + ql
-        const float inv_own = lsum > 0.f ? 1.f / lsum : 0.f;
+        // o[dt][e]: query q (this lane's own softmax row), head dim dt*16 + 4g + e  ->  8-byte stores, 32 B per row per dt
+        const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+        if (q < Sq) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float inv = __shfl(inv_own, 4 * g + e, 64);
-            const int qo = qt * 16 + 4 * g + e;
-            if (qo < Sq) {
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    p.O[(qtok0 + qo) * p.ldo + h * HD + dt * 16 + ql] = f2bf(o[dt][e] * inv);
+            for (int dt = 0; dt < 4; ++dt) {
+                const u32x2 w = {pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv)};
+                *(u32x2*)(p.O + (qtok0 + q) * p.ldo + h * HD + dt * 16 + 4 * g) = w;
             }
         }
         if (p.LSE && g == 0 && q < Sq) p.LSE[((size_t)r * p.H + h) * Sq + q] = (mx + __log2f(lsum)) * LN2;   // natural-log LSE
@@ -263,9 +272,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dq_kernel(AttnArgs p) {
     }
     __syncthreads();
     const unsigned char* kvp = p.kvalid ? kv_s : nullptr;
-    const bf16_t* Krow = Ks + ql * LDSROW + 8 * g;
-    const bf16_t* Vrow = Vs + ql * LDSROW + 8 * g;
-    const bf16_t* Ktr = Ks + (4 * g + (ql >> 2)) * LDSROW + 4 * (ql & 3);
+    const RowBase Krow = att_row_base(Ks, lane), Vrow = att_row_base(Vs, lane);
+    const TrBase Ktr = att_tr_base(Ks, lane);
     const int ntile = (Sq + 15) / 16;
 #pragma unroll
     for (int t = 0; t < MAXQT; ++t) {
@@ -290,10 +298,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dq_kernel(AttnArgs p) {
                 for (int e2 = 0; e2 < 2; ++e2) {
                     const int kt = 2 * u + e2;
                     f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                    s = mfma16(lds_row8i(Krow, kt * 16, 0), qf0, s);
-                    s = mfma16(lds_row8i(Krow, kt * 16, 32), qf1, s);
-                    dp = mfma16(lds_row8i(Vrow, kt * 16, 0), gf0, dp);
-                    dp = mfma16(lds_row8i(Vrow, kt * 16, 32), gf1, dp);
+                    s = mfma16(lds_row8i(Krow.lo, kt * 16), qf0, s);
+                    s = mfma16(lds_row8i(Krow.hi, kt * 16), qf1, s);
+                    dp = mfma16(lds_row8i(Vrow.lo, kt * 16), gf0, dp);
+                    dp = mfma16(lds_row8i(Vrow.hi, kt * 16), gf1, dp);
                     if constexpr (GENERIC) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -315,23 +323,21 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dq_kernel(AttnArgs p) {
                 const bf16x8 da = pack8(dsv);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
-                    dq[dt] = mfma16(da, lds_tr8i(Ktr, 32 * u, 32 * u + 16, dt * 16), dq[dt]);
+                    dq[dt] = mfma16(lds_tr8i(Ktr.d[dt], 32 * u, 32 * u + 16), da, dq[dt]);   // dQ^T: rows = head dims, cols = queries
             }
         }
+        if (qok) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int qo = qt * 16 + 4 * g + e;
-            if (qo < Sq) {
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    p.dQ[(qtok0 + qo) * p.lddq + h * HD + dt * 16 + ql] = f2bf(dq[dt][e]);
+            for (int dt = 0; dt < 4; ++dt) {
+                const u32x2 w = {pack_bf2(dq[dt][0], dq[dt][1]), pack_bf2(dq[dt][2], dq[dt][3])};
+                *(u32x2*)(p.dQ + (qtok0 + q) * p.lddq + h * HD + dt * 16 + 4 * g) = w;
             }
         }
     }
 }
 
 template <int NKT, bool GENERIC>
-__global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dkv_kernel(AttnArgs p) {
+__global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 1) attn_bwd_dkv_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16;
     bf16_t* Qs = (bf16_t*)smem;
@@ -344,18 +350,19 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dkv_kernel(AttnArgs p) {
     const int r = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const size_t tok0 = (size_t)r * p.S;
     const int S = p.S;
-    // this wave's K/V B-operand fragments for all its key tiles, issued ahead of the staging barrier
+    // this wave's K/V B-operand fragments: the first key tile's are issued ahead of the staging barrier, tile t+1's at the top
+    // of tile t (two register sets instead of MAXKT: the kernel must fit 168 VGPRs to run 3 workgroups per CU)
     constexpr int MAXKT = (NKT + 3) / 4;
-    bf16x8 kvall[MAXKT][4];
-#pragma unroll
-    for (int t = 0; t < MAXKT; ++t) {
+    bf16x8 kvbuf[2][4];
+    auto load_kv = [&](int t, bf16x8 (&dst)[4]) {
         const int keyl = (wid + 4 * t) * 16 + (lane & 15);
         const bool kok = keyl < S;
         const bf16_t* kp = p.K + (tok0 + (kok ? keyl : 0)) * p.ld + h * HD + 8 * (lane >> 4);
         const bf16_t* vp = p.V + (tok0 + (kok ? keyl : 0)) * p.ld + h * HD + 8 * (lane >> 4);
-        kvall[t][0] = gld8(kp, kok); kvall[t][1] = gld8(kp + 32, kok);
-        kvall[t][2] = gld8(vp, kok); kvall[t][3] = gld8(vp + 32, kok);
-    }
+        dst[0] = gld8(kp, kok); dst[1] = gld8(kp + 32, kok);
+        dst[2] = gld8(vp, kok); dst[3] = gld8(vp + 32, kok);
+    };
+    load_kv(0, kvbuf[0]);
     const int Sq = p.Sq;
     const size_t qtok0 = (size_t)r * Sq;
     stage_head<SP>(Qs, p.Q + qtok0 * p.ldq + h * HD, p.ldq, Sq, tid);
@@ -393,17 +400,16 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dkv_kernel(AttnArgs p) {
     const int ql = lane & 15, g = lane >> 4;
     const int ntile = (S + 15) / 16;
     const float sl2 = p.scale * LOG2E;
-    const bf16_t* Qrow = Qs + ql * LDSROW + 8 * g;
-    const bf16_t* Grow = Gs + ql * LDSROW + 8 * g;
-    const bf16_t* Qtr = Qs + (4 * g + (ql >> 2)) * LDSROW + 4 * (ql & 3);
-    const bf16_t* Gtr = Gs + (4 * g + (ql >> 2)) * LDSROW + 4 * (ql & 3);
+    const RowBase Qrow = att_row_base(Qs, lane), Grow = att_row_base(Gs, lane);
+    const TrBase Qtr = att_tr_base(Qs, lane), Gtr = att_tr_base(Gs, lane);
 #pragma unroll
     for (int t = 0; t < MAXKT; ++t) {
         const int kt = wid + 4 * t;
         if (kt >= ntile) break;
         const int keyl = kt * 16 + ql;  // this lane's key as the B-operand column
         const bool kok = keyl < S;
-        const bf16x8 kf0 = kvall[t][0], kf1 = kvall[t][1], vf0 = kvall[t][2], vf1 = kvall[t][3];
+        if (t + 1 < MAXKT && kt + 4 < ntile) load_kv(t + 1, kvbuf[(t + 1) & 1]);
+        const bf16x8 kf0 = kvbuf[t & 1][0], kf1 = kvbuf[t & 1][1], vf0 = kvbuf[t & 1][2], vf1 = kvbuf[t & 1][3];
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -415,10 +421,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dkv_kernel(AttnArgs p) {
                 for (int e2 = 0; e2 < 2; ++e2) {
                     const int qt = 2 * w + e2;
                     f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                    s = mfma16(lds_row8i(Qrow, qt * 16, 0), kf0, s);
-                    s = mfma16(lds_row8i(Qrow, qt * 16, 32), kf1, s);
-                    dp = mfma16(lds_row8i(Grow, qt * 16, 0), vf0, dp);
-                    dp = mfma16(lds_row8i(Grow, qt * 16, 32), vf1, dp);
+                    s = mfma16(lds_row8i(Qrow.lo, qt * 16), kf0, s);
+                    s = mfma16(lds_row8i(Qrow.hi, qt * 16), kf1, s);
+                    dp = mfma16(lds_row8i(Grow.lo, qt * 16), vf0, dp);
+                    dp = mfma16(lds_row8i(Grow.hi, qt * 16), vf1, dp);
                     // s[e]: query qt*16 + 4g + e, key keyl
                     if constexpr (GENERIC) {
 #pragma unroll
@@ -445,20 +451,18 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dkv_kernel(AttnArgs p) {
                 const bf16x8 pa = pack8(pv), da = pack8(dsv);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    dv[dt] = mfma16(pa, lds_tr8i(Gtr, 32 * w, 32 * w + 16, dt * 16), dv[dt]);
-                    dk[dt] = mfma16(da, lds_tr8i(Qtr, 32 * w, 32 * w + 16, dt * 16), dk[dt]);
+                    dv[dt] = mfma16(lds_tr8i(Gtr.d[dt], 32 * w, 32 * w + 16), pa, dv[dt]);   // dV^T / dK^T: rows = head dims, cols = keys
+                    dk[dt] = mfma16(lds_tr8i(Qtr.d[dt], 32 * w, 32 * w + 16), da, dk[dt]);
                 }
             }
         }
+        if (kok) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int ko = kt * 16 + 4 * g + e;
-            if (ko < S) {
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    p.dK[(tok0 + ko) * p.ldd + h * HD + dt * 16 + ql] = f2bf(dk[dt][e]);
-                    p.dV[(tok0 + ko) * p.ldd + h * HD + dt * 16 + ql] = f2bf(dv[dt][e]);
-                }
+            for (int dt = 0; dt < 4; ++dt) {
+                const u32x2 wk = {pack_bf2(dk[dt][0], dk[dt][1]), pack_bf2(dk[dt][2], dk[dt][3])};
+                const u32x2 wv = {pack_bf2(dv[dt][0], dv[dt][1]), pack_bf2(dv[dt][2], dv[dt][3])};
+                *(u32x2*)(p.dK + (tok0 + keyl) * p.ldd + h * HD + dt * 16 + 4 * g) = wk;
+                *(u32x2*)(p.dV + (tok0 + keyl) * p.ldd + h * HD + dt * 16 + 4 * g) = wv;
             }
         }
     }
