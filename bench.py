@@ -53,7 +53,7 @@ class GemmTimer:
             k2 = key
             if key == "gemm_nt":   # same dispatch rule as svla_gemm_nt_bf16: big row-streaming shapes run the persistent 256x256 kernel
                 M, N, K = a[2], a[3], a[4]
-                if not kw.get("out_f32") and N % 256 == 0 and ((M + 255) // 256) * (N // 256) >= 256 and K >= 96:
+                if not kw.get("out_f32") and N % 256 == 0 and K % 64 == 0 and K >= 128 and ((M + 255) // 256) * (N // 256) >= 256:
                     k2 = "gemm_nt256"
             self.rec[k2].append((e0, e1, flops(*a, **kw)))
             return out
@@ -200,13 +200,14 @@ def main():
         executed = sum(v["flops"] for v in allk.values())
         traffic = None   # HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/, collected offline)
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"]
-            traffic = round([v for k, v in pm.items() if "gemm_nt256" in k][0]["hbm_bytes_per_launch"])
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_hbm_traffic.json")))["kernels"]
+            inst = [v for k, v in pm.items() if "gemm_nt256" in k]      # one entry per epilogue instantiation: launch-weighted mean
+            traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in inst) / sum(v["launches"] for v in inst))
         except Exception:
             pass
-        roof = {"bound": "mfma", "kernel": "gemm_nt256_bf16_kernel (svla_gemm_nt_bf16, persistent 256x256 tile)", "achieved": round(g["tflops"], 1),
+        roof = {"bound": "mfma", "kernel": "gemm_nt256k64_bf16_kernel (svla_gemm_nt_bf16, persistent 256x256 tile, BK=64)", "achieved": round(g["tflops"], 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(g["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/r01_pmc_hbm_traffic.json)",
+                "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/r01e_pmc_hbm_traffic.json; launch-weighted over the epilogue instantiations)",
                 "launches_per_update": g["launches"], "avg_launch_ms": round(g["avg_ms"], 4), "flops_per_launch": g["flops"] / max(1, g["launches"]),
                 "share_of_update": round(g["total_s"] / (ms * 1e-3), 3),
                 "other_mfma_kernels": {k: {"achieved_tflops": round(v["tflops"], 1), "launches": v["launches"], "avg_launch_ms": round(v["avg_ms"], 4),
