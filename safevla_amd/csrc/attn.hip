@@ -218,6 +218,129 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ persistent forward
+// The one-item-per-workgroup kernel above is latency-bound (stage -> barrier -> compute -> store; 1 -> 2 workgroups per CU
+// = 1.74x).  For the shape that carries > 99 % of the attention work (no mask / bias, S <= 192) a workgroup walks a list of
+// (row, head) items instead and keeps the NEXT item's K/V head slices and Q fragments in flight in registers (72 VGPRs)
+// while it computes the current item from LDS: global latency is off the critical path after the first item.
+template <int NKT>
+__global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_persist_kernel(AttnArgs p, int nitems) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SP = NKT * 16, IT = SP * 8 / ATT_THREADS, MAXQT = (NKT + 3) / 4;
+    bf16_t* Ks = (bf16_t*)smem;
+    bf16_t* Vs = Ks + SP * LDSROW;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ql = lane & 15, g = lane >> 4;
+    const int S = p.S, Sq = p.Sq, nqt = (Sq + 15) / 16;
+    u32x4 kreg[IT], vreg[IT];
+    bf16x8 qreg[MAXQT][2];
+    auto fetch = [&](int item) {
+        const int r = item / p.H, h = item % p.H;
+        const bf16_t* kp = p.K + (size_t)r * p.kv_rows * p.ld + h * HD;
+        const bf16_t* vp = p.V + (size_t)r * p.kv_rows * p.ld + h * HD;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int q = tid + i * ATT_THREADS, row = q >> 3, c = q & 7;
+            kreg[i] = u32x4{0, 0, 0, 0}; vreg[i] = u32x4{0, 0, 0, 0};
+            if (row < S) {
+                kreg[i] = *(const u32x4*)(kp + (size_t)row * p.ld + c * 8);
+                vreg[i] = *(const u32x4*)(vp + (size_t)row * p.ld + c * 8);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < MAXQT; ++t) {
+            const int q = (wid + 4 * t) * 16 + ql;
+            const bool ok = q < Sq;
+            const bf16_t* qp = p.Q + ((size_t)r * Sq + (ok ? q : 0)) * p.ldq + h * HD + 8 * g;
+            qreg[t][0] = ok ? *(const bf16x8*)qp : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            qreg[t][1] = ok ? *(const bf16x8*)(qp + 32) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    };
+    int item = blockIdx.x;
+    if (item >= nitems) return;
+    fetch(item);
+    const RowBase Krow = att_row_base(Ks, lane);
+    const TrBase Vtr = att_tr_base(Vs, lane);
+    const float sl2 = p.scale * LOG2E;      // scores are kept in the log2 domain: p = exp2(s*scale*log2e - max)
+    for (; item < nitems; item += gridDim.x) {
+        const int r = item / p.H, h = item % p.H;
+        const size_t qtok0 = (size_t)r * Sq;
+        __syncthreads();                     // every wave is done reading the previous item's K/V
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int q = tid + i * ATT_THREADS;
+            const int off = (q >> 3) * LDSROW + (((q & 7) ^ att_swz(q >> 3)) << 3);
+            *(u32x4*)(Ks + off) = kreg[i];
+            *(u32x4*)(Vs + off) = vreg[i];
+        }
+        bf16x8 qcur[MAXQT][2];
+#pragma unroll
+        for (int t = 0; t < MAXQT; ++t) { qcur[t][0] = qreg[t][0]; qcur[t][1] = qreg[t][1]; }
+        __syncthreads();
+        if (item + (int)gridDim.x < nitems) fetch(item + gridDim.x);
+#pragma unroll
+        for (int t = 0; t < MAXQT; ++t) {
+            const int qt = wid + 4 * t;
+            if (qt >= nqt) break;
+            const int q = qt * 16 + ql;
+            // raw scores stay in the MFMA result vectors; scale (> 0) and log2(e) are folded into the exp2 argument:
+            //   p = exp2(raw * sl2 - max(raw) * sl2)        (vector arithmetic so the compiler can use packed fp32 ops)
+            f32x4 sc[NKT];
+            f32x4 mx4 = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                a = mfma16(lds_row8i(Krow.lo, kt * 16), qcur[t][0], a);
+                a = mfma16(lds_row8i(Krow.hi, kt * 16), qcur[t][1], a);
+                if (kt == NKT - 1) {   // (NKT-1)*16 < S <= NKT*16 (launcher): only the last key tile is ragged
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (kt * 16 + 4 * g + e >= S) a[e] = -INFINITY;
+                }
+                sc[kt] = a;
+                mx4 = __builtin_elementwise_max(mx4, a);
+            }
+            float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float nm = -mx * sl2;
+            const f32x4 nm4 = {nm, nm, nm, nm}, sl4 = {sl2, sl2, sl2, sl2};
+            f32x4 ls4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                const f32x4 x = sc[kt] * sl4 + nm4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sc[kt][e] = __builtin_amdgcn_exp2f(x[e]);
+                ls4 += sc[kt];
+            }
+            float lsum = (ls4[0] + ls4[1]) + (ls4[2] + ls4[3]);
+            lsum += __shfl_xor(lsum, 16, 64);
+            lsum += __shfl_xor(lsum, 32, 64);
+            f32x4 o[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < NKT / 2; ++u) {
+                const float pv[8] = {sc[2 * u][0], sc[2 * u][1], sc[2 * u][2], sc[2 * u][3],
+                                     sc[2 * u + 1][0], sc[2 * u + 1][1], sc[2 * u + 1][2], sc[2 * u + 1][3]};
+                const bf16x8 pa = pack8(pv);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    o[dt] = mfma16(lds_tr8i(Vtr.d[dt], 32 * u, 32 * u + 16), pa, o[dt]);
+            }
+            const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+            if (q < Sq) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const u32x2 w = {pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv)};
+                    *(u32x2*)(p.O + (qtok0 + q) * p.ldo + h * HD + dt * 16 + 4 * g) = w;
+                }
+            }
+            if (p.LSE && g == 0 && q < Sq) p.LSE[((size_t)r * p.H + h) * Sq + q] = (mx * sl2 + __log2f(lsum)) * LN2;
+        }
+    }
+}
+
 // ================================================================================================ backward
 // Two kernels, each with only two [S,64] operands resident in LDS (2 workgroups per CU):
 //   dQ  kernel (waves own query tiles, swapped layout, K and V in LDS):   dQ = dS.K
@@ -478,6 +601,22 @@ static int launch_fwd(const AttnArgs& p, int rows, hipStream_t st) {
         attr = true;
     }
     const bool generic = p.mask_mode != MASK_NONE || p.bias || p.kvalid;
+    if constexpr (NKT == 12) {
+        if (!generic && p.S > (NKT - 1) * 16) {
+            const size_t ldsp = (size_t)2 * NKT * 16 * LDSROW * sizeof(bf16_t);
+            static int slots = 0;
+            if (!slots) {
+                int dev = 0, n_cu = 0;
+                HIP_CHECK_RET(hipGetDevice(&dev));
+                HIP_CHECK_RET(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+                HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_persist_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
+                slots = 2 * n_cu;              // 2 workgroups per CU (217 VGPRs)
+            }
+            const int nitems = rows * p.H;
+            hipLaunchKernelGGL((attn_fwd_persist_kernel<12>), dim3(nitems < slots ? nitems : slots), dim3(ATT_THREADS), ldsp, st, p, nitems);
+            return svla_launch_status();
+        }
+    }
     if (generic) hipLaunchKernelGGL((attn_fwd_kernel<NKT, true>), dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<NKT, false>), dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
     return svla_launch_status();
