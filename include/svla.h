@@ -83,14 +83,16 @@ int svla_colsum_bf16(const svla_bf16* dY, long ldy, int M, int N, int row_stride
  * Sq > 0: only the first Sq query tokens of every row are computed (Q/O/dO/dQ hold Sq rows per batch row, Q/dQ row
  * strides ldq/lddq) -- the last fusion layer only feeds sequence position 0 onwards (allenact_dino_transformer.py:708).
  * Sq = 0: all S queries, Q laid out like K/V.  kv_rows > 0 (forward only): K/V hold kv_rows token rows per batch row of
- * which the first S are used -- the llama KV cache of the acting path (llama/model.py:224-239,279-293). */
+ * which the first S are used -- the llama KV cache of the acting path (llama/model.py:224-239,279-293).
+ * Backward: D_ws = optional [rows,H,Sq] fp32 workspace; with it the dQ pass hands rowsum(dO*O) to the dK/dV pass instead of
+ * both re-reading O (null: each pass recomputes it). */
 int svla_attn_fwd_bf16(const svla_bf16* Q, const svla_bf16* K, const svla_bf16* V, long ld, svla_bf16* O, long ldo, float* LSE,
                        int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj, const float* bias,
                        const unsigned char* kvalid, int Sq, long ldq, int kv_rows, void* stream);
 int svla_attn_bwd_bf16(const svla_bf16* Q, const svla_bf16* K, const svla_bf16* V, long ld, const svla_bf16* O, long ldo,
                        const float* LSE, const svla_bf16* dO, long lddo, svla_bf16* dQ, svla_bf16* dK, svla_bf16* dV, long ldd,
                        int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj, const float* bias,
-                       const unsigned char* kvalid, int Sq, long ldq, long lddq, void* stream);
+                       const unsigned char* kvalid, int Sq, long ldq, long lddq, float* D_ws, void* stream);
 
 /* ---- observation / embedding glue ---------------------------------------------------------------------------- */
 /* (R,C,7,12) fp32 channels-first DINO features -> bf16 tokens [R, ncam, P, C] (input layout of the 1x1-conv compressor,

@@ -33,6 +33,7 @@ struct AttnArgs {
     int kv_rows;                          // K/V (dK/dV) token rows allocated per batch row (>= S; KV caches), default S
     int Sq;                               // query rows per batch row present in Q / O / dO / dQ / LSE (<= S; S = all)
     long ldq, lddq;                       // token row strides of Q and dQ (the K/V tensors use ld / ldd)
+    float* Dws;                           // [rows, H, Sq] rowsum(dO * O): written by the dQ kernel, read by the dK/dV kernel (or null)
 };
 
 // physical 16-byte chunk of logical chunk c in row r: c ^ ((r >> 1) & 7).  16 consecutive rows x one logical chunk hit 16
@@ -591,6 +592,185 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 1) attn_bwd_dkv_k
     }
 }
 
+// ------------------------------------------------------------------------------------------------ exact-tile backward
+// The fusion-encoder case (no mask / bias, (NKT-1)*16 < S <= NKT*16): every per-tile runtime predicate of the kernels above
+// disappears (they cost SGPR spills through v_readlane/v_writelane and hundreds of register moves around the partially
+// unrolled loops), the key / query pair loops are rolled, the softmax algebra is vector code (packed fp32), and
+// D = rowsum(dO * O) is computed once (dQ kernel) and handed to the dK/dV kernel through a workspace instead of re-reading O.
+template <int NKT>
+__global__ void __launch_bounds__(ATT_THREADS, 3) attn_bwd_dq_exact_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SP = NKT * 16, MAXQT = (NKT + 3) / 4;
+    bf16_t* Ks = (bf16_t*)smem;
+    bf16_t* Vs = Ks + SP * LDSROW;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const size_t tok0 = (size_t)r * p.S;
+    const int S = p.S, Sq = p.Sq;
+    stage_head<SP>(Ks, p.K + tok0 * p.ld + h * HD, p.ld, S, tid);
+    stage_head<SP>(Vs, p.V + tok0 * p.ld + h * HD, p.ld, S, tid);
+    const int ql = lane & 15, g = lane >> 4;
+    const size_t qtok0 = (size_t)r * Sq;
+    bf16x8 qall[MAXQT][4];
+    float dall[MAXQT], lall[MAXQT];
+#pragma unroll
+    for (int t = 0; t < MAXQT; ++t) {
+        const int q = (wid + 4 * t) * 16 + ql;
+        const bool qok = q < Sq;
+        const bf16_t* qp = p.Q + (qtok0 + (qok ? q : 0)) * p.ldq + h * HD + 8 * g;
+        const bf16_t* gp = p.dO + (qtok0 + (qok ? q : 0)) * p.lddo + h * HD + 8 * g;
+        const bf16_t* op = p.O + (qtok0 + (qok ? q : 0)) * p.ldo + h * HD + 8 * g;
+        qall[t][0] = gld8(qp, qok); qall[t][1] = gld8(qp + 32, qok);
+        qall[t][2] = gld8(gp, qok); qall[t][3] = gld8(gp + 32, qok);
+        dall[t] = dot8(qall[t][2], gld8(op, qok)) + dot8(qall[t][3], gld8(op + 32, qok));
+        lall[t] = qok ? p.LSE[((size_t)r * p.H + h) * Sq + q] * LOG2E : INFINITY;     // +inf => P = 0 for padded queries
+    }
+    __syncthreads();
+    const RowBase Krow = att_row_base(Ks, lane), Vrow = att_row_base(Vs, lane);
+    const TrBase Ktr = att_tr_base(Ks, lane);
+    const int ntile = (Sq + 15) / 16;
+    const float sl2 = p.scale * LOG2E;
+    const f32x4 sl4 = {sl2, sl2, sl2, sl2}, sc4 = {p.scale, p.scale, p.scale, p.scale};
+#pragma unroll
+    for (int t = 0; t < MAXQT; ++t) {
+        const int qt = wid + 4 * t;
+        if (qt < ntile) {                                   // wave-uniform
+            const int q = qt * 16 + ql;
+            const bool qok = q < Sq;
+            float D_q = dall[t];
+            D_q += __shfl_xor(D_q, 16, 64);
+            D_q += __shfl_xor(D_q, 32, 64);
+            if (p.Dws && g == 0 && qok) p.Dws[((size_t)r * p.H + h) * Sq + q] = D_q;
+            const f32x4 nl4 = {-lall[t], -lall[t], -lall[t], -lall[t]}, nd4 = {-D_q, -D_q, -D_q, -D_q};
+            f32x4 dq[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // padded keys need no mask: their K rows are zero, so their dS never reaches dQ
+#pragma unroll 2
+            for (int u = 0; u < NKT / 2; ++u) {
+                const int off = u * 32 * LDSROW;
+                float dsv[8];
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const int o2 = off + e2 * 16 * LDSROW;
+                    f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    sv = mfma16(*(const bf16x8*)(Krow.lo + o2), qall[t][0], sv);
+                    sv = mfma16(*(const bf16x8*)(Krow.hi + o2), qall[t][1], sv);
+                    dp = mfma16(*(const bf16x8*)(Vrow.lo + o2), qall[t][2], dp);
+                    dp = mfma16(*(const bf16x8*)(Vrow.hi + o2), qall[t][3], dp);
+                    const f32x4 x = sv * sl4 + nl4;
+                    f32x4 pr;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pr[e] = __builtin_amdgcn_exp2f(x[e]);
+                    const f32x4 ds = pr * (dp + nd4) * sc4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dsv[e2 * 4 + e] = ds[e];
+                }
+                const bf16x8 da = pack8(dsv);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    dq[dt] = mfma16(lds_tr8i(Ktr.d[dt] + off, 0, 16), da, dq[dt]);   // dQ^T: rows = head dims, cols = queries
+            }
+            if (qok) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const u32x2 w = {pack_bf2(dq[dt][0], dq[dt][1]), pack_bf2(dq[dt][2], dq[dt][3])};
+                    *(u32x2*)(p.dQ + (qtok0 + q) * p.lddq + h * HD + dt * 16 + 4 * g) = w;
+                }
+            }
+        }
+    }
+}
+
+template <int NKT>
+__global__ void __launch_bounds__(ATT_THREADS, 3) attn_bwd_dkv_exact_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SP = NKT * 16, MAXKT = (NKT + 3) / 4;
+    bf16_t* Qs = (bf16_t*)smem;
+    bf16_t* Gs = Qs + SP * LDSROW;  // dO
+    float* lse_s = (float*)(Gs + SP * LDSROW);
+    float* D_s = lse_s + SP;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const size_t tok0 = (size_t)r * p.S;
+    const int S = p.S, Sq = p.Sq;
+    bf16x8 kvbuf[2][4];
+    auto load_kv = [&](int t, bf16x8 (&dst)[4]) {
+        const int keyl = (wid + 4 * t) * 16 + (lane & 15);
+        const bool kok = keyl < S;
+        const bf16_t* kp = p.K + (tok0 + (kok ? keyl : 0)) * p.ld + h * HD + 8 * (lane >> 4);
+        const bf16_t* vp = p.V + (tok0 + (kok ? keyl : 0)) * p.ld + h * HD + 8 * (lane >> 4);
+        dst[0] = gld8(kp, kok); dst[1] = gld8(kp + 32, kok);
+        dst[2] = gld8(vp, kok); dst[3] = gld8(vp + 32, kok);
+    };
+    load_kv(0, kvbuf[0]);
+    const size_t qtok0 = (size_t)r * Sq;
+    stage_head<SP>(Qs, p.Q + qtok0 * p.ldq + h * HD, p.ldq, Sq, tid);
+    stage_head<SP>(Gs, p.dO + qtok0 * p.lddo + h * HD, p.lddo, Sq, tid);
+    for (int i = tid; i < SP; i += ATT_THREADS) {
+        lse_s[i] = i < Sq ? p.LSE[((size_t)r * p.H + h) * Sq + i] * LOG2E : INFINITY;   // +inf => P = 0 for padded queries
+        D_s[i] = i < Sq ? p.Dws[((size_t)r * p.H + h) * Sq + i] : 0.f;
+    }
+    __syncthreads();
+    const int ql = lane & 15, g = lane >> 4;
+    const float sl2 = p.scale * LOG2E;
+    const f32x4 sl4 = {sl2, sl2, sl2, sl2}, sc4 = {p.scale, p.scale, p.scale, p.scale};
+    const RowBase Qrow = att_row_base(Qs, lane), Grow = att_row_base(Gs, lane);
+    const TrBase Qtr = att_tr_base(Qs, lane), Gtr = att_tr_base(Gs, lane);
+    const int nw = (Sq + 31) / 32;                        // query-tile pairs holding any real query
+#pragma unroll
+    for (int t = 0; t < MAXKT; ++t) {
+        const int kt = wid + 4 * t;
+        if (kt < NKT) {                                     // all NKT key tiles are live (exact-tile launch)
+            const int keyl = kt * 16 + ql;
+            const bool kok = keyl < S;
+            if (t + 1 < MAXKT && kt + 4 < NKT) load_kv(t + 1, kvbuf[(t + 1) & 1]);
+            const bf16x8 kf0 = kvbuf[t & 1][0], kf1 = kvbuf[t & 1][1], vf0 = kvbuf[t & 1][2], vf1 = kvbuf[t & 1][3];
+            f32x4 dk[4], dv[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 2
+            for (int w = 0; w < nw; ++w) {
+                const int off = w * 32 * LDSROW;
+                float pv[8], dsv[8];
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const int o2 = off + e2 * 16 * LDSROW;
+                    f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    sv = mfma16(*(const bf16x8*)(Qrow.lo + o2), kf0, sv);
+                    sv = mfma16(*(const bf16x8*)(Qrow.hi + o2), kf1, sv);
+                    dp = mfma16(*(const bf16x8*)(Grow.lo + o2), vf0, dp);
+                    dp = mfma16(*(const bf16x8*)(Grow.hi + o2), vf1, dp);
+                    // sv[e]: query (2w+e2)*16 + 4g + e, key keyl
+                    const f32x4 l4 = *(const f32x4*)(lse_s + w * 32 + e2 * 16 + 4 * g), d4 = *(const f32x4*)(D_s + w * 32 + e2 * 16 + 4 * g);
+                    const f32x4 x = sv * sl4 - l4;
+                    f32x4 pr;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pr[e] = __builtin_amdgcn_exp2f(x[e]);
+                    const f32x4 ds = pr * (dp - d4) * sc4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { pv[e2 * 4 + e] = pr[e]; dsv[e2 * 4 + e] = ds[e]; }
+                }
+                const bf16x8 pa = pack8(pv), da = pack8(dsv);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dv[dt] = mfma16(lds_tr8i(Gtr.d[dt] + off, 0, 16), pa, dv[dt]);   // dV^T / dK^T: rows = head dims, cols = keys
+                    dk[dt] = mfma16(lds_tr8i(Qtr.d[dt] + off, 0, 16), da, dk[dt]);
+                }
+            }
+            if (kok) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const u32x2 wk = {pack_bf2(dk[dt][0], dk[dt][1]), pack_bf2(dk[dt][2], dk[dt][3])};
+                    const u32x2 wv = {pack_bf2(dv[dt][0], dv[dt][1]), pack_bf2(dv[dt][2], dv[dt][3])};
+                    *(u32x2*)(p.dK + (tok0 + keyl) * p.ldd + h * HD + dt * 16 + 4 * g) = wk;
+                    *(u32x2*)(p.dV + (tok0 + keyl) * p.ldd + h * HD + dt * 16 + 4 * g) = wv;
+                }
+            }
+        }
+    }
+}
+
 template <int NKT>
 static int launch_fwd(const AttnArgs& p, int rows, hipStream_t st) {
     const size_t lds = (size_t)2 * NKT * 16 * LDSROW * sizeof(bf16_t) + NKT * 16 * (sizeof(int) + 1);
@@ -634,6 +814,19 @@ static int launch_bwd(const AttnArgs& p, int rows, hipStream_t st) {
         attr = true;
     }
     const bool generic = p.mask_mode != MASK_NONE || p.bias || p.kvalid;
+    if constexpr (NKT <= 12) if (!generic && p.Dws && p.S > (NKT - 1) * 16) {
+        const size_t le_q = (size_t)2 * NKT * 16 * LDSROW * sizeof(bf16_t);
+        const size_t le_kv = le_q + NKT * 16 * 2 * sizeof(float);
+        static bool attr_e = false;
+        if (!attr_e) {
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_dq_exact_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)le_q));
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_dkv_exact_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)le_kv));
+            attr_e = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_dq_exact_kernel<NKT>), dim3(rows * p.H), dim3(ATT_THREADS), le_q, st, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_exact_kernel<NKT>), dim3(rows * p.H), dim3(ATT_THREADS), le_kv, st, p);
+        return svla_launch_status();
+    }
     if (generic) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<NKT, true>), dim3(rows * p.H), dim3(ATT_THREADS), lds_q, st, p);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKT, true>), dim3(rows * p.H), dim3(ATT_THREADS), lds_kv, st, p);
@@ -667,7 +860,7 @@ extern "C" int svla_attn_fwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t
 extern "C" int svla_attn_bwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t* V, long ld, const bf16_t* O, long ldo,
                                   const float* LSE, const bf16_t* dO, long lddo, bf16_t* dQ, bf16_t* dK, bf16_t* dV, long ldd,
                                   int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj,
-                                  const float* bias, const unsigned char* kvalid, int Sq, long ldq, long lddq, void* stream) {
+                                  const float* bias, const unsigned char* kvalid, int Sq, long ldq, long lddq, float* D_ws, void* stream) {
     if (head_dim != HD || rows <= 0 || S <= 0 || S > 256 || (ld % 8) || (lddo % 8) || H <= 0) return SVLA_EINVAL;
     if (mask_mode == MASK_BLOCK_CAUSAL && !traj) return SVLA_EINVAL;
     if (Sq < 0 || Sq > S || (Sq > 0 && ((ldq % 8) || (lddq % 8)))) return SVLA_EINVAL;
@@ -675,7 +868,7 @@ extern "C" int svla_attn_bwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t
     p.Sq = Sq > 0 ? Sq : S; p.ldq = Sq > 0 ? ldq : ld; p.lddq = Sq > 0 ? lddq : ldd; p.kv_rows = S;
     p.Q = Q; p.K = K; p.V = V; p.ld = ld; p.O = (bf16_t*)O; p.ldo = ldo; p.LSE = (float*)LSE; p.dO = dO; p.lddo = lddo;
     p.dQ = dQ; p.dK = dK; p.dV = dV; p.ldd = ldd; p.traj = traj; p.bias = bias; p.kvalid = kvalid;
-    p.S = S; p.H = H; p.mask_mode = mask_mode; p.scale = scale;
+    p.S = S; p.H = H; p.mask_mode = mask_mode; p.scale = scale; p.Dws = D_ws;
     hipStream_t st = (hipStream_t)stream;
     if (S <= 64) return launch_bwd<4>(p, rows, st);
     if (S <= 128) return launch_bwd<8>(p, rows, st);

@@ -156,9 +156,11 @@ def attn_fwd(q, k, v, ld, rows, S, H, scale, out=None, ldo=None, mask_mode=MASK_
 
 
 def attn_bwd(q, k, v, ld, o, ldo, lse, do, lddo, dq, dk, dv, ldd, rows, S, H, scale, mask_mode=MASK_NONE, traj=None,
-             bias=None, kvalid=None, Sq=0, ldq=0, lddq=0):
+             bias=None, kvalid=None, Sq=0, ldq=0, lddq=0, d_ws=None):
+    if d_ws is None:   # [rows, H, Sq] fp32 workspace: rowsum(dO * O), handed from the dQ kernel to the dK/dV kernel
+        d_ws = torch.empty(rows * H * (Sq or S), device=q.device, dtype=F32)
     lib().call("svla_attn_bwd_bf16", _p(q), _p(k), _p(v), ld, _p(o), ldo, _p(lse), _p(do), lddo, _p(dq), _p(dk), _p(dv), ldd,
-               rows, S, H, 64, float(scale), mask_mode, _p(traj), _p(bias), _p(kvalid), int(Sq), int(ldq), int(lddq), _stream())
+               rows, S, H, 64, float(scale), mask_mode, _p(traj), _p(bias), _p(kvalid), int(Sq), int(ldq), int(lddq), _p(d_ws), _stream())
 
 
 # ------------------------------------------------------------------------------------------------ glue
