@@ -86,6 +86,39 @@ class GemmTimer:
         return out
 
 
+def acting_bench(model, st, B, dev, n=24):
+    """Secondary number ("report separately the rollout-time throughput"): the acting path that precedes the update --
+    frozen DINOv2 ViT on 2 uint8 frames per env step + single-step 3-tower forward with the llama KV caches."""
+    from safevla_amd.preproc import DinoViTPreprocessor
+
+    for t in model.towers:
+        t.time_step_counter, t._kv = 0, None
+    step_in = lambda t: ({k: v[t:t + 1] for k, v in st.observations.items()}, None, st.prev_actions[t:t + 1], st.masks[t:t + 1])
+    with torch.no_grad():
+        for t in range(4):
+            model(*step_in(t))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(4, 4 + n):
+            model(*step_in(t))
+        torch.cuda.synchronize()
+        pol = n * B / (time.perf_counter() - t0)
+    for t in model.towers:
+        t.time_step_counter, t._kv = 0, None
+    vit = DinoViTPreprocessor("rgb_raw", "rgb_dinov2", device=dev)
+    fr = torch.randint(0, 256, (2 * B, 224, 384, 3), device=dev, dtype=torch.uint8)
+    vit.process({"rgb_raw": fr})
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        vit.process({"rgb_raw": fr})
+    torch.cuda.synchronize()
+    fps = 3 * 2 * B / (time.perf_counter() - t0)
+    return {"policy_single_step_env_steps_per_s": round(pol, 1), "vit_frames_per_s": round(fps, 1),
+            "acting_env_steps_per_s": round(1.0 / (1.0 / pol + 2.0 / fps), 1), "envs": B,
+            "note": "per env step: 2 frames (224x384) through DINOv2 ViT-S/14 + one KV-cached 3-tower step; synthetic frames"}
+
+
 def cpu_baseline(T=32, B=8, L=12):
     """fp32 CPU port (oracle) of the same update on a bounded sample: one epoch = 3-tower forward, SafePPOLogGrad +
     SafePPOValue, backward, clip 0.5, Adam; env-steps/s = T*B / (4 epochs)."""
@@ -215,6 +248,9 @@ def main():
                 "executed_mfma_tflop_per_update": round(executed / 1e12, 1),
                 "executed_mfma_tflops_sustained": round(executed / (ms * 1e-3) / 1e12, 1)}
     cpu = None
+    acting = None
+    if rank == 0 and world == 1 and not args.no_roofline:
+        acting = acting_bench(model, st, B, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(L=args.L)
     if rank == 0:
@@ -229,7 +265,7 @@ def main():
                "note": "reference_equivalent counts SURVEY 8(d) FLOPs of the reference's schedule; the engine executes fewer (last fusion "
                        "layer only for the consumed token, T5 once per unique goal) -- see roofline.executed_mfma_*",
                "loss": {k: (round(v, 5) if isinstance(v, float) else v) for k, v in info.items()},
-               "roofline": roof, "cpu_baseline": cpu}
+               "roofline": roof, "cpu_baseline": cpu, "acting": acting}
         print(json.dumps(out), flush=True)
 
 

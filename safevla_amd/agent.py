@@ -1,0 +1,149 @@
+"""Evaluation / rollout-time agent on the MI355X acting path.
+
+Mirrors ``InferenceAgentVIDA`` (/root/reference/architecture/models/allenact_transformer_models/inference_agent.py:74-296) behind
+``AbstractAgent`` (/root/reference/architecture/agent.py:5-51): ``reset()``, ``get_action_list()`` and
+``get_action(frame, goal_spec) -> (action_str, action_probs)``.  One call = uint8 frames -> frozen DINOv2 ViT preprocessor
+(``preproc.DinoViTPreprocessor``) -> single-step 3-tower forward with per-tower llama KV caches (``model`` acting path) ->
+sample / mode.  The rollout storage is used exactly as the reference uses it (``initialize`` on the first step of a task, ``add``
+with dummy value/reward fields afterwards, ``agent_input_for_next_step``), so the prev-action / mask / time-step plumbing is the
+update path's own.
+"""
+import json
+import os
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import checkpoint
+from .preproc import DinoViTPreprocessor
+from .storage import RolloutStorage
+from .text import str_to_bytes
+
+# Stretch action vocabulary in the order of the policy head (utils/constants/stretch_initialization_utils.py:145-166,
+# short names utils/type_utils.py:55-74; the ACTION_DICT / LONG_ACTION_NAME environment overrides are honoured like upstream)
+ALL_STRETCH_ACTIONS = ["m", "r", "l", "b", "end", "sub_done", "ls", "rs", "p", "zm", "zp", "yp", "ym", "wp", "wm", "yms", "zms",
+                       "zps", "yps", "d"]
+STRETCH_LONG_NAMES = {"m": "move_ahead", "r": "rotate_right", "l": "rotate_left", "b": "move_back", "end": "done",
+                      "sub_done": "sub_done", "ls": "rotate_left_small", "rs": "rotate_right_small", "p": "pickup",
+                      "zm": "move_arm_in", "zp": "move_arm_out", "yp": "move_arm_up", "ym": "move_arm_down", "wp": "wrist_open",
+                      "wm": "wrist_close", "yms": "move_arm_down_small", "zms": "move_arm_in_small", "zps": "move_arm_out_small",
+                      "yps": "move_arm_up_small", "d": "dropoff"}
+
+
+class AbstractAgent:
+    def reset(self) -> None:
+        raise NotImplementedError
+
+    def get_action_list(self) -> List[str]:
+        raise NotImplementedError
+
+    def get_action(self, observations: Dict[str, Any], goal: str) -> Tuple[str, Any]:
+        raise NotImplementedError
+
+
+class InferenceAgentVIDA(AbstractAgent):
+    num_evaluated_traj = 0
+
+    def __init__(self, actor_critic, device="cuda", greedy_sampling: bool = False, nav_preprocessor=None, manip_preprocessor=None,
+                 steps_before_rollout_refresh: int = 64, generator: Optional[torch.Generator] = None):
+        self.actor_critic = actor_critic
+        self.device = torch.device(device)
+        self.greedy_sampling = greedy_sampling
+        u = actor_critic.uuids
+        self.nav_pre = nav_preprocessor or DinoViTPreprocessor("rgb_raw", u["nav"], device=device)
+        self.manip_pre = manip_preprocessor or DinoViTPreprocessor("manipulation_rgb_raw", u["manip"], device=device)
+        if manip_preprocessor is None and nav_preprocessor is None:
+            self.manip_pre.vit = self.nav_pre.vit            # one frozen ViT serves both cameras
+        self.steps_before_rollout_refresh = steps_before_rollout_refresh
+        self.rollout_storage = RolloutStorage(steps_before_rollout_refresh, device=device, store_tokens=True,
+                                              nav_uuid=u["nav"], manip_uuid=u["manip"])
+        self.generator = generator
+        self.has_initialized = False
+        self.memory = None
+        self.steps_taken_in_task = 0
+        self.last_action_flat = None
+
+    @classmethod
+    def build_agent(cls, actor_critic, device="cuda", greedy_sampling: bool = False, ckpt_path: Optional[str] = None, **kw):
+        """ckpt formats auto-detected like upstream (:128-165): Lightning ``state_dict`` (IL), AllenAct ``model_state_dict``, or a
+        bare state dict."""
+        if ckpt_path is not None:
+            ckpt = torch.load(ckpt_path, map_location="cpu")
+            if "state_dict" in ckpt:
+                checkpoint.load_pl_ckpt_allenact(actor_critic, ckpt["state_dict"])
+                actor_critic.sync_weights()
+            elif "model_state_dict" in ckpt:
+                actor_critic.load_state_dict(ckpt["model_state_dict"], strict=False)
+            elif any(k.startswith(("visual_encoder.", "actor.", "decoder.")) for k in ckpt):
+                actor_critic.load_state_dict(ckpt, strict=False)
+            else:
+                raise ValueError(f"Unknown checkpoint format; found keys {list(ckpt.keys())[:10]}")
+        agent = cls(actor_critic, device=device, greedy_sampling=greedy_sampling, **kw)
+        agent.reset()
+        return agent
+
+    # ---- AbstractAgent ------------------------------------------------------------------------------------------------------
+    def reset(self):
+        if self.has_initialized:
+            self.rollout_storage.after_updates()
+        self.steps_taken_in_task = 0
+        type(self).num_evaluated_traj += 1
+        self.traj_index = type(self).num_evaluated_traj
+        self.memory = None
+
+    def get_action_list(self) -> List[str]:
+        if os.getenv("ACTION_DICT") is not None:
+            return list(json.load(open(os.getenv("ACTION_DICT"), "r")).keys())
+        if os.getenv("LONG_ACTION_NAME") is not None and bool(int(os.getenv("LONG_ACTION_NAME"))):
+            return [STRETCH_LONG_NAMES[a] for a in ALL_STRETCH_ACTIONS]
+        return list(ALL_STRETCH_ACTIONS)
+
+    def get_action(self, frame: Dict[str, Any], goal_spec: str) -> Tuple[str, torch.Tensor]:
+        observations = {"rgb_raw": frame["raw_navigation_camera"], "natural_language_spec": str_to_bytes(goal_spec, 1000),
+                        "time_step": self.steps_taken_in_task, "traj_index": self.traj_index}
+        if "raw_manipulation_camera" in frame:
+            observations["manipulation_rgb_raw"] = frame["raw_manipulation_camera"]
+        if "an_object_is_in_hand" in frame:
+            observations["an_object_is_in_hand"] = frame["an_object_is_in_hand"]
+        return self.act(observations, goal_spec)
+
+    # ---- one acting step ----------------------------------------------------------------------------------------------------
+    def _batch(self, observations: Dict[str, Any]) -> Dict[str, torch.Tensor]:
+        dev, u = self.device, self.actor_critic.uuids
+        as_u8 = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(dev).reshape((1,) + tuple(np.shape(a)))
+        nav = as_u8(observations["rgb_raw"])
+        manip = as_u8(observations["manipulation_rgb_raw"]) if "manipulation_rgb_raw" in observations else torch.zeros_like(nav)
+        return {
+            u["nav"]: self.nav_pre.process({"rgb_raw": nav}),
+            u["manip"]: self.manip_pre.process({"manipulation_rgb_raw": manip}),
+            u["goal"]: torch.as_tensor(np.asarray(observations["natural_language_spec"], dtype=np.uint8)).to(dev).reshape(1, -1),
+            u["time"]: torch.tensor([int(observations["time_step"])], device=dev, dtype=torch.int64),
+            u["traj"]: torch.tensor([int(observations["traj_index"])], device=dev, dtype=torch.int64),
+            u["hand"]: torch.tensor([int(np.asarray(observations.get("an_object_is_in_hand", 0)).reshape(-1)[0])], device=dev, dtype=torch.int64),
+        }
+
+    @torch.no_grad()
+    def act(self, observations: Dict[str, Any], goal_spec: str = "") -> Tuple[str, torch.Tensor]:
+        obs_batch = self._batch(observations)
+        st = self.rollout_storage
+        if self.steps_taken_in_task == 0:
+            self.has_initialized = True
+            st.initialize(observations=obs_batch, num_samplers=1,
+                          recurrent_memory_specification=self.actor_critic.recurrent_memory_specification, action_space=None)
+            st.after_updates()
+        else:
+            dummy = torch.zeros((1, 1), device=self.device)
+            st.add(observations=obs_batch, memory=self.memory, actions=self.last_action_flat, action_log_probs=dummy,
+                   value_preds=dummy, rewards=dummy, costs=dummy, c_value_preds=dummy,
+                   masks=torch.ones((1, 1), device=self.device))   # always 1: a single task until ``reset``
+        aco, self.memory = self.actor_critic(**st.agent_input_for_next_step())
+        action = aco.distributions.sample(generator=self.generator)
+        action_greedy = aco.distributions.mode()
+        self.last_action_flat = action.reshape(1)                   # the stored previous action is always the stochastic one
+        self.steps_taken_in_task += 1
+        if st.step == st.T:
+            st.after_updates()
+        names = self.get_action_list()
+        chosen = action_greedy if self.greedy_sampling else action
+        return names[int(chosen.reshape(-1)[0])], aco.distributions.probs[0][0]

@@ -51,3 +51,16 @@ def test_categorical_distr_matches_torch():
     a = torch.randint(0, 20, (5, 3))
     assert torch.allclose(d.log_prob(a), t.log_prob(a), atol=1e-6) and torch.allclose(d.entropy(), t.entropy(), atol=1e-6)
     assert d.sample().shape == (5, 3) and torch.equal(d.mode(), lg.argmax(-1))
+
+
+def test_agent_action_vocabulary(monkeypatch):
+    """Stretch action list of the evaluation agent: order of the policy head (stretch_initialization_utils.py:145-166), long-name
+    override like upstream."""
+    from safevla_amd import agent
+    a = agent.InferenceAgentVIDA.__new__(agent.InferenceAgentVIDA)
+    monkeypatch.delenv("ACTION_DICT", raising=False)
+    monkeypatch.delenv("LONG_ACTION_NAME", raising=False)
+    names = a.get_action_list()
+    assert len(names) == 20 and len(set(names)) == 20 and names[:5] == ["m", "r", "l", "b", "end"] and names[-1] == "d"
+    monkeypatch.setenv("LONG_ACTION_NAME", "1")
+    assert a.get_action_list()[:3] == ["move_ahead", "rotate_right", "rotate_left"]
