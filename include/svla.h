@@ -62,10 +62,14 @@ int svla_norm_bwd_bf16(const svla_bf16* dy, int dyG, int dyGS, int dyOFF, const 
 /* ---- GEMMs (MFMA bf16, fp32 accumulate) --------------------------------------------------------------------- */
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear / 1x1 nn.Conv2d of the policy
  * (allenact_dino_transformer.py:509-552; llama/model.py:203-222,355-357,437) and, with transposed weights, their input
- * gradients.  act: 0 none, 1 ReLU, 2 GELU(erf).  relu_mask: zero outputs where mask <= 0.  N % 128 == 0, K % 64 == 0. */
+ * gradients.  act: 0 none, 1 ReLU, 2 GELU(erf).  relu_mask: zero outputs where mask <= 0.  N % 128 == 0, K % 64 == 0.
+ * relu_bits_out (act == 1 only): additionally write the sign bits of the output, ceil(M/32)*32 * N/8 bytes in an opaque blocked
+ * layout ([M/32][N/64][32 rows][8 bytes], N % 64 == 0; SVLA_RELU_BITS_BYTES); relu_bits: the same mask as relu_mask, given as those bits (the ReLU derivative of nn.TransformerEncoderLayer's
+ * feed-forward, allenact_dino_transformer.py:545-552, without re-reading the 2048-wide activation). */
+#define SVLA_RELU_BITS_BYTES(M, N) ((((long)(M) + 31) / 32) * 32 * ((long)(N) / 8))
 int svla_gemm_nt_bf16(const svla_bf16* A, long lda, const svla_bf16* B, long ldb, const float* bias, const svla_bf16* residual,
                       long ldr, const svla_bf16* relu_mask, long ldm, void* C, long ldc, int M, int N, int K, int act,
-                      int out_f32, float alpha, void* stream);
+                      int out_f32, float alpha, unsigned char* relu_bits_out, const unsigned char* relu_bits, void* stream);
 /* Test hook: force the 128x128-tile kernel even where the 256x256 one would be chosen (same cited layers). */
 int svla_gemm_force_small_tile(int on);
 /* dW[N,K] (fp32) += dY[M,N]^T . X[M,K]: weight gradients (autograd of the same layers); optional fused bias gradient

@@ -41,8 +41,14 @@ struct GemmNtArgs {
     void* C; long ldc;
     int M, N, K, act, out_f32;
     float alpha;
+    unsigned char* bits_out;          // act == ReLU: also write the output's sign bits (blocked layout, see relu_bits_word)
+    const unsigned char* bits_in;     // ReLU mask given as such bits instead of a bf16 activation tensor (relu_mask)
     int dbg;          // timing-only ablations of the 256-tile kernel (tools/ab_gemm.py): 1 = no C stores, 2 = no epilogue
 };
+
+// ReLU sign bits live in a kernel-private blocked layout: [ceil(M/32)][N/64][32 rows][8 bytes]: the 64 bits of (row m, 64-column
+// group) are one 8-byte word and a 32-row x 64-column slab (one wave's epilogue unit in the 256-tile kernel) is 256 contiguous bytes
+__device__ __forceinline__ size_t relu_bits_word(int m, int n, int N) { return ((size_t)(m >> 5) * (N >> 6) + (n >> 6)) * 256 + (size_t)(m & 31) * 8; }
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
@@ -116,6 +122,16 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p)
         for (int j = 0; j < 8; ++j) {
             const int m = min(m0 + ((tid + NTHREADS * j) >> 4), p.M - 1);
             emask[j] = *(const u32x4*)(p.relu_mask + (size_t)m * p.ldm + n0 + ecc * 8);
+        }
+    }
+    unsigned ebits = 0;       // 8 rows x 8 mask bits
+    unsigned ebits_hi = 0;
+    if (!p.out_f32 && p.bits_in) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = min(m0 + ((tid + NTHREADS * j) >> 4), p.M - 1);
+            const unsigned b = p.bits_in[relu_bits_word(m, n0 + ecc * 8, p.N) + (((n0 + ecc * 8) & 63) >> 3)];
+            if (j < 4) ebits |= b << (8 * j); else ebits_hi |= b << (8 * (j - 4));
         }
     }
 
@@ -216,6 +232,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p)
         const f32x4 a = *(const f32x4*)(Cs + row * CS + ecc * 8), b = *(const f32x4*)(Cs + row * CS + ecc * 8 + 4);
         float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
         u32x4 w;
+        unsigned obits = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float lo = v[2 * e] + ebias[2 * e], hi = v[2 * e + 1] + ebias[2 * e + 1];
@@ -225,10 +242,18 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p)
                 if (!(bf_lo(emask[j][e]) > 0.f)) lo = 0.f;
                 if (!(bf_hi(emask[j][e]) > 0.f)) hi = 0.f;
             }
+            if (p.bits_in) {
+                const unsigned b = ((j < 4 ? ebits : ebits_hi) >> (8 * (j & 3))) & 0xffu;
+                if (!((b >> (2 * e)) & 1u)) lo = 0.f;
+                if (!((b >> (2 * e + 1)) & 1u)) hi = 0.f;
+            }
             if (p.residual) { lo += bf_lo(eres[j][e]); hi += bf_hi(eres[j][e]); }
             w[e] = pack_bf2(lo, hi);
+            if (lo > 0.f) obits |= 1u << (2 * e);
+            if (hi > 0.f) obits |= 2u << (2 * e);
         }
         *(u32x4*)(C + (size_t)m * p.ldc + n0 + ecc * 8) = w;
+        if (p.bits_out) p.bits_out[relu_bits_word(m, n0 + ecc * 8, p.N) + (((n0 + ecc * 8) & 63) >> 3)] = (unsigned char)obits;
     }
 }
 
@@ -317,7 +342,7 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
     f32x16 acc[4][2];
     const int fr = lane & 31, fh = lane >> 5;
     bf16_t* C = (bf16_t*)p.C;
-    constexpr bool HAS_RES = (AUX & 1) != 0, HAS_MASK = (AUX & 2) != 0;
+    constexpr bool HAS_RES = (AUX & 1) != 0, HAS_MASK = (AUX & 2) != 0, HAS_BITS = AUX == 4, LDS_AUX = HAS_RES || HAS_MASK;
     const bf16_t* aux = HAS_RES ? p.residual : (HAS_MASK ? p.relu_mask : nullptr);
     const long ldaux = HAS_RES ? p.ldr : p.ldm;
     // the residual / mask slab is fetched row-major (8 full 128-byte lines per instruction), one slab ahead, and turned into the
@@ -329,6 +354,13 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
             const int mr = min(tm0 + wm * 128 + i * 32 + it * 8 + (lane >> 3), p.M - 1);
             buf[it] = *(const u32x4*)(aux + (size_t)mr * ldaux + tn0 + wn * 64 + (lane & 7) * 8);
         }
+    };
+    // AUX == 4: the ReLU mask as 1 bit per element ([M, N/8] bytes): the 64 bits of this lane's slab row are ONE 8-byte load in
+    // the accumulator layout -- no LDS round trip, 16x fewer mask bytes than a bf16 activation tensor
+    u32x2 mbits[2];
+    auto load_bits = [&](int i, u32x2& dst, int tm0, int tn0) {
+        const int mc = min(tm0 + wm * 128 + i * 32 + fr, p.M - 1);
+        dst = *(const u32x2*)(p.bits_in + relu_bits_word(mc, tn0 + wn * 64, p.N));
     };
     // epilogue staging (wave-private 4 KiB): write (row fr, 8-byte piece), read (row lane>>3 [+8 it], 16-byte chunk lane&7)
     char* Es = smem + (size_t)NS64 * 512 * BK64 * 2 + (size_t)__builtin_amdgcn_readfirstlane(wid) * 4096;
@@ -355,7 +387,8 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
             }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (AUX != 0 && kt == nk - 1) load_aux(0, auxrm[0], m0, n0);
+            if (LDS_AUX && kt == nk - 1) load_aux(0, auxrm[0], m0, n0);
+            if (HAS_BITS && kt == nk - 1) load_bits(0, mbits[0], m0, n0);
             issue_next();
             const int st = g % NS64;
             const bf16_t* Ab = As + st * 256 * BK64;
@@ -396,12 +429,14 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + wm * 128 + i * 32 + fr;
                 const int mc = min(m, p.M - 1);
-                if (AUX != 0 && i + 1 < 4) load_aux(i + 1, auxrm[(i + 1) & 1], m0, n0);
-                if (AUX != 0) {
+                if (LDS_AUX && i + 1 < 4) load_aux(i + 1, auxrm[(i + 1) & 1], m0, n0);
+                if (HAS_BITS && i + 1 < 4) load_bits(i + 1, mbits[(i + 1) & 1], m0, n0);
+                if (LDS_AUX) {
 #pragma unroll
                     for (int it = 0; it < 4; ++it) *(u32x4*)(Es + it * 1024 + e_rd) = auxrm[i & 1][it];
                     __builtin_amdgcn_wave_barrier();
                 }
+                unsigned obw[2] = {0u, 0u};       // sign bits of this lane's 2 x 16 outputs, at their column positions
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int nb = n0 + wn * 64 + j * 32;
@@ -423,6 +458,12 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
                             if (!(bf_lo(mk[1]) > 0.f)) v[2] = 0.f;
                             if (!(bf_hi(mk[1]) > 0.f)) v[3] = 0.f;
                         }
+                        if (HAS_BITS) {
+                            const unsigned nib = mbits[i & 1][j] >> (8 * rg + 4 * fh);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (!((nib >> e) & 1u)) v[e] = 0.f;
+                        }
                         if (HAS_RES) {
                             const u32x2 rs = *(const u32x2*)(Es + e_wr + (((j * 4 + rg) ^ e_sw) << 4));
                             v[0] += bf_lo(rs[0]); v[1] += bf_hi(rs[0]); v[2] += bf_lo(rs[1]); v[3] += bf_hi(rs[1]);
@@ -430,6 +471,11 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
                         pk[rg][0] = pack_bf2(v[0], v[1]);
                         pk[rg][1] = pack_bf2(v[2], v[3]);
                         *(u32x2*)(Es + e_wr + (((j * 4 + rg) ^ e_sw) << 4)) = pk[rg];
+                        if (ACT == ACT_RELU && AUX == 0) {   // outputs are >= 0: "positive" == non-zero magnitude bits of the rounded value
+                            const unsigned nib = ((pk[rg][0] & 0x7fffu) ? 1u : 0u) | ((pk[rg][0] & 0x7fff0000u) ? 2u : 0u) |
+                                                 ((pk[rg][1] & 0x7fffu) ? 4u : 0u) | ((pk[rg][1] & 0x7fff0000u) ? 8u : 0u);
+                            obw[j] |= nib << (8 * rg + 4 * fh);
+                        }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -439,6 +485,14 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
                     const int mr = m0 + wm * 128 + i * 32 + it * 8 + (lane >> 3);
                     if (p.dbg & 1) { asm volatile("" ::"v"(w)); }
                     else if (mr < p.M) *(u32x4*)(C + (size_t)mr * p.ldc + n0 + wn * 64 + (lane & 7) * 8) = w;
+                }
+                if (ACT == ACT_RELU && AUX == 0 && p.bits_out) {
+                    // lanes fr and fr+32 hold the two interleaved nibble sets of row fr: merge, then ONE 8-byte store per row (store
+                    // instructions, not bytes, are what the CU's store path charges for)
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(obw[0], obw[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(obw[1], obw[1], false, false);
+                    const u32x2 ob = {obw[0] | s0[1], obw[1] | s1[1]};
+                    if (fh == 0 && m < p.M) *(u32x2*)(p.bits_out + relu_bits_word(m, n0 + wn * 64, p.N)) = ob;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -460,6 +514,7 @@ static int launch_nt256_inst(const GemmNtArgs& p, int grid, hipStream_t stream) 
 }
 static int launch_nt256(const GemmNtArgs& p, int grid, hipStream_t stream) {
     const int aux = (p.residual ? 1 : 0) | (p.relu_mask ? 2 : 0);
+    if (p.bits_in) return p.act == ACT_NONE ? launch_nt256_inst<0, 4>(p, grid, stream) : SVLA_EINVAL;
     switch (p.act * 4 + aux) {
         case 0: return launch_nt256_inst<0, 0>(p, grid, stream);
         case 1: return launch_nt256_inst<0, 1>(p, grid, stream);
@@ -487,11 +542,13 @@ extern "C" int svla_gemm_force_small_tile(int on) {
 
 extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, long ldb, const float* bias,
                                  const bf16_t* residual, long ldr, const bf16_t* relu_mask, long ldm, void* C, long ldc,
-                                 int M, int N, int K, int act, int out_f32, float alpha, void* stream) {
+                                 int M, int N, int K, int act, int out_f32, float alpha, unsigned char* relu_bits_out,
+                                 const unsigned char* relu_bits, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || (N % BN) || (K % BK)) return SVLA_EINVAL;
+    if ((relu_bits && (relu_mask || residual || out_f32)) || (relu_bits_out && (act != ACT_RELU || out_f32 || residual || relu_mask || relu_bits))) return SVLA_EINVAL;
     if (act < ACT_NONE || act > ACT_GELU) return SVLA_EINVAL;
     if ((lda % 8) || (ldb % 8) || (ldc % (out_f32 ? 4 : 8)) || (residual && (ldr % 8)) || (relu_mask && (ldm % 8))) return SVLA_EINVAL;
-    GemmNtArgs p{A, lda, B, ldb, bias, residual, ldr, relu_mask, ldm, C, ldc, M, N, K, act, out_f32, alpha, g_dbg};
+    GemmNtArgs p{A, lda, B, ldb, bias, residual, ldr, relu_mask, ldm, C, ldc, M, N, K, act, out_f32, alpha, relu_bits_out, relu_bits, g_dbg};
     if (!out_f32 && (N % 256) == 0 && (K % BK64) == 0 && K >= 2 * BK64 && (long)((M + 255) / 256) * (N / 256) >= 256 && !g_force_small_tile) {
         static int n_cu = 0;
         if (!n_cu) {

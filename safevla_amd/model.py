@@ -266,11 +266,13 @@ class Tower(nn.Module):
             ao, lse = ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, R, S, 8, 0.125, save_lse=need_grad)
             h1 = ops.gemm_nt(ao, w[f"f{i}.out"], M, D, D, bias=l.self_attn.out_proj.bias, residual=xf)
             x1, m1, r1 = ops.norm_fwd(h1, l.norm1.weight, l.norm1.bias, 1e-5, M, save_stats=need_grad)
-            f1 = ops.gemm_nt(x1, w[f"f{i}.l1"], M, 2048, D, bias=l.linear1.bias, act=ops.ACT_RELU)
+            # the ReLU derivative is kept as 1 bit per element (M x 256 bytes): the input-gradient GEMM then reads 16x fewer mask bytes
+            f1b = torch.empty(ops.relu_bits_bytes(M, 2048), device=x1.device, dtype=torch.uint8) if need_grad else None
+            f1 = ops.gemm_nt(x1, w[f"f{i}.l1"], M, 2048, D, bias=l.linear1.bias, act=ops.ACT_RELU, relu_bits_out=f1b)
             h2 = ops.gemm_nt(f1, w[f"f{i}.l2"], M, D, 2048, bias=l.linear2.bias, residual=x1)
             xo, m2, r2 = ops.norm_fwd(h2, l.norm2.weight, l.norm2.bias, 1e-5, M, save_stats=need_grad)
             if need_grad:
-                fl.append(dict(pruned=False, x=xf, qkv=qkv, ao=ao, lse=lse, h1=h1, x1=x1, n1=(m1, r1), f1=f1, h2=h2, n2=(m2, r2)))
+                fl.append(dict(pruned=False, x=xf, qkv=qkv, ao=ao, lse=lse, h1=h1, x1=x1, n1=(m1, r1), f1=f1, f1b=f1b, h2=h2, n2=(m2, r2)))
             xf = xo
         c["fusion"] = fl
         # decoder over the rollout time axis, rows (b*T + t)
@@ -399,7 +401,7 @@ class Tower(nn.Module):
                 continue
             dh2 = ops.norm_bwd(dyf, a["h2"], l.norm2.weight, l.norm2.bias, a["n2"][0], a["n2"][1], M, g(l.norm2.weight), g(l.norm2.bias))
             ops.gemm_tn_acc(dh2, a["f1"], dw[f"f{i}.l2"], M, D, 2048, db=g(l.linear2.bias))
-            df1 = ops.gemm_nt(dh2, wt[f"f{i}.l2"], M, 2048, D, relu_mask=a["f1"])
+            df1 = ops.gemm_nt(dh2, wt[f"f{i}.l2"], M, 2048, D, relu_bits=a["f1b"])
             ops.gemm_tn_acc(df1, a["x1"], dw[f"f{i}.l1"], M, 2048, D, db=g(l.linear1.bias))
             dx1 = ops.gemm_nt(df1, wt[f"f{i}.l1"], M, D, 2048, residual=dh2)
             del df1

@@ -107,7 +107,7 @@ def norm_bwd(dy, x, gamma, beta, mean, rstd, rows, dgamma, dbeta, D=512, rms=Fal
 
 # ------------------------------------------------------------------------------------------------ GEMMs
 def gemm_nt(A, B, M, N, K, bias=None, residual=None, relu_mask=None, act=ACT_NONE, out=None, out_f32=False, alpha=1.0,
-            lda=None, ldb=None, ldc=None, ldr=None, ldm=None):
+            lda=None, ldb=None, ldc=None, ldr=None, ldm=None, relu_bits_out=None, relu_bits=None):
     """out[M,N] = epi(alpha * A[M,K] @ B[N,K]^T).  A/B bf16; leading dims default to the last-dim stride of 2-D views."""
     _chk(A, BF16, "A")
     _chk(B, BF16, "B")
@@ -119,8 +119,13 @@ def gemm_nt(A, B, M, N, K, bias=None, residual=None, relu_mask=None, act=ACT_NON
     ldr = ldr if ldr is not None else (residual.stride(-2) if residual is not None else 0)
     ldm = ldm if ldm is not None else (relu_mask.stride(-2) if relu_mask is not None else 0)
     lib().call("svla_gemm_nt_bf16", _p(A), lda, _p(B), ldb, _p(bias), _p(residual), ldr, _p(relu_mask), ldm, _p(out), ldc, M, N, K,
-               int(act), int(out_f32), float(alpha), _stream())
+               int(act), int(out_f32), float(alpha), _p(relu_bits_out), _p(relu_bits), _stream())
     return out
+
+
+def relu_bits_bytes(M: int, N: int) -> int:
+    """Size of the opaque ReLU sign-bit buffer of gemm_nt(..., relu_bits_out=) (SVLA_RELU_BITS_BYTES in svla.h)."""
+    return ((M + 31) // 32) * 32 * (N // 8)
 
 
 def gemm_force_small_tile(on: bool):

@@ -469,3 +469,31 @@ def test_adam_clip_matches_torch(ops):
         ops.adam_step(p, gd, m, v, pb, 2e-5, i + 1, gnorm_sq=ss, max_norm=0.5)
     close(p, pt.data, 1e-6, 1e-7, "adam p")
     assert torch.equal(pb.float().cpu(), bf(p.cpu()))
+
+
+@pytest.mark.parametrize("M,force_small", [(700, True), (256 * 300 + 77, False)])
+def test_gemm_nt_relu_bit_mask_roundtrip(ops, M, force_small):
+    """relu_bits_out of a ReLU GEMM == (output > 0) packed LSB-first, and relu_bits masks exactly like relu_mask=<that output>."""
+    torch.manual_seed(3)
+    N, K = 512, 256
+    A = torch.randn(M, K, device=DEV).to(torch.bfloat16); B = (torch.randn(N, K, device=DEV) * 0.1).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV) * 0.1
+    ops.gemm_force_small_tile(force_small)
+    try:
+        bits = torch.zeros(ops.relu_bits_bytes(M, N), device=DEV, dtype=torch.uint8)
+        y = ops.gemm_nt(A, B, M, N, K, bias=bias, act=ops.ACT_RELU, relu_bits_out=bits)
+        want = (y.float() > 0).view(M, N // 8, 8).to(torch.int32)
+        packed = (want << torch.arange(8, device=DEV, dtype=torch.int32)).sum(-1).to(torch.uint8)       # [M, N/8] row-major
+        MP = (M + 31) // 32 * 32                                                                       # -> blocked [M/32][N/64][32][8]
+        pad = torch.zeros(MP, N // 8, device=DEV, dtype=torch.uint8); pad[:M] = packed
+        blocked = pad.view(MP // 32, 32, N // 64, 8).permute(0, 2, 1, 3).reshape(-1)
+        valid = torch.zeros(MP, N // 8, device=DEV, dtype=torch.bool); valid[:M] = True
+        vb = valid.view(MP // 32, 32, N // 64, 8).permute(0, 2, 1, 3).reshape(-1)
+        assert torch.equal(bits[vb], blocked[vb])
+        assert 0.2 < want.float().mean().item() < 0.8
+        dY = torch.randn(M, K, device=DEV).to(torch.bfloat16); W = (torch.randn(N, K, device=DEV) * 0.1).to(torch.bfloat16)
+        a = ops.gemm_nt(dY, W, M, N, K, relu_mask=y)
+        b = ops.gemm_nt(dY, W, M, N, K, relu_bits=bits)
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    finally:
+        ops.gemm_force_small_tile(False)
