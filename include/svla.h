@@ -36,6 +36,11 @@ int svla_ppo_lag_loss_fwd_bwd_f32(const float* logits, const float* values, cons
 /* PPOValue / SafePPOValue [3P AllenAct fork]; call sites training/online/dinov2_vits_tsfm_base.py:337-342. */
 int svla_value_mse_fwd_bwd_f32(const float* values, const float* returns, int rows, float coef, float inv_n, float* dvalues,
                                double* sums, void* stream);
+/* Imitation-learning action loss: nn.CrossEntropyLoss(ignore_index=-1), mean over non-ignored rows
+ * (architecture/models/transformer_models/early_fusion_tsfm_models.py:93,115-117).  sums[0] += sum of row losses;
+ * dlogits = (softmax - onehot) / *n_valid (device scalar). */
+int svla_ce_loss_fwd_bwd_f32(const float* logits, const long* target, int rows, int A, long ignore_index, const float* n_valid,
+                             float* dlogits, double* sums, void* stream);
 
 /* ---- heads ------------------------------------------------------------------------------------------------ */
 /* LinearActorHead / LinearCriticHead [3P AllenAct] applied at
@@ -141,10 +146,12 @@ int svla_vit_tokens(const svla_bf16* patch, const float* cls, const float* pos, 
 int svla_adaptive_pool_tokens(const svla_bf16* x, int B, int skip, int gh, int gw, int C, int oh, int ow, int cam, int ncam,
                               svla_bf16* tok_out, float* chw_out, void* stream);
 
-/* ---- optimiser (Adam lr 2e-5, max_grad_norm 0.5: training/online/dinov2_vits_tsfm_base.py:331-334) ------------- */
+/* ---- optimiser (Adam lr 2e-5, max_grad_norm 0.5: training/online/dinov2_vits_tsfm_base.py:331-334; weight_decay > 0 = the
+ * decoupled AdamW of the imitation-learning trainer, training/offline/train_pl.py:283-287) ---------------------------------- */
 int svla_sumsq_f32(const float* g, long n, double* out, void* stream);
 int svla_adam_step_f32(float* p, const float* g, float* m, float* v, svla_bf16* p_bf16, long n, float lr, float beta1,
-                       float beta2, float eps, int step, const double* gnorm_sq, float max_norm, float grad_scale, void* stream);
+                       float beta2, float eps, int step, const double* gnorm_sq, float max_norm, float grad_scale,
+                       float weight_decay, void* stream);
 int svla_cast_f32_bf16(const float* src, svla_bf16* dst, long n, void* stream);
 int svla_transpose_cast_f32_bf16(const float* src, int rows, int cols, svla_bf16* dst, void* stream);
 

@@ -1,0 +1,55 @@
+"""TEST INFRASTRUCTURE ONLY -- fp32 CPU restatement of the imitation-learning model.
+
+``EarlyFusionCnnTransformer`` in its ``small_3`` configuration with the llama decoder
+(/root/reference/architecture/models/transformer_models/early_fusion_tsfm_models.py:49-207,221-226) on pre-encoded DINOv2
+features: the frozen image encoder is outside this restatement (its features are the input, as for the RL towers).  Same
+state_dict names as the reference module minus ``visual_encoder.image_encoder.*``.  Pinned against the reference itself by
+tests/golden/g8_il.npz (tests/golden/make_golden_il.py).
+"""
+from typing import Dict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .ref_model import N_ACTIONS, RefGoalEncoder, RefLlamaDecoder, RefPositionalEncoder
+
+NAV, MANIP = "raw_navigation_camera", "raw_manipulation_camera"
+
+
+class RefEarlyFusion(nn.Module):
+    def __init__(self, max_length=1000, max_batch=8):
+        super().__init__()
+        d = 512
+        self.visual_encoder = RefGoalEncoder(tokenizer=None)
+        self.decoder = RefLlamaDecoder(d, 3, 8, 1e-5, max_batch, max_length)
+        self.actor = nn.Linear(d, N_ACTIONS)
+        self.time_encoder = RefPositionalEncoder(d)
+        self.last_actions_embed = nn.Embedding(N_ACTIONS + 2, d, padding_idx=N_ACTIONS + 1)
+        self.object_in_hand_embed = nn.Embedding(3, d)
+
+    def encode(self, batch: Dict[str, torch.Tensor]):
+        ve = self.visual_encoder
+        nav = batch[NAV]
+        B, T = nav.shape[:2]
+        R = B * T
+        with torch.no_grad():   # text_cond_visual_encoder.py:144-152
+            text = ve.text_encoder(batch["goals"]["input_ids"], batch["goals"]["attention_mask"])
+        text = ve.text_adapter(text)                                             # [B, L, d]
+        parts = [ve.fusion_token.view(1, 1, -1).expand(R, -1, -1)]
+        for key, tok in sorted([(MANIP, ve.visual_sensor_token_raw_manipulation_camera), (NAV, ve.visual_sensor_token_raw_navigation_camera)]):
+            parts.append(ve._camera(batch[key].reshape(R, *nav.shape[-3:]), tok))   # sensors in sorted order (:104)
+        parts.append(text.unsqueeze(1).expand(B, T, -1, -1).reshape(R, text.shape[1], -1))
+        fused = ve.fusion_xformer(torch.cat(parts, dim=1))[:, 0]
+        return fused.view(B, T, -1)
+
+    def forward(self, batch):
+        x = self.encode(batch)
+        x = x + self.last_actions_embed(batch["last_actions"])
+        x = x + self.object_in_hand_embed(batch["an_object_is_in_hand"])
+        x = x + self.time_encoder(batch["time_ids"])
+        B, T = x.shape[:2]
+        mask = torch.tril(torch.ones(T, T, dtype=torch.bool))[None, None].expand(B, 1, T, T)
+        logits = self.actor(self.decoder(x, 0, mask))
+        loss = F.cross_entropy(logits.reshape(-1, N_ACTIONS), batch["actions"].reshape(-1), ignore_index=-1)
+        return dict(actions_logits=logits, actions_loss=loss, loss=loss)

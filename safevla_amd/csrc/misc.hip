@@ -246,11 +246,11 @@ extern "C" int svla_sumsq_f32(const float* g, long n, double* out, void* stream)
     return svla_launch_status();
 }
 
-// torch.optim.Adam (defaults amsgrad=False, weight_decay=0) fused with clip_grad_norm_: the clip coefficient is read
+// torch.optim.Adam (amsgrad=False) / AdamW (decoupled ``weight_decay``: p *= 1 - lr*wd first) fused with clip_grad_norm_: the clip coefficient is read
 // from the device-side squared norm (no host sync).  Also refreshes the bf16 mirror of the parameters.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             bf16_t* __restrict__ p_bf16, long n, float lr, float beta1, float beta2, float eps, float bc1,
-                            float bc2_sqrt, const double* __restrict__ gnorm_sq, float max_norm, float grad_scale) {
+                            float bc2_sqrt, const double* __restrict__ gnorm_sq, float max_norm, float grad_scale, float decay) {
     float clip = grad_scale;
     if (gnorm_sq && max_norm > 0.f) {
         const float tn = sqrtf((float)(*gnorm_sq)) * grad_scale;
@@ -263,20 +263,20 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         const float mi = m[i] + (gi - m[i]) * (1.f - beta1);        // lerp_
         const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;    // mul_ + addcmul_
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        const float pi = p[i] - step * (mi / denom);
+        const float pi = p[i] * decay - step * (mi / denom);
         m[i] = mi; v[i] = vi; p[i] = pi;
         if (p_bf16) p_bf16[i] = f2bf(pi);
     }
 }
 extern "C" int svla_adam_step_f32(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, long n, float lr, float beta1,
                                   float beta2, float eps, int step, const double* gnorm_sq, float max_norm, float grad_scale,
-                                  void* stream) {
+                                  float weight_decay, void* stream) {
     if (n <= 0 || step <= 0) return SVLA_EINVAL;
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, p_bf16, n, lr, beta1, beta2, eps,
-                       bc1, bc2s, gnorm_sq, max_norm, grad_scale);
+                       bc1, bc2s, gnorm_sq, max_norm, grad_scale, 1.f - lr * weight_decay);
     return svla_launch_status();
 }
 

@@ -178,6 +178,44 @@ extern "C" int svla_value_mse_fwd_bwd_f32(const float* values, const float* retu
 }
 
 // ------------------------------------------------------------------------------------------------
+// Imitation-learning action loss: nn.CrossEntropyLoss(ignore_index) on [rows, A] fp32 logits, mean over the non-ignored rows
+// (/root/reference/architecture/models/transformer_models/early_fusion_tsfm_models.py:93,115-117).  Fused forward + backward,
+// one thread per row (A <= 32): sums[0] += sum_r -log_softmax(logits[r])[target[r]];  dlogits = (softmax - onehot) / n_valid.
+// ``n_valid`` is read from device memory (counted by the caller without a host sync); rows with target == ignore_index get 0.
+__global__ void ce_loss_kernel(const float* __restrict__ logits, const long* __restrict__ target, int rows, int A, long ignore_index,
+                               const float* __restrict__ n_valid, float* __restrict__ dlogits, double* __restrict__ sums) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    float loss = 0.f;
+    if (r < rows) {
+        const float* x = logits + (size_t)r * A;
+        float* dx = dlogits + (size_t)r * A;
+        const long t = target[r];
+        if (t == ignore_index || t < 0 || t >= A) {
+            for (int a = 0; a < A; ++a) dx[a] = 0.f;
+        } else {
+            float mx = x[0];
+            for (int a = 1; a < A; ++a) mx = fmaxf(mx, x[a]);
+            float se = 0.f;
+            for (int a = 0; a < A; ++a) se += __expf(x[a] - mx);
+            const float lse = mx + __logf(se);
+            const float inv = 1.f / fmaxf(*n_valid, 1.f);
+            for (int a = 0; a < A; ++a) dx[a] = (__expf(x[a] - lse) - (a == (int)t ? 1.f : 0.f)) * inv;
+            loss = lse - x[t];
+        }
+    }
+    loss = wave_sum(loss);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sums[0], (double)loss);
+}
+
+extern "C" int svla_ce_loss_fwd_bwd_f32(const float* logits, const long* target, int rows, int A, long ignore_index,
+                                        const float* n_valid, float* dlogits, double* sums, void* stream) {
+    if (rows <= 0 || A <= 0 || A > 1024 || !n_valid) return SVLA_EINVAL;
+    hipLaunchKernelGGL(ce_loss_kernel, dim3((rows + 127) / 128), dim3(128), 0, (hipStream_t)stream, logits, target, rows, A,
+                       ignore_index, n_valid, dlogits, sums);
+    return svla_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Small heads on fp32 beliefs (AllenAct LinearActorHead / LinearCriticHead [3P]): out[r, n] = x[r,:].W[n,:] + b[n],
 // D = 512 (8 values per lane, one wave per row), N <= 32.  ``row_perm_T``/``row_perm_B`` > 0: x rows are stored
 // (b*T + t) (decoder layout) while out rows are (t*B + b) (the [step, sampler] layout of the API).

@@ -1,0 +1,178 @@
+"""Offline imitation-learning workload on the same kernels.
+
+Mirrors ``EarlyFusionCnnTransformer`` in its ``small_3`` configuration with the llama decoder
+(/root/reference/architecture/models/transformer_models/early_fusion_tsfm_models.py:49-207,221-226): text-conditioned multi-camera
+encoder (text_cond_visual_encoder.py:56-268) -> + last-action / in-hand / time embeddings (:120-157) -> causal llama decoder ->
+``actor`` -> ``nn.CrossEntropyLoss(ignore_index=-1)`` (:93,115-117); and the optimiser of ``training/offline/train_pl.py:283-287``
+(AdamW, lr 1e-4).  It IS one tower of the RL model -- the RL towers are initialised from exactly these weights
+(``checkpoint.init_towers_from_il``) -- so the forward/backward run the update path's kernel schedules (``model.Tower``); new here:
+the batch-first IL batch format, the fused cross-entropy kernel and decoupled weight decay in the Adam kernel.
+
+The frozen image encoder stays outside, as on the RL path: visual sensors are either pre-encoded DINOv2 features ``[B,T,384,7,12]``
+or uint8 frames ``[B,T,H,W,3]`` (then ``preproc.DinoViT`` runs first).  ``state_dict`` uses the reference's names
+(``actor.weight``, no critic head), so Lightning checkpoints (``model.`` prefix) interchange.
+"""
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .model import BF16, DINO, F32, N_ACTIONS, NPATCH, TEXT_OFF, Prep, Tower, _Arena, _TowerFn
+
+NAV, MANIP = "raw_navigation_camera", "raw_manipulation_camera"
+START_TOKEN, PAD_TOKEN = N_ACTIONS, N_ACTIONS + 1      # last_actions vocabulary (:95-101)
+
+
+class _CEFn(torch.autograd.Function):
+    """Fused cross-entropy forward+backward (svla_ce_loss_fwd_bwd_f32): mean over targets != ignore_index."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        rows, A = logits.shape
+        n_valid = (target != ignore_index).sum().to(F32).reshape(1)
+        dlogits = torch.empty_like(logits)
+        sums = torch.zeros(1, device=logits.device, dtype=torch.float64)
+        ops.ce_loss_fwd_bwd(logits.contiguous(), target.contiguous(), n_valid, dlogits, sums, ignore_index)
+        ctx.save_for_backward(dlogits)
+        return (sums[0] / n_valid[0].clamp(min=1.0).double()).to(F32)
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g, None, None
+
+
+class EarlyFusionCnnTransformer(Tower):
+    def __init__(self, device="cuda", max_length: int = 1000, input_sensors=(NAV, MANIP, "last_actions", "an_object_is_in_hand"),
+                 image_preprocessor=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("safevla_amd needs an MI355X: there is no CPU or eager fallback for the policy kernels")
+        ops.lib()
+        arena = _Arena()
+        device = torch.device(device)
+        super().__init__(arena, device, max_steps=max_length)
+        arena.build(device)
+        self.bind()
+        self.towers = [self]
+        self.input_sensors = list(input_sensors)
+        self.image_preprocessor = image_preprocessor
+        self._anchor = torch.zeros(1, device=device, requires_grad=True)
+        self.sync_weights()
+
+    # ---- weights: reference names ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _to_ref(k: str) -> Optional[str]:
+        if k.startswith("critic."):
+            return None
+        return k.replace("actor.linear.", "actor.")
+
+    def state_dict(self, *a, **kw):
+        sd = super().state_dict(*a, **kw)
+        return type(sd)((self._to_ref(k), v) for k, v in sd.items() if self._to_ref(k) is not None)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        own = super().state_dict()
+        sd = {k.replace("actor.weight", "actor.linear.weight").replace("actor.bias", "actor.linear.bias"): v for k, v in state_dict.items()}
+        missing = [k for k in own if k not in sd and not k.startswith("critic.")]
+        unexpected = [k for k in sd if k not in own and "visual_encoder.image_encoder" not in k]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"state_dict mismatch: missing {missing[:5]}, unexpected {unexpected[:5]}")
+        with torch.no_grad():
+            for k, v in sd.items():
+                if k in own:
+                    own[k].copy_(v.to(own[k].device, own[k].dtype))
+        self.sync_weights()
+        return missing, unexpected
+
+    def sync_weights(self):
+        ar = self.arena
+        ops.cast_bf16(ar.flat_p, ar.flat_bf16)
+        self.refresh_transposes()
+        self.visual_encoder.text_encoder.sync()
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.arena.flat_g.zero_()
+
+    def trainable_parameters(self):
+        return [p for n, p in self.named_parameters() if p.requires_grad and not n.startswith("critic.")]
+
+    # ---- batch -> kernel inputs ----------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def prepare(self, batch: Dict) -> Prep:
+        dev = self.device_
+        nav = batch[NAV]
+        B, T = nav.shape[:2]
+        R = T * B
+        p = Prep()
+        p.T, p.B, p.R = T, B, R
+        p.tokens = torch.empty(R, 2, NPATCH, DINO, device=dev, dtype=BF16)
+        for cam, key in enumerate((NAV, MANIP)):
+            x = batch[key].to(dev)
+            if x.dtype == torch.uint8:                           # raw frames [B,T,H,W,3] -> frozen ViT
+                if self.image_preprocessor is None:
+                    from .preproc import DinoViTPreprocessor
+                    self.image_preprocessor = DinoViTPreprocessor(key, key, device=dev)
+                fr = x.transpose(0, 1).reshape(R, *x.shape[2:]).contiguous()
+                self.image_preprocessor.process_tokens(fr, p.tokens, cam)
+            else:                                                # pre-encoded features [B,T,384,7,12]
+                ops.feat_to_tokens(x.transpose(0, 1).reshape(R, DINO, NPATCH).contiguous().float(), p.tokens, cam)
+        tb = lambda v: v.to(dev).transpose(0, 1).reshape(R).contiguous()     # [B,T] -> rows (t*B + b)
+        la = tb(batch["last_actions"]).to(torch.int64)
+        p.prev_actions = la
+        p.masks = (la != START_TOKEN).to(F32)                    # start token <=> "no previous action" (mask 0 selects row 20)
+        p.hand = tb(batch["an_object_is_in_hand"]).to(torch.int64) if "an_object_is_in_hand" in batch else torch.zeros(R, device=dev, dtype=torch.int64)
+        p.time_step = tb(batch["time_ids"]).to(torch.int64)
+        p.traj_bt = torch.arange(B, device=dev, dtype=torch.int32)[:, None].expand(B, T).contiguous()   # one trajectory per row: causal
+        p.ids = batch["goals"]["input_ids"].to(dev).to(torch.int64).contiguous()
+        p.attn_mask = batch["goals"]["attention_mask"].to(dev).to(torch.int64).contiguous()
+        p.gid = (torch.arange(R, device=dev) % B).to(torch.int32).contiguous()
+        p.U, p.L = p.ids.shape
+        p.S = TEXT_OFF + p.L
+        return p
+
+    # ---- reference forward API --------------------------------------------------------------------------------------------------
+    def forward(self, batch: Dict) -> Dict[str, torch.Tensor]:
+        prep = self.prepare(batch)
+        logits, _ = _TowerFn.apply(self._anchor, self, prep, True, False)      # [T, B, A] fp32
+        out = dict(actions_logits=logits.transpose(0, 1))
+        if "actions" in batch:
+            tgt = batch["actions"].to(self.device_).transpose(0, 1).reshape(-1).to(torch.int64)
+            loss = _CEFn.apply(logits.reshape(-1, N_ACTIONS), tgt, -1)
+            out["actions_loss"] = loss
+            out["loss"] = loss
+        return out
+
+    @classmethod
+    def build_model(cls, model_version="small_3", input_sensors=(NAV, MANIP, "last_actions", "an_object_is_in_hand"), loss="action",
+                    device="cuda", ckpt_pth: Optional[str] = None, ckpt_prefix: str = "model."):
+        if model_version not in ("small", "small_3"):
+            raise NotImplementedError("only the shipped DINOv2-S / t5-small / 3+3-layer geometry is built (early_fusion_tsfm_models.py:221-226)")
+        m = cls(device=device, input_sensors=input_sensors)
+        if ckpt_pth is not None:    # Lightning checkpoint (training/offline/train_utils.py:6-68)
+            sd = torch.load(ckpt_pth, map_location="cpu")["state_dict"]
+            m.load_state_dict({k[len(ckpt_prefix):]: v for k, v in sd.items() if k.startswith(ckpt_prefix)}, strict=False)
+        return m
+
+
+class ILTrainer:
+    """``LitModel.training_step`` + ``configure_optimizers`` (training/offline/train_pl.py:154-186,283-287): AdamW(lr) on the flat arena."""
+
+    def __init__(self, model: EarlyFusionCnnTransformer, lr: float = 1e-4, weight_decay: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.model, self.lr, self.wd, self.betas, self.eps = model, lr, weight_decay, betas, eps
+        self.step_count = 0
+
+    def training_step(self, batch: Dict) -> Dict[str, float]:
+        m = self.model
+        m.zero_grad()
+        out = m(batch)
+        out["loss"].backward()
+        self.step_count += 1
+        ar = m.arena
+        ops.adam_step(ar.flat_p, ar.flat_g, ar.flat_m, ar.flat_v, ar.flat_bf16, self.lr, self.step_count, self.betas[0], self.betas[1],
+                      self.eps, weight_decay=self.wd)
+        m.refresh_transposes()
+        return {"loss": float(out["loss"])}
+
+    def state_dict(self):
+        ar = self.model.arena
+        return dict(step=self.step_count, exp_avg=ar.flat_m.clone(), exp_avg_sq=ar.flat_v.clone())

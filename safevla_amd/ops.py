@@ -236,9 +236,17 @@ def sumsq(g, out):
     lib().call("svla_sumsq_f32", _p(g), g.numel(), _p(out), _stream())
 
 
-def adam_step(p, g, m, v, p_bf16, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, gnorm_sq=None, max_norm=0.0, grad_scale=1.0):
+def adam_step(p, g, m, v, p_bf16, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, gnorm_sq=None, max_norm=0.0, grad_scale=1.0,
+              weight_decay=0.0):
     lib().call("svla_adam_step_f32", _p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), float(lr), float(beta1), float(beta2),
-               float(eps), int(step), _p(gnorm_sq), float(max_norm), float(grad_scale), _stream())
+               float(eps), int(step), _p(gnorm_sq), float(max_norm), float(grad_scale), float(weight_decay), _stream())
+
+
+def ce_loss_fwd_bwd(logits, target, n_valid, dlogits, sums, ignore_index=-1):
+    """logits [rows, A] fp32, target [rows] int64; n_valid: 1-element fp32 device tensor (# non-ignored rows)."""
+    _chk(logits, F32, "logits")
+    rows, A = logits.shape
+    lib().call("svla_ce_loss_fwd_bwd_f32", _p(logits), _p(target), rows, A, int(ignore_index), _p(n_valid), _p(dlogits), _p(sums), _stream())
 
 
 def cast_bf16(src, dst):

@@ -497,3 +497,21 @@ def test_gemm_nt_relu_bit_mask_roundtrip(ops, M, force_small):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
     finally:
         ops.gemm_force_small_tile(False)
+
+
+def test_ce_loss_fwd_bwd_vs_torch(ops):
+    """svla_ce_loss_fwd_bwd_f32 == F.cross_entropy(ignore_index=-1) and its gradient (early_fusion_tsfm_models.py:93,115-117)."""
+    torch.manual_seed(5)
+    R, A = 777, 20
+    logits = (torch.randn(R, A, device=DEV) * 3).requires_grad_(True)
+    tgt = torch.randint(0, A, (R,), device=DEV)
+    tgt[torch.rand(R, device=DEV) < 0.3] = -1
+    want = F.cross_entropy(logits, tgt, ignore_index=-1)
+    want.backward()
+    n_valid = (tgt != -1).sum().float().reshape(1)
+    dl = torch.empty(R, A, device=DEV)
+    sums = torch.zeros(1, device=DEV, dtype=torch.float64)
+    ops.ce_loss_fwd_bwd(logits.detach(), tgt, n_valid, dl, sums)
+    assert abs(sums.item() / n_valid.item() - want.item()) < 2e-6 * max(1.0, abs(want.item()))
+    assert torch.allclose(dl, logits.grad, rtol=1e-5, atol=1e-8)
+    assert (dl[tgt == -1] == 0).all()

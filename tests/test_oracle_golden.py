@@ -139,3 +139,31 @@ def test_g6_losses():
     np.testing.assert_allclose(r.grad.numpy(), g["ppo:dlogits"], rtol=1e-4, atol=1e-8)
     # lambda = 0  =>  SafePPOLogGrad == PPOLogGrad
     np.testing.assert_allclose(g["safe:0:0.0:scalars"], g["ppo:scalars"], rtol=1e-6)
+
+
+def test_g8_imitation_learning_model_vs_reference():
+    """oracle.ref_il.RefEarlyFusion (EarlyFusionCnnTransformer small_3 / llama decoder on pre-encoded features) vs the reference's
+    own logits, cross-entropy loss and gradient checksums (tests/golden/make_golden_il.py)."""
+    from oracle.detfill import fill_state_dict, grad_probe
+    from oracle.ref_il import RefEarlyFusion
+
+    g = dict(np.load(os.path.join(G, "g8_il.npz"), allow_pickle=False))
+    m = RefEarlyFusion().eval()
+    want = {l.split("\t")[0]: l.rstrip("\n").split("\t")[1] for l in open(os.path.join(G, "state_dict_manifest_il.txt"))}
+    have = {k: str(tuple(v.shape)) for k, v in m.state_dict().items()}
+    assert have == want
+    fill_state_dict(m, seed=7, share_t5=False)
+    batch = {k: torch.from_numpy(g[k].astype(np.float32) if g[k].dtype == np.float16 else g[k])
+             for k in ("raw_navigation_camera", "raw_manipulation_camera", "time_ids", "an_object_is_in_hand", "actions", "last_actions", "padding_mask")}
+    batch["goals"] = dict(input_ids=torch.from_numpy(g["goal_ids"]), attention_mask=torch.from_numpy(g["goal_mask"]))
+    out = m(batch)
+    out["loss"].backward()
+    assert np.allclose(out["actions_logits"].detach().numpy(), g["logits"], rtol=2e-4, atol=2e-4)
+    assert abs(out["loss"].item() - float(g["loss"])) < 1e-5
+    n = 0
+    for name, p in m.named_parameters():
+        if "gp:" + name in g:
+            got = np.array(grad_probe(name, p.grad))
+            assert np.allclose(got, g["gp:" + name], rtol=2e-3, atol=1e-6), (name, got, g["gp:" + name])
+            n += 1
+    assert n == sum(k.startswith("gp:") for k in g)
