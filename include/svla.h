@@ -17,6 +17,16 @@ extern "C" {
 
 typedef uint16_t svla_bf16;
 
+/* Train-mode dropout.  The reference leaves the policy in train() mode (allenact_dino_transformer.py:193), so the dropout 0.1 of
+ * nn.TransformerEncoderLayer (attention probabilities, both sub-layer outputs, the feed-forward activation; :545-552) is active in
+ * rollouts and updates.  Here it is counter-based and stateless (forward and backward regenerate the same mask, nothing is stored):
+ *   r    = lowbias32((uint32)(e>>1) * 0x9E3779B1 ^ (uint32)(e>>33) * 0x85EBCA77 ^ seed ^ stream * 0xC2B2AE3D)
+ *   keep = ((e & 1) ? r >> 16 : r & 0xffff) >= (uint32)(p * 65536 + 0.5);   kept values are scaled by 1 / (1 - p)
+ * with e = the element's flat index in its site's logical tensor: (row * row_mult) * N + col for [rows, N] activations (row_mult
+ * > 1 when only every row_mult-th row of the logical tensor is materialised), ((row*H + head)*S + query)*S4 + key for attention
+ * probabilities with the key stride S rounded up to a multiple of 4.  lowbias32(x): x ^= x>>16; x *= 0x7FEB352D; x ^= x>>15; x *= 0x846CA68B; x ^= x>>16.  NULL / p == 0: no dropout. */
+typedef struct svla_dropout { unsigned seed, stream; float p; int row_mult; } svla_dropout;
+
 /* ---- rollout statistics ------------------------------------------------------------------------------ */
 /* Reward + cost GAE reverse scan.  Replaces AllenAct-fork RolloutStorage.compute_returns(use_gae=True) [3P];
  * hyper-parameters at training/online/dinov2_vits_tsfm_base.py:345-347; arrays are [T,B] (masks [T+1,B]). */
@@ -62,7 +72,7 @@ int svla_norm_fwd_bf16(const svla_bf16* x, int xG, int xGS, int xOFF, const floa
 int svla_norm_bwd_bf16(const svla_bf16* dy, int dyG, int dyGS, int dyOFF, const svla_bf16* x, int xG, int xGS, int xOFF,
                        const float* gamma, const float* beta, const float* mean, const float* rstd, int rows, int D, int rms,
                        int relu, int tok_group, const svla_bf16* dres, svla_bf16* dx, int dxG, int dxGS, int dxOFF, float* dgamma,
-                       float* dbeta, float* dtok, void* stream);
+                       float* dbeta, float* dtok, svla_bf16* dx_drop, const svla_dropout* drop, void* stream);
 
 /* ---- GEMMs (MFMA bf16, fp32 accumulate) --------------------------------------------------------------------- */
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear / 1x1 nn.Conv2d of the policy
@@ -70,11 +80,13 @@ int svla_norm_bwd_bf16(const svla_bf16* dy, int dyG, int dyGS, int dyOFF, const 
  * gradients.  act: 0 none, 1 ReLU, 2 GELU(erf).  relu_mask: zero outputs where mask <= 0.  N % 128 == 0, K % 64 == 0.
  * relu_bits_out (act == 1 only): additionally write the sign bits of the output, ceil(M/32)*32 * N/8 bytes in an opaque blocked
  * layout ([M/32][N/64][32 rows][8 bytes], N % 64 == 0; SVLA_RELU_BITS_BYTES); relu_bits: the same mask as relu_mask, given as those bits (the ReLU derivative of nn.TransformerEncoderLayer's
- * feed-forward, allenact_dino_transformer.py:545-552, without re-reading the 2048-wide activation). */
+ * feed-forward, allenact_dino_transformer.py:545-552, without re-reading the 2048-wide activation).
+ * drop: dropout applied after the activation and before the residual add (sub-layer output / feed-forward activation sites). */
 #define SVLA_RELU_BITS_BYTES(M, N) ((((long)(M) + 31) / 32) * 32 * ((long)(N) / 8))
 int svla_gemm_nt_bf16(const svla_bf16* A, long lda, const svla_bf16* B, long ldb, const float* bias, const svla_bf16* residual,
                       long ldr, const svla_bf16* relu_mask, long ldm, void* C, long ldc, int M, int N, int K, int act,
-                      int out_f32, float alpha, unsigned char* relu_bits_out, const unsigned char* relu_bits, void* stream);
+                      int out_f32, float alpha, unsigned char* relu_bits_out, const unsigned char* relu_bits,
+                      const svla_dropout* drop, void* stream);
 /* Test hook: force the 128x128-tile kernel even where the 256x256 one would be chosen (same cited layers). */
 int svla_gemm_force_small_tile(int on);
 /* dW[N,K] (fp32) += dY[M,N]^T . X[M,K]: weight gradients (autograd of the same layers); optional fused bias gradient
@@ -97,11 +109,12 @@ int svla_colsum_bf16(const svla_bf16* dY, long ldy, int M, int N, int row_stride
  * both re-reading O (null: each pass recomputes it). */
 int svla_attn_fwd_bf16(const svla_bf16* Q, const svla_bf16* K, const svla_bf16* V, long ld, svla_bf16* O, long ldo, float* LSE,
                        int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj, const float* bias,
-                       const unsigned char* kvalid, int Sq, long ldq, int kv_rows, void* stream);
+                       const unsigned char* kvalid, int Sq, long ldq, int kv_rows, const svla_dropout* drop, void* stream);
 int svla_attn_bwd_bf16(const svla_bf16* Q, const svla_bf16* K, const svla_bf16* V, long ld, const svla_bf16* O, long ldo,
                        const float* LSE, const svla_bf16* dO, long lddo, svla_bf16* dQ, svla_bf16* dK, svla_bf16* dV, long ldd,
                        int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj, const float* bias,
-                       const unsigned char* kvalid, int Sq, long ldq, long lddq, float* D_ws, void* stream);
+                       const unsigned char* kvalid, int Sq, long ldq, long lddq, float* D_ws, const svla_dropout* drop,
+                       void* stream);
 
 /* ---- observation / embedding glue ---------------------------------------------------------------------------- */
 /* (R,C,7,12) fp32 channels-first DINO features -> bf16 tokens [R, ncam, P, C] (input layout of the 1x1-conv compressor,

@@ -134,8 +134,42 @@ class _MHAParams(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
 
 
+def hash_keep(seed: int, stream: int, p: float, idx: np.ndarray) -> np.ndarray:
+    """Keep-mask of the counter-based dropout defined in include/svla.h (svla_dropout): ``idx`` = flat element indices."""
+    with np.errstate(over="ignore"):
+        idx = idx.astype(np.uint64)
+        key = np.uint32(seed & 0xFFFFFFFF) ^ (np.uint32(stream) * np.uint32(0xC2B2AE3D))
+        pair = idx >> np.uint64(1)
+        x = (pair & np.uint64(0xFFFFFFFF)).astype(np.uint32) * np.uint32(0x9E3779B1)
+        x ^= (pair >> np.uint64(32)).astype(np.uint32) * np.uint32(0x85EBCA77)
+        x ^= key
+        x ^= x >> np.uint32(16); x *= np.uint32(0x7FEB352D); x ^= x >> np.uint32(15); x *= np.uint32(0x846CA68B); x ^= x >> np.uint32(16)
+        bits = np.where((idx & np.uint64(1)) != 0, x >> np.uint32(16), x & np.uint32(0xFFFF))
+        thr = np.uint32(np.float32(p) * np.float32(65536.0) + np.float32(0.5))
+    return bits >= thr
+
+
+def hash_dropout(x: torch.Tensor, seed: int, stream: int, p: float, attn_S: int = 0) -> torch.Tensor:
+    """x * keep / (1 - p) with the element index = the flat index of ``x`` (attention probabilities [R,H,S,S]: key stride
+    rounded up to a multiple of 4, as the kernels index them)."""
+    if attn_S:
+        R, H, S, _ = x.shape
+        S4 = (S + 3) & ~3
+        base = (np.arange(R * H * S, dtype=np.uint64) * np.uint64(S4)).reshape(R, H, S, 1)
+        idx = base + np.arange(S, dtype=np.uint64)
+    else:
+        idx = np.arange(x.numel(), dtype=np.uint64).reshape(tuple(x.shape))
+    keep = torch.from_numpy(hash_keep(seed, stream, p, idx))
+    return x * keep.to(x.dtype) * np.float32(1.0 / (1.0 - np.float32(p)))
+
+
 class RefFusionLayer(nn.Module):
-    """``nn.TransformerEncoderLayer(d,h,batch_first=True)`` defaults: post-LN, ReLU, ff 2048, eps 1e-5."""
+    """``nn.TransformerEncoderLayer(d,h,batch_first=True)`` defaults: post-LN, ReLU, ff 2048, eps 1e-5.
+
+    ``hash_seed`` (set by tests): replace torch's Philox dropout by the counter-based masks of include/svla.h so that train-mode
+    forward/backward can be compared element for element with the HIP path (same 4 sites, streams 4*layer + {0,1,2,3})."""
+    hash_seed = None
+    layer_idx = 0
 
     def __init__(self, d=512, h=8, ff=2048, p=0.0):
         super().__init__()
@@ -154,17 +188,23 @@ class RefFusionLayer(nn.Module):
         q = q.view(R, S, self.h, hd).transpose(1, 2)
         k = k.view(R, S, self.h, hd).transpose(1, 2)
         v = v.view(R, S, self.h, hd).transpose(1, 2)
-        pr = F.dropout(F.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), dim=-1), self.p, self.training)
+        if self.hash_seed is not None and self.training and self.p > 0:
+            drop = lambda t, k, attn=0: hash_dropout(t, self.hash_seed, 4 * self.layer_idx + k, self.p, attn)
+        else:
+            drop = lambda t, k, attn=0: F.dropout(t, self.p, self.training)
+        pr = drop(F.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), dim=-1), 0, S)
         a = self.self_attn.out_proj((pr @ v).transpose(1, 2).reshape(R, S, d))
-        x = self.norm1(x + F.dropout(a, self.p, self.training))
-        f = self.linear2(F.dropout(F.relu(self.linear1(x)), self.p, self.training))
-        return self.norm2(x + F.dropout(f, self.p, self.training))
+        x = self.norm1(x + drop(a, 1))
+        f = self.linear2(drop(F.relu(self.linear1(x)), 2))
+        return self.norm2(x + drop(f, 3))
 
 
 class _Layers(nn.Module):
     def __init__(self, n, d, h, p):
         super().__init__()
         self.layers = nn.ModuleList([RefFusionLayer(d, h, 2048, p) for _ in range(n)])
+        for i, l in enumerate(self.layers):
+            l.layer_idx = i
 
     def forward(self, x):
         for l in self.layers:

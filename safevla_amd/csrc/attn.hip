@@ -34,7 +34,18 @@ struct AttnArgs {
     int Sq;                               // query rows per batch row present in Q / O / dO / dQ / LSE (<= S; S = all)
     long ldq, lddq;                       // token row strides of Q and dQ (the K/V tensors use ld / ldd)
     float* Dws;                           // [rows, H, Sq] rowsum(dO * O): written by the dQ kernel, read by the dK/dV kernel (or null)
+    DropCfg drop;                         // dropout on the attention probabilities (thr == 0: off)
 };
+
+// element index of probability (row r, head h, query q, key k): ((r*H + h)*S + q) * SP4 + k with the key stride SP4 = S rounded
+// up to a multiple of 4, so that the 4 consecutive keys a lane holds share two RNG words (include/svla.h: svla_dropout)
+__device__ __forceinline__ unsigned long long att_drop_row(const AttnArgs& p, int r, int h, int q) {
+    return ((unsigned long long)((size_t)r * p.H + h) * p.S + q) * (unsigned long long)((p.S + 3) & ~3);
+}
+__device__ __forceinline__ bool att_keep1(const DropCfg& c, unsigned long long e) {
+    const unsigned x = drop_bits(c.key, e >> 1);
+    return ((e & 1) ? (x >> 16) : (x & 0xffffu)) >= c.thr;
+}
 
 // physical 16-byte chunk of logical chunk c in row r: c ^ ((r >> 1) & 7).  16 consecutive rows x one logical chunk hit 16
 // distinct 16-byte bank slots (conflict-free ds_read_b128); a transposed 64-lane read (16 rows x 32 B) takes its 2 cycles.
@@ -192,6 +203,15 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
             for (int e = 0; e < 4; ++e) { sc[kt][e] = __builtin_amdgcn_exp2f(sc[kt][e] - mx); lsum += sc[kt][e]; }
         lsum += __shfl_xor(lsum, 16, 64);
         lsum += __shfl_xor(lsum, 32, 64);
+        if (p.drop.thr) {      // dropout on the normalised probabilities: zero here, 1/(1-p) folded into the final scale
+            const unsigned long long rb = att_drop_row(p, r, h, q < Sq ? q : 0);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                const unsigned keep = drop_keep4(p.drop, rb + kt * 16 + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (!((keep >> e) & 1u)) sc[kt][e] = 0.f;
+            }
+        }
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -207,7 +227,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
             }
         }
         // o[dt][e]: query q (this lane's own softmax row), head dim dt*16 + 4g + e  ->  8-byte stores, 32 B per row per dt
-        const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+        const float inv = lsum > 0.f ? p.drop.scale / lsum : 0.f;
         if (q < Sq) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -317,6 +337,15 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_persist_kernel(AttnAr
             float lsum = (ls4[0] + ls4[1]) + (ls4[2] + ls4[3]);
             lsum += __shfl_xor(lsum, 16, 64);
             lsum += __shfl_xor(lsum, 32, 64);
+            if (p.drop.thr) {      // wave-uniform; dropout on the normalised probabilities (scale folded into ``inv``)
+                const unsigned long long rb = att_drop_row(p, r, h, q < Sq ? q : 0);
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    const unsigned keep = drop_keep4(p.drop, rb + kt * 16 + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (!((keep >> e) & 1u)) sc[kt][e] = 0.f;
+                }
+            }
             f32x4 o[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -329,7 +358,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_persist_kernel(AttnAr
                 for (int dt = 0; dt < 4; ++dt)
                     o[dt] = mfma16(lds_tr8i(Vtr.d[dt], 32 * u, 32 * u + 16), pa, o[dt]);
             }
-            const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+            const float inv = lsum > 0.f ? p.drop.scale / lsum : 0.f;
             if (q < Sq) {
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
@@ -426,6 +455,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dq_kernel(AttnArgs p) {
                     s = mfma16(lds_row8i(Krow.hi, kt * 16), qf1, s);
                     dp = mfma16(lds_row8i(Vrow.lo, kt * 16), gf0, dp);
                     dp = mfma16(lds_row8i(Vrow.hi, kt * 16), gf1, dp);
+                    // dP = keep/(1-p) * (dO V^T): the forward's keep-mask, regenerated
+                    const unsigned dkeep = p.drop.thr ? drop_keep4(p.drop, att_drop_row(p, r, h, qok ? q : 0) + kt * 16 + 4 * g) : 0xfu;
                     if constexpr (GENERIC) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -434,14 +465,14 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dq_kernel(AttnArgs p) {
                             if (p.bias && qok && key < S) sv += p.bias[((size_t)h * S + q) * S + key];
                             const bool mk = !qok || masked(p, qok ? q : 0, key, traj_s, kvp);
                             const float pr = mk ? 0.f : __expf(sv - lse_q);
-                            dsv[e2 * 4 + e] = pr * (dp[e] - D_q) * p.scale;
+                            dsv[e2 * 4 + e] = pr * (((dkeep >> e) & 1u ? dp[e] * p.drop.scale : 0.f) - D_q) * p.scale;
                         }
                     } else {
                         // no mask needed: padded keys have zero K rows (their dS never reaches dQ), padded queries have
                         // lse = +inf => P = 0
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            dsv[e2 * 4 + e] = __builtin_amdgcn_exp2f(s[e] * sl2 - lse2_q) * (dp[e] - D_q) * p.scale;
+                            dsv[e2 * 4 + e] = __builtin_amdgcn_exp2f(s[e] * sl2 - lse2_q) * (((dkeep >> e) & 1u ? dp[e] * p.drop.scale : 0.f) - D_q) * p.scale;
                     }
                 }
                 const bf16x8 da = pack8(dsv);
@@ -558,8 +589,9 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 1) attn_bwd_dkv_k
                             if (p.bias && q < S && kok) sv += p.bias[((size_t)h * S + q) * S + keyl];
                             const bool mk = (q >= Sq) || masked(p, q < Sq ? q : 0, keyl, traj_s, kvp);
                             const float pr = mk ? 0.f : __expf(sv - lse_s[q]);
-                            pv[e2 * 4 + e] = pr;
-                            dsv[e2 * 4 + e] = pr * (dp[e] - D_s[q]) * p.scale;
+                            const bool kp = !p.drop.thr || att_keep1(p.drop, att_drop_row(p, r, h, q < Sq ? q : 0) + keyl);
+                            pv[e2 * 4 + e] = kp ? pr * p.drop.scale : 0.f;
+                            dsv[e2 * 4 + e] = pr * ((kp ? dp[e] * p.drop.scale : 0.f) - D_s[q]) * p.scale;
                         }
                     } else {
                         // lse_s holds lse*log2e here (+inf for padded queries => P = 0); padded key columns are never stored
@@ -567,8 +599,10 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 1) attn_bwd_dkv_k
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float pr = __builtin_amdgcn_exp2f(s[e] * sl2 - l4[e]);
-                            pv[e2 * 4 + e] = pr;
-                            dsv[e2 * 4 + e] = pr * (dp[e] - d4[e]) * p.scale;
+                            const int q = qt * 16 + 4 * g + e;
+                            const bool kp = !p.drop.thr || att_keep1(p.drop, att_drop_row(p, r, h, q < Sq ? q : 0) + keyl);
+                            pv[e2 * 4 + e] = kp ? pr * p.drop.scale : 0.f;
+                            dsv[e2 * 4 + e] = pr * ((kp ? dp[e] * p.drop.scale : 0.f) - d4[e]) * p.scale;
                         }
                     }
                 }
@@ -642,6 +676,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) attn_bwd_dq_exact_kernel(AttnA
             D_q += __shfl_xor(D_q, 32, 64);
             if (p.Dws && g == 0 && qok) p.Dws[((size_t)r * p.H + h) * Sq + q] = D_q;
             const f32x4 nl4 = {-lall[t], -lall[t], -lall[t], -lall[t]}, nd4 = {-D_q, -D_q, -D_q, -D_q};
+            const unsigned long long drow = att_drop_row(p, r, h, qok ? q : 0);
             f32x4 dq[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -662,6 +697,11 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) attn_bwd_dq_exact_kernel(AttnA
                     f32x4 pr;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) pr[e] = __builtin_amdgcn_exp2f(x[e]);
+                    if (p.drop.thr) {      // wave-uniform: dP = keep/(1-p) * (dO V^T), the forward's keep-mask regenerated
+                        const unsigned keep = drop_keep4(p.drop, drow + (2 * u + e2) * 16 + 4 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dp[e] = ((keep >> e) & 1u) ? dp[e] * p.drop.scale : 0.f;
+                    }
                     const f32x4 ds = pr * (dp + nd4) * sc4;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dsv[e2 * 4 + e] = ds[e];
@@ -744,12 +784,22 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) attn_bwd_dkv_exact_kernel(Attn
                     // sv[e]: query (2w+e2)*16 + 4g + e, key keyl
                     const f32x4 l4 = *(const f32x4*)(lse_s + w * 32 + e2 * 16 + 4 * g), d4 = *(const f32x4*)(D_s + w * 32 + e2 * 16 + 4 * g);
                     const f32x4 x = sv * sl4 - l4;
-                    f32x4 pr;
+                    f32x4 pr, pd;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) pr[e] = __builtin_amdgcn_exp2f(x[e]);
+                    pd = pr;
+                    if (p.drop.thr) {      // wave-uniform.  This layout holds 4 consecutive QUERIES of one key: one RNG word each
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int q = w * 32 + e2 * 16 + 4 * g + e;
+                            const bool kp = att_keep1(p.drop, att_drop_row(p, r, h, q < Sq ? q : 0) + keyl);
+                            pd[e] = kp ? pr[e] * p.drop.scale : 0.f;       // dropped-out probabilities feed dV
+                            dp[e] = kp ? dp[e] * p.drop.scale : 0.f;       // and dP = keep/(1-p) * (dO V^T)
+                        }
+                    }
                     const f32x4 ds = pr * (dp - d4) * sc4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { pv[e2 * 4 + e] = pr[e]; dsv[e2 * 4 + e] = ds[e]; }
+                    for (int e = 0; e < 4; ++e) { pv[e2 * 4 + e] = pd[e]; dsv[e2 * 4 + e] = ds[e]; }
                 }
                 const bf16x8 pa = pack8(pv), da = pack8(dsv);
 #pragma unroll
@@ -839,7 +889,8 @@ static int launch_bwd(const AttnArgs& p, int rows, hipStream_t st) {
 
 extern "C" int svla_attn_fwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t* V, long ld, bf16_t* O, long ldo, float* LSE,
                                   int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj,
-                                  const float* bias, const unsigned char* kvalid, int Sq, long ldq, int kv_rows, void* stream) {
+                                  const float* bias, const unsigned char* kvalid, int Sq, long ldq, int kv_rows, const svla_dropout* drop,
+                                  void* stream) {
     if (head_dim != HD || rows <= 0 || S <= 0 || S > 512 || (ld % 8) || H <= 0 || (kv_rows > 0 && kv_rows < S)) return SVLA_EINVAL;
     if (mask_mode == MASK_BLOCK_CAUSAL && !traj) return SVLA_EINVAL;
     if (Sq < 0 || Sq > S || (Sq > 0 && (ldq % 8))) return SVLA_EINVAL;
@@ -848,6 +899,7 @@ extern "C" int svla_attn_fwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t
     p.S = S; p.H = H; p.mask_mode = mask_mode; p.scale = scale;
     p.Sq = Sq > 0 ? Sq : S; p.ldq = Sq > 0 ? ldq : ld;
     p.kv_rows = kv_rows > 0 ? kv_rows : S;
+    p.drop = drop_cfg(drop);
     hipStream_t st = (hipStream_t)stream;
     if (S <= 64) return launch_fwd<4>(p, rows, st);
     if (S <= 128) return launch_fwd<8>(p, rows, st);
@@ -860,7 +912,8 @@ extern "C" int svla_attn_fwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t
 extern "C" int svla_attn_bwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t* V, long ld, const bf16_t* O, long ldo,
                                   const float* LSE, const bf16_t* dO, long lddo, bf16_t* dQ, bf16_t* dK, bf16_t* dV, long ldd,
                                   int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj,
-                                  const float* bias, const unsigned char* kvalid, int Sq, long ldq, long lddq, float* D_ws, void* stream) {
+                                  const float* bias, const unsigned char* kvalid, int Sq, long ldq, long lddq, float* D_ws,
+                                  const svla_dropout* drop, void* stream) {
     if (head_dim != HD || rows <= 0 || S <= 0 || S > 256 || (ld % 8) || (lddo % 8) || H <= 0) return SVLA_EINVAL;
     if (mask_mode == MASK_BLOCK_CAUSAL && !traj) return SVLA_EINVAL;
     if (Sq < 0 || Sq > S || (Sq > 0 && ((ldq % 8) || (lddq % 8)))) return SVLA_EINVAL;
@@ -868,7 +921,7 @@ extern "C" int svla_attn_bwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t
     p.Sq = Sq > 0 ? Sq : S; p.ldq = Sq > 0 ? ldq : ld; p.lddq = Sq > 0 ? lddq : ldd; p.kv_rows = S;
     p.Q = Q; p.K = K; p.V = V; p.ld = ld; p.O = (bf16_t*)O; p.ldo = ldo; p.LSE = (float*)LSE; p.dO = dO; p.lddo = lddo;
     p.dQ = dQ; p.dK = dK; p.dV = dV; p.ldd = ldd; p.traj = traj; p.bias = bias; p.kvalid = kvalid;
-    p.S = S; p.H = H; p.mask_mode = mask_mode; p.scale = scale; p.Dws = D_ws;
+    p.S = S; p.H = H; p.mask_mode = mask_mode; p.scale = scale; p.Dws = D_ws; p.drop = drop_cfg(drop);
     hipStream_t st = (hipStream_t)stream;
     if (S <= 64) return launch_bwd<4>(p, rows, st);
     if (S <= 128) return launch_bwd<8>(p, rows, st);

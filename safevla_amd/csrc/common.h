@@ -64,3 +64,29 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     } while (0)
 
 static inline int svla_launch_status() { return (int)hipGetLastError(); }
+
+// ---- counter-based dropout (definition in include/svla.h: svla_dropout) ----------------------------------------------------
+struct svla_dropout { unsigned seed, stream; float p; int row_mult; };
+struct DropCfg { unsigned key, thr; float scale; int row_mult; };   // thr == 0: off
+__host__ __device__ inline DropCfg drop_cfg(const svla_dropout* d) {
+    DropCfg c{0u, 0u, 1.f, 1};
+    if (d && d->p > 0.f) {
+        c.key = d->seed ^ (d->stream * 0xC2B2AE3Du);
+        c.thr = (unsigned)(d->p * 65536.f + 0.5f);
+        c.scale = 1.f / (1.f - d->p);
+        c.row_mult = d->row_mult > 0 ? d->row_mult : 1;
+    }
+    return c;
+}
+// 32 random bits for the element pair (e >> 1): low half -> even element, high half -> odd element
+__device__ __forceinline__ unsigned drop_bits(unsigned key, unsigned long long pair) {
+    unsigned x = ((unsigned)pair * 0x9E3779B1u) ^ ((unsigned)(pair >> 32) * 0x85EBCA77u) ^ key;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+// keep-mask (bit i <=> element e0 + i kept) of 4 consecutive elements, e0 % 4 == 0
+__device__ __forceinline__ unsigned drop_keep4(const DropCfg& c, unsigned long long e0) {
+    const unsigned r0 = drop_bits(c.key, e0 >> 1), r1 = drop_bits(c.key, (e0 >> 1) + 1);
+    return ((r0 & 0xffffu) >= c.thr ? 1u : 0u) | ((r0 >> 16) >= c.thr ? 2u : 0u) | ((r1 & 0xffffu) >= c.thr ? 4u : 0u) | ((r1 >> 16) >= c.thr ? 8u : 0u);
+}
+

@@ -43,6 +43,7 @@ struct GemmNtArgs {
     float alpha;
     unsigned char* bits_out;          // act == ReLU: also write the output's sign bits (blocked layout, see relu_bits_word)
     const unsigned char* bits_in;     // ReLU mask given as such bits instead of a bf16 activation tensor (relu_mask)
+    DropCfg drop;                     // train-mode dropout after the activation, before the residual add (thr == 0: off)
     int dbg;          // timing-only ablations of the 256-tile kernel (tools/ab_gemm.py): 1 = no C stores, 2 = no epilogue
 };
 
@@ -232,12 +233,20 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p)
         const f32x4 a = *(const f32x4*)(Cs + row * CS + ecc * 8), b = *(const f32x4*)(Cs + row * CS + ecc * 8 + 4);
         float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
         u32x4 w;
-        unsigned obits = 0;
+        unsigned obits = 0, dkeep = 0;
+        if (p.drop.thr) {
+            const unsigned long long e0 = (unsigned long long)m * p.drop.row_mult * p.N + n0 + ecc * 8;
+            dkeep = drop_keep4(p.drop, e0) | (drop_keep4(p.drop, e0 + 4) << 4);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float lo = v[2 * e] + ebias[2 * e], hi = v[2 * e + 1] + ebias[2 * e + 1];
             if (p.act == ACT_RELU) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
             else if (p.act == ACT_GELU) { lo = gelu_f(lo); hi = gelu_f(hi); }
+            if (p.drop.thr) {
+                lo = ((dkeep >> (2 * e)) & 1u) ? lo * p.drop.scale : 0.f;
+                hi = ((dkeep >> (2 * e + 1)) & 1u) ? hi * p.drop.scale : 0.f;
+            }
             if (p.relu_mask) {
                 if (!(bf_lo(emask[j][e]) > 0.f)) lo = 0.f;
                 if (!(bf_hi(emask[j][e]) > 0.f)) hi = 0.f;
@@ -451,6 +460,11 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
                             if (ACT == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
                             else if (ACT == ACT_GELU) v[e] = gelu_f(v[e]);
                         }
+                        if (p.drop.thr) {      // wave-uniform
+                            const unsigned keep = drop_keep4(p.drop, (unsigned long long)m * p.drop.row_mult * p.N + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = ((keep >> e) & 1u) ? v[e] * p.drop.scale : 0.f;
+                        }
                         if (HAS_MASK) {
                             const u32x2 mk = HAS_RES ? *(const u32x2*)(p.relu_mask + (size_t)mc * p.ldm + n) : *(const u32x2*)(Es + e_wr + (((j * 4 + rg) ^ e_sw) << 4));
                             if (!(bf_lo(mk[0]) > 0.f)) v[0] = 0.f;
@@ -543,12 +557,12 @@ extern "C" int svla_gemm_force_small_tile(int on) {
 extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, long ldb, const float* bias,
                                  const bf16_t* residual, long ldr, const bf16_t* relu_mask, long ldm, void* C, long ldc,
                                  int M, int N, int K, int act, int out_f32, float alpha, unsigned char* relu_bits_out,
-                                 const unsigned char* relu_bits, void* stream) {
+                                 const unsigned char* relu_bits, const svla_dropout* drop, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || (N % BN) || (K % BK)) return SVLA_EINVAL;
     if ((relu_bits && (relu_mask || residual || out_f32)) || (relu_bits_out && (act != ACT_RELU || out_f32 || residual || relu_mask || relu_bits))) return SVLA_EINVAL;
     if (act < ACT_NONE || act > ACT_GELU) return SVLA_EINVAL;
     if ((lda % 8) || (ldb % 8) || (ldc % (out_f32 ? 4 : 8)) || (residual && (ldr % 8)) || (relu_mask && (ldm % 8))) return SVLA_EINVAL;
-    GemmNtArgs p{A, lda, B, ldb, bias, residual, ldr, relu_mask, ldm, C, ldc, M, N, K, act, out_f32, alpha, relu_bits_out, relu_bits, g_dbg};
+    GemmNtArgs p{A, lda, B, ldb, bias, residual, ldr, relu_mask, ldm, C, ldc, M, N, K, act, out_f32, alpha, relu_bits_out, relu_bits, drop_cfg(drop), g_dbg};
     if (!out_f32 && (N % 256) == 0 && (K % BK64) == 0 && K >= 2 * BK64 && (long)((M + 255) / 256) * (N / 256) >= 256 && !g_force_small_tile) {
         static int n_cu = 0;
         if (!n_cu) {

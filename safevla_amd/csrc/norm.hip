@@ -87,7 +87,7 @@ __global__ void norm_bwd_kernel(const bf16_t* __restrict__ dy, RowMap dymap, con
                                 const float* __restrict__ mean, const float* __restrict__ rstd_in, int rows, int rms,
                                 int relu, int tok_group, const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
                                 RowMap dxmap, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                float* __restrict__ dtok) {
+                                float* __restrict__ dtok, bf16_t* __restrict__ dx_drop, DropCfg drop) {
     constexpr int VPL = D / 64;
     __shared__ float red[4][4 * D];  // [wave][dgamma | dbeta | dtok0 | dtok1]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -129,6 +129,17 @@ __global__ void norm_bwd_kernel(const bf16_t* __restrict__ dy, RowMap dymap, con
             for (int i = 0; i < VPL; ++i) xv[i] += rv[i];
         }
         store_row_bf16<VPL>(dx + map_row(dxmap, m) * D + lane * VPL, xv);
+        if (dx_drop) {
+            // gradient through the dropout on the sub-layer output that was added to the residual stream before this norm
+            // (x + dropout(sublayer(x))): the same keep-mask as the forward GEMM epilogue, regenerated from the element index
+#pragma unroll
+            for (int q4 = 0; q4 < VPL / 4; ++q4) {
+                const unsigned keep = drop.thr ? drop_keep4(drop, (unsigned long long)m * drop.row_mult * D + lane * VPL + q4 * 4) : 0xfu;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[q4 * 4 + e] = ((keep >> e) & 1u) ? xv[q4 * 4 + e] * drop.scale : 0.f;
+            }
+            store_row_bf16<VPL>(dx_drop + (size_t)m * D + lane * VPL, xv);
+        }
     }
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
@@ -172,13 +183,14 @@ extern "C" int svla_norm_fwd_bf16(const bf16_t* x, int xG, int xGS, int xOFF, co
 extern "C" int svla_norm_bwd_bf16(const bf16_t* dy, int dyG, int dyGS, int dyOFF, const bf16_t* x, int xG, int xGS, int xOFF,
                                   const float* gamma, const float* beta, const float* mean, const float* rstd, int rows,
                                   int D, int rms, int relu, int tok_group, const bf16_t* dres, bf16_t* dx, int dxG, int dxGS,
-                                  int dxOFF, float* dgamma, float* dbeta, float* dtok, void* stream) {
+                                  int dxOFF, float* dgamma, float* dbeta, float* dtok, bf16_t* dx_drop, const svla_dropout* drop,
+                                  void* stream) {
     if (rows <= 0 || D != 512) return SVLA_EINVAL;
     if (dtok && tok_group <= 0) return SVLA_EINVAL;
     RowMap dym{dyG, dyGS, dyOFF}, xm{xG, xGS, xOFF}, dxm{dxG, dxGS, dxOFF};
     int blocks = norm_grid(rows);
     if (blocks > 512) blocks = 512;  // fewer, fatter blocks: each ends with 4*D atomics
     hipLaunchKernelGGL(norm_bwd_kernel<512>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, dym, x, xm, gamma, beta, mean,
-                       rstd, rows, rms, relu, tok_group > 0 ? tok_group : 1, dres, dx, dxm, dgamma, dbeta, dtok);
+                       rstd, rows, rms, relu, tok_group > 0 ? tok_group : 1, dres, dx, dxm, dgamma, dbeta, dtok, dx_drop, drop_cfg(drop));
     return svla_launch_status();
 }

@@ -115,6 +115,11 @@ class Tower(nn.Module):
         self.max_steps = max_steps
         self.time_step_counter = 0
         self.prune_last = True      # dead-output elimination in the last fusion layer (exact; see run_forward)
+        # The reference leaves the policy in train() mode (allenact_dino_transformer.py:193): nn.TransformerEncoderLayer's
+        # dropout 0.1 is active in rollouts and updates.  Same here: ``.eval()`` turns it off (parity fixtures are eval-mode).
+        self.dropout_p = 0.1
+        self.drop_seed_base = 0x5AFE + 977 * len(arena.specs)   # distinct per tower; settable for reproducible tests
+        self._fwd_count = 0
         dec = arena.declare
         ve = self.visual_encoder = _NS()
         dec(ve, "fusion_token", (D,), "tok")
@@ -207,6 +212,20 @@ class Tower(nn.Module):
             off, _ = ar.offsets[id(ps[0])]
             ops.transpose_cast_bf16(ar.flat_p[off:off + n * k].view(n, k), self._wt[key])
 
+    def _drop_sites(self):
+        """Dropout descriptors of one forward pass: site(layer, k), k = 0 attention probabilities, 1 attention sub-layer output,
+        2 feed-forward activation, 3 feed-forward sub-layer output; None in eval mode.  The pass seed is saved with the
+        activations so that the backward regenerates the same masks."""
+        if not self.training or self.dropout_p <= 0:
+            return None, (lambda i, k, rm=1: None)
+        self._fwd_count += 1
+        seed = (self.drop_seed_base * 0x9E3779B1 + self._fwd_count * 0x85EBCA77) & 0xFFFFFFFF
+        return seed, self._site_fn(seed)
+
+    def _site_fn(self, seed):
+        p = self.dropout_p
+        return (lambda i, k, rm=1: ops.Dropout(seed, 4 * i + k, p, rm)) if seed is not None else (lambda i, k, rm=1: None)
+
     def g(self, p):  # fp32 grad view of a parameter
         return self.arena.slab(p, self.arena.flat_g)
 
@@ -228,6 +247,7 @@ class Tower(nn.Module):
         ve, w = self.visual_encoder, self._w
         M2, M = R * 2 * NPATCH, R * S
         c = {}  # saved activations
+        c["drop_seed"], site = self._drop_sites()
         tok = prep.tokens.view(M2, DINO)
         c1 = ops.gemm_nt(tok, w["c1"], M2, D, DINO, bias=ve.visual_compressor[0].bias, act=ops.ACT_RELU)
         c2 = ops.gemm_nt(c1, w["c2"], M2, D, D, bias=ve.visual_compressor[2].bias, act=ops.ACT_RELU)
@@ -252,24 +272,24 @@ class Tower(nn.Module):
                 b_in = l.self_attn.in_proj_bias
                 kv = ops.gemm_nt(xf, w[f"f{i}.in"][D:], M, 2 * D, D, bias=b_in[D:])
                 q0 = ops.gemm_nt(xf, w[f"f{i}.in"][:D], R, D, D, bias=b_in[:D], lda=S * D)
-                ao, lse = ops.attn_fwd(q0, kv, kv[:, D:], 2 * D, R, S, 8, 0.125, save_lse=need_grad, Sq=1, ldq=D)
-                h1 = ops.gemm_nt(ao, w[f"f{i}.out"], R, D, D, bias=l.self_attn.out_proj.bias, residual=xf, ldr=S * D)
+                ao, lse = ops.attn_fwd(q0, kv, kv[:, D:], 2 * D, R, S, 8, 0.125, save_lse=need_grad, Sq=1, ldq=D, drop=site(i, 0))
+                h1 = ops.gemm_nt(ao, w[f"f{i}.out"], R, D, D, bias=l.self_attn.out_proj.bias, residual=xf, ldr=S * D, drop=site(i, 1, S))
                 x1, m1, r1 = ops.norm_fwd(h1, l.norm1.weight, l.norm1.bias, 1e-5, R, save_stats=need_grad)
-                f1 = ops.gemm_nt(x1, w[f"f{i}.l1"], R, 2048, D, bias=l.linear1.bias, act=ops.ACT_RELU)
-                h2 = ops.gemm_nt(f1, w[f"f{i}.l2"], R, D, 2048, bias=l.linear2.bias, residual=x1)
+                f1 = ops.gemm_nt(x1, w[f"f{i}.l1"], R, 2048, D, bias=l.linear1.bias, act=ops.ACT_RELU, drop=site(i, 2, S))
+                h2 = ops.gemm_nt(f1, w[f"f{i}.l2"], R, D, 2048, bias=l.linear2.bias, residual=x1, drop=site(i, 3, S))
                 xo, m2, r2 = ops.norm_fwd(h2, l.norm2.weight, l.norm2.bias, 1e-5, R, save_stats=need_grad)
                 if need_grad:
                     fl.append(dict(pruned=True, x=xf, kv=kv, q0=q0, ao=ao, lse=lse, h1=h1, x1=x1, n1=(m1, r1), f1=f1, h2=h2, n2=(m2, r2)))
                 xf, xf_stride = xo, D
                 continue
             qkv = ops.gemm_nt(xf, w[f"f{i}.in"], M, 3 * D, D, bias=l.self_attn.in_proj_bias)
-            ao, lse = ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, R, S, 8, 0.125, save_lse=need_grad)
-            h1 = ops.gemm_nt(ao, w[f"f{i}.out"], M, D, D, bias=l.self_attn.out_proj.bias, residual=xf)
+            ao, lse = ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, R, S, 8, 0.125, save_lse=need_grad, drop=site(i, 0))
+            h1 = ops.gemm_nt(ao, w[f"f{i}.out"], M, D, D, bias=l.self_attn.out_proj.bias, residual=xf, drop=site(i, 1))
             x1, m1, r1 = ops.norm_fwd(h1, l.norm1.weight, l.norm1.bias, 1e-5, M, save_stats=need_grad)
             # the ReLU derivative is kept as 1 bit per element (M x 256 bytes): the input-gradient GEMM then reads 16x fewer mask bytes
             f1b = torch.empty(ops.relu_bits_bytes(M, 2048), device=x1.device, dtype=torch.uint8) if need_grad else None
-            f1 = ops.gemm_nt(x1, w[f"f{i}.l1"], M, 2048, D, bias=l.linear1.bias, act=ops.ACT_RELU, relu_bits_out=f1b)
-            h2 = ops.gemm_nt(f1, w[f"f{i}.l2"], M, D, 2048, bias=l.linear2.bias, residual=x1)
+            f1 = ops.gemm_nt(x1, w[f"f{i}.l1"], M, 2048, D, bias=l.linear1.bias, act=ops.ACT_RELU, relu_bits_out=f1b, drop=site(i, 2))
+            h2 = ops.gemm_nt(f1, w[f"f{i}.l2"], M, D, 2048, bias=l.linear2.bias, residual=x1, drop=site(i, 3))
             xo, m2, r2 = ops.norm_fwd(h2, l.norm2.weight, l.norm2.bias, 1e-5, M, save_stats=need_grad)
             if need_grad:
                 fl.append(dict(pruned=False, x=xf, qkv=qkv, ao=ao, lse=lse, h1=h1, x1=x1, n1=(m1, r1), f1=f1, f1b=f1b, h2=h2, n2=(m2, r2)))
@@ -375,22 +395,34 @@ class Tower(nn.Module):
             ops.decoder_embed_bwd(dx, prep.prev_actions, prep.masks, prep.hand, T, B, dxf, S * D, g(self.last_actions_embed.weight),
                                   g(self.object_in_hand_embed.weight))
             dyf = dxf.view(M, D)
+        site = self._site_fn(c.get("drop_seed"))
+        drop_scale = 1.0 / (1.0 - self.dropout_p) if c.get("drop_seed") is not None else 1.0
+        def masked_like(t, on):   # second norm_bwd output: the gradient of the dropped-out sub-layer output
+            return torch.empty_like(t) if on else None
         for i in reversed(range(len(ve.fusion_xformer.layers))):
             l, a = ve.fusion_xformer.layers[i], c["fusion"][i]
             if a["pruned"]:
-                dh2 = ops.norm_bwd(dyf, a["h2"], l.norm2.weight, l.norm2.bias, a["n2"][0], a["n2"][1], R, g(l.norm2.weight), g(l.norm2.bias))
-                ops.gemm_tn_acc(dh2, a["f1"], dw[f"f{i}.l2"], R, D, 2048, db=g(l.linear2.bias))
-                df1 = ops.gemm_nt(dh2, wt[f"f{i}.l2"], R, 2048, D, relu_mask=a["f1"])
+                d3, d1 = site(i, 3, S), site(i, 1, S)
+                df = masked_like(a["h2"], d3 is not None)
+                dh2 = ops.norm_bwd(dyf, a["h2"], l.norm2.weight, l.norm2.bias, a["n2"][0], a["n2"][1], R, g(l.norm2.weight), g(l.norm2.bias),
+                                   dx_drop=df, drop=d3)
+                df = dh2 if df is None else df           # grad of linear2's output (through dropout2); dh2 = residual-path grad
+                ops.gemm_tn_acc(df, a["f1"], dw[f"f{i}.l2"], R, D, 2048, db=g(l.linear2.bias))
+                # f1 is stored after ReLU and dropout: f1 > 0 <=> (pre-activation > 0 and kept); alpha = the dropout scale
+                df1 = ops.gemm_nt(df, wt[f"f{i}.l2"], R, 2048, D, relu_mask=a["f1"], alpha=drop_scale)
                 ops.gemm_tn_acc(df1, a["x1"], dw[f"f{i}.l1"], R, 2048, D, db=g(l.linear1.bias))
                 dx1 = ops.gemm_nt(df1, wt[f"f{i}.l1"], R, D, 2048, residual=dh2)
-                dh1 = ops.norm_bwd(dx1, a["h1"], l.norm1.weight, l.norm1.bias, a["n1"][0], a["n1"][1], R, g(l.norm1.weight), g(l.norm1.bias))
-                ops.gemm_tn_acc(dh1, a["ao"], dw[f"f{i}.out"], R, D, D, db=g(l.self_attn.out_proj.bias))
-                dao = ops.gemm_nt(dh1, wt[f"f{i}.out"], R, D, D)
+                da = masked_like(a["h1"], d1 is not None)
+                dh1 = ops.norm_bwd(dx1, a["h1"], l.norm1.weight, l.norm1.bias, a["n1"][0], a["n1"][1], R, g(l.norm1.weight), g(l.norm1.bias),
+                                   dx_drop=da, drop=d1)
+                da = dh1 if da is None else da
+                ops.gemm_tn_acc(da, a["ao"], dw[f"f{i}.out"], R, D, D, db=g(l.self_attn.out_proj.bias))
+                dao = ops.gemm_nt(da, wt[f"f{i}.out"], R, D, D)
                 dq0 = torch.empty(R, D, device=dev, dtype=BF16)
                 dkv = torch.empty(M, 2 * D, device=dev, dtype=BF16)
                 kv = a["kv"]
                 ops.attn_bwd(a["q0"], kv, kv[:, D:], 2 * D, a["ao"], D, a["lse"], dao, D, dq0, dkv, dkv[:, D:], 2 * D, R, S, 8, 0.125,
-                             Sq=1, ldq=D, lddq=D)
+                             Sq=1, ldq=D, lddq=D, drop=site(i, 0))
                 gb = g(l.self_attn.in_proj_bias)
                 ops.gemm_tn_acc(dkv, a["x"], dw[f"f{i}.in"][D:], M, 2 * D, D, db=gb[D:])
                 ops.gemm_tn_acc(dq0, a["x"], dw[f"f{i}.in"][:D], R, D, D, ldx=S * D, db=gb[:D])
@@ -399,19 +431,27 @@ class Tower(nn.Module):
                 ops.rows_add(dyf, S * D, t0, D, R)
                 c["fusion"][i] = None
                 continue
-            dh2 = ops.norm_bwd(dyf, a["h2"], l.norm2.weight, l.norm2.bias, a["n2"][0], a["n2"][1], M, g(l.norm2.weight), g(l.norm2.bias))
-            ops.gemm_tn_acc(dh2, a["f1"], dw[f"f{i}.l2"], M, D, 2048, db=g(l.linear2.bias))
-            df1 = ops.gemm_nt(dh2, wt[f"f{i}.l2"], M, 2048, D, relu_bits=a["f1b"])
+            d3, d1 = site(i, 3), site(i, 1)
+            df = masked_like(a["h2"], d3 is not None)
+            dh2 = ops.norm_bwd(dyf, a["h2"], l.norm2.weight, l.norm2.bias, a["n2"][0], a["n2"][1], M, g(l.norm2.weight), g(l.norm2.bias),
+                               dx_drop=df, drop=d3)
+            df = dh2 if df is None else df               # grad of linear2's output (through dropout2); dh2 = residual-path grad
+            ops.gemm_tn_acc(df, a["f1"], dw[f"f{i}.l2"], M, D, 2048, db=g(l.linear2.bias))
+            # the sign bits were taken after ReLU and dropout: bit <=> (pre-activation > 0 and kept); alpha = the dropout scale
+            df1 = ops.gemm_nt(df, wt[f"f{i}.l2"], M, 2048, D, relu_bits=a["f1b"], alpha=drop_scale)
             ops.gemm_tn_acc(df1, a["x1"], dw[f"f{i}.l1"], M, 2048, D, db=g(l.linear1.bias))
             dx1 = ops.gemm_nt(df1, wt[f"f{i}.l1"], M, D, 2048, residual=dh2)
-            del df1
-            dh1 = ops.norm_bwd(dx1, a["h1"], l.norm1.weight, l.norm1.bias, a["n1"][0], a["n1"][1], M, g(l.norm1.weight), g(l.norm1.bias))
-            ops.gemm_tn_acc(dh1, a["ao"], dw[f"f{i}.out"], M, D, D, db=g(l.self_attn.out_proj.bias))
-            dao = ops.gemm_nt(dh1, wt[f"f{i}.out"], M, D, D)
+            del df1, df
+            da = masked_like(a["h1"], d1 is not None)
+            dh1 = ops.norm_bwd(dx1, a["h1"], l.norm1.weight, l.norm1.bias, a["n1"][0], a["n1"][1], M, g(l.norm1.weight), g(l.norm1.bias),
+                               dx_drop=da, drop=d1)
+            da = dh1 if da is None else da
+            ops.gemm_tn_acc(da, a["ao"], dw[f"f{i}.out"], M, D, D, db=g(l.self_attn.out_proj.bias))
+            dao = ops.gemm_nt(da, wt[f"f{i}.out"], M, D, D)
             dqkv = torch.empty(M, 3 * D, device=dev, dtype=BF16)
             q = a["qkv"]
             ops.attn_bwd(q, q[:, D:], q[:, 2 * D:], 3 * D, a["ao"], D, a["lse"], dao, D, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D,
-                         R, S, 8, 0.125)
+                         R, S, 8, 0.125, drop=site(i, 0))
             ops.gemm_tn_acc(dqkv, a["x"], dw[f"f{i}.in"], M, 3 * D, D, db=g(l.self_attn.in_proj_bias))
             dyf = ops.gemm_nt(dqkv, wt[f"f{i}.in"], M, D, 3 * D, residual=dh1)
             c["fusion"][i] = None

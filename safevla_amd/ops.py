@@ -1,5 +1,6 @@
 """Stream-aware Python bindings of the C-ABI kernels (include/svla.h).  torch is plumbing only: device memory
 and the current HIP stream.  Every function launches on ``torch.cuda.current_stream()`` and raises on failure."""
+import ctypes
 from typing import Optional, Tuple
 
 import torch
@@ -96,18 +97,43 @@ def norm_fwd(x, gamma, beta, eps, rows, D=512, rms=False, relu=False, tok=None, 
 
 
 def norm_bwd(dy, x, gamma, beta, mean, rstd, rows, dgamma, dbeta, D=512, rms=False, relu=False, dtok=None, tok_group=0,
-             dx=None, dymap=(0, 0, 0), xmap=(0, 0, 0), dxmap=(0, 0, 0), dres=None):
+             dx=None, dymap=(0, 0, 0), xmap=(0, 0, 0), dxmap=(0, 0, 0), dres=None, dx_drop=None, drop=None):
+    """``dx_drop`` (optional [rows, D] output) = dx with the keep-mask / scale of dropout site ``drop`` applied: the gradient of
+    the sub-layer output that was dropped out before being added to the residual stream."""
     _chk(dy, BF16, "dy")
     if dx is None:
         dx = torch.empty(rows, D, device=x.device, dtype=BF16)
     lib().call("svla_norm_bwd_bf16", _p(dy), *dymap, _p(x), *xmap, _p(gamma), _p(beta), _p(mean), _p(rstd), rows, D, int(rms),
-               int(relu), int(tok_group), _p(dres), _p(dx), *dxmap, _p(dgamma), _p(dbeta), _p(dtok), _stream())
+               int(relu), int(tok_group), _p(dres), _p(dx), *dxmap, _p(dgamma), _p(dbeta), _p(dtok), _p(dx_drop), _d(drop), _stream())
     return dx
+
+
+# ------------------------------------------------------------------------------------------------ dropout descriptor
+class _SvlaDropout(ctypes.Structure):
+    _fields_ = [("seed", ctypes.c_uint), ("stream", ctypes.c_uint), ("p", ctypes.c_float), ("row_mult", ctypes.c_int)]
+
+
+class Dropout:
+    """``svla_dropout`` of include/svla.h: one dropout site of one forward pass (seed = the pass, stream = the site)."""
+
+    def __init__(self, seed: int, stream: int, p: float, row_mult: int = 1):
+        self.c = _SvlaDropout(seed & 0xFFFFFFFF, stream & 0xFFFFFFFF, float(p), int(row_mult))
+
+    def with_row_mult(self, row_mult: int) -> "Dropout":
+        return Dropout(self.c.seed, self.c.stream, self.c.p, row_mult)
+
+    @property
+    def scale(self) -> float:
+        return 1.0 / (1.0 - self.c.p)
+
+
+def _d(drop):
+    return None if drop is None or drop.c.p <= 0 else ctypes.cast(ctypes.pointer(drop.c), ctypes.c_void_p)
 
 
 # ------------------------------------------------------------------------------------------------ GEMMs
 def gemm_nt(A, B, M, N, K, bias=None, residual=None, relu_mask=None, act=ACT_NONE, out=None, out_f32=False, alpha=1.0,
-            lda=None, ldb=None, ldc=None, ldr=None, ldm=None, relu_bits_out=None, relu_bits=None):
+            lda=None, ldb=None, ldc=None, ldr=None, ldm=None, relu_bits_out=None, relu_bits=None, drop=None):
     """out[M,N] = epi(alpha * A[M,K] @ B[N,K]^T).  A/B bf16; leading dims default to the last-dim stride of 2-D views."""
     _chk(A, BF16, "A")
     _chk(B, BF16, "B")
@@ -119,7 +145,7 @@ def gemm_nt(A, B, M, N, K, bias=None, residual=None, relu_mask=None, act=ACT_NON
     ldr = ldr if ldr is not None else (residual.stride(-2) if residual is not None else 0)
     ldm = ldm if ldm is not None else (relu_mask.stride(-2) if relu_mask is not None else 0)
     lib().call("svla_gemm_nt_bf16", _p(A), lda, _p(B), ldb, _p(bias), _p(residual), ldr, _p(relu_mask), ldm, _p(out), ldc, M, N, K,
-               int(act), int(out_f32), float(alpha), _p(relu_bits_out), _p(relu_bits), _stream())
+               int(act), int(out_f32), float(alpha), _p(relu_bits_out), _p(relu_bits), _d(drop), _stream())
     return out
 
 
@@ -147,7 +173,7 @@ def colsum_acc(dY, db, M, N, ldy=None, row_stride=1):
 
 # ------------------------------------------------------------------------------------------------ attention
 def attn_fwd(q, k, v, ld, rows, S, H, scale, out=None, ldo=None, mask_mode=MASK_NONE, traj=None, bias=None, kvalid=None,
-             save_lse=True, Sq=0, ldq=0, kv_rows=0):
+             save_lse=True, Sq=0, ldq=0, kv_rows=0, drop=None):
     """q/k/v: bf16 views whose element (token, h*64+d) sits at token*ld + h*64 + d.  Sq > 0: only the first Sq queries of
     every row (q then holds Sq rows per batch row with row stride ldq)."""
     nq = Sq if Sq > 0 else S
@@ -156,16 +182,16 @@ def attn_fwd(q, k, v, ld, rows, S, H, scale, out=None, ldo=None, mask_mode=MASK_
     ldo = ldo if ldo is not None else out.stride(-2)
     lse = torch.empty(rows, H, nq, device=q.device, dtype=F32) if save_lse else None
     lib().call("svla_attn_fwd_bf16", _p(q), _p(k), _p(v), ld, _p(out), ldo, _p(lse), rows, S, H, 64, float(scale), mask_mode,
-               _p(traj), _p(bias), _p(kvalid), int(Sq), int(ldq), int(kv_rows), _stream())
+               _p(traj), _p(bias), _p(kvalid), int(Sq), int(ldq), int(kv_rows), _d(drop), _stream())
     return out, lse
 
 
 def attn_bwd(q, k, v, ld, o, ldo, lse, do, lddo, dq, dk, dv, ldd, rows, S, H, scale, mask_mode=MASK_NONE, traj=None,
-             bias=None, kvalid=None, Sq=0, ldq=0, lddq=0, d_ws=None):
+             bias=None, kvalid=None, Sq=0, ldq=0, lddq=0, d_ws=None, drop=None):
     if d_ws is None:   # [rows, H, Sq] fp32 workspace: rowsum(dO * O), handed from the dQ kernel to the dK/dV kernel
         d_ws = torch.empty(rows * H * (Sq or S), device=q.device, dtype=F32)
     lib().call("svla_attn_bwd_bf16", _p(q), _p(k), _p(v), ld, _p(o), ldo, _p(lse), _p(do), lddo, _p(dq), _p(dk), _p(dv), ldd,
-               rows, S, H, 64, float(scale), mask_mode, _p(traj), _p(bias), _p(kvalid), int(Sq), int(ldq), int(lddq), _p(d_ws), _stream())
+               rows, S, H, 64, float(scale), mask_mode, _p(traj), _p(bias), _p(kvalid), int(Sq), int(ldq), int(lddq), _p(d_ws), _d(drop), _stream())
 
 
 # ------------------------------------------------------------------------------------------------ glue

@@ -23,6 +23,7 @@ def agent():
     m = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV)
     fill_state_dict(m, seed=7)
     m.sync_weights()
+    m.eval()        # step-by-step vs full-sequence equality needs the dropout noise off
     g = torch.Generator(device=DEV)
     g.manual_seed(5)
     return InferenceAgentVIDA.build_agent(m, device=DEV, greedy_sampling=False, steps_before_rollout_refresh=4, generator=g)

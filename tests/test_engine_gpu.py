@@ -21,6 +21,7 @@ def setup():
     m = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV)
     fill_state_dict(m, seed=7)
     m.sync_weights()
+    m.eval()        # chunk-accumulation exactness / oracle comparisons need the (row-indexed) dropout noise off
     g = dict(np.load(os.path.join(G, "g5_samelen.npz"), allow_pickle=False))
     return m, g
 

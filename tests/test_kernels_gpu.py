@@ -515,3 +515,89 @@ def test_ce_loss_fwd_bwd_vs_torch(ops):
     assert abs(sums.item() / n_valid.item() - want.item()) < 2e-6 * max(1.0, abs(want.item()))
     assert torch.allclose(dl, logits.grad, rtol=1e-5, atol=1e-8)
     assert (dl[tgt == -1] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------------ train-mode dropout
+def _keep_np(seed, stream, p, idx):
+    from oracle.ref_model import hash_keep
+    return torch.from_numpy(hash_keep(seed, stream, p, idx))
+
+
+@pytest.mark.parametrize("S,mask_mode", [(100, 0), (181, 0), (40, 1)])
+def test_attn_dropout_fwd_bwd_vs_hash_reference(ops, S, mask_mode):
+    """Dropout on the attention probabilities: generic kernels (S = 100, block-causal S = 40) and the persistent-forward /
+    exact-tile backward kernels (S = 181) against torch with the SAME counter-based masks (include/svla.h: svla_dropout)."""
+    from oracle.ref_model import hash_dropout
+    rows, H, scale, p = 3, 8, 0.125, 0.1
+    drop = ops.Dropout(seed=0xC0FFEE, stream=8, p=p)
+    qkv = bf(rnd(rows * S, 3 * H * 64, seed=11))
+    d_qkv = qkv.to(DEV).bfloat16()
+    ld = 3 * H * 64
+    q, k, v = [qkv[:, i * H * 64:(i + 1) * H * 64].view(rows, S, H, 64).transpose(1, 2).clone().requires_grad_(True) for i in range(3)]
+    traj = None
+    s = (q @ k.transpose(-1, -2)) * scale
+    if mask_mode == 1:
+        g = torch.Generator().manual_seed(3)
+        traj = torch.sort(torch.randint(0, 3, (rows, S), generator=g), dim=1).values
+        s = s.masked_fill(~torch.tril(traj[:, :, None] == traj[:, None, :])[:, None], float("-inf"))
+    pr = hash_dropout(torch.softmax(s, -1), 0xC0FFEE, 8, p, attn_S=S)
+    want = pr @ v
+    kw = dict(mask_mode=mask_mode, traj=None if traj is None else traj.int().to(DEV), drop=drop)
+    out, lse = ops.attn_fwd(d_qkv, d_qkv[:, H * 64:], d_qkv[:, 2 * H * 64:], ld, rows, S, H, scale, **kw)
+    close(out.float().view(rows, S, H, 64), want.transpose(1, 2), 1e-2, 1e-2, f"O drop S={S}")
+    nodrop, _ = ops.attn_fwd(d_qkv, d_qkv[:, H * 64:], d_qkv[:, 2 * H * 64:], ld, rows, S, H, scale, mask_mode=mask_mode, traj=kw["traj"])
+    assert (nodrop.float() - out.float()).abs().max() > 0.05         # the mask really is applied
+    do = bf(rnd(rows * S, H * 64, seed=12))
+    want.backward(do.view(rows, S, H, 64).transpose(1, 2))
+    dqkv = torch.zeros_like(d_qkv)
+    ops.attn_bwd(d_qkv, d_qkv[:, H * 64:], d_qkv[:, 2 * H * 64:], ld, out, H * 64, lse, do.to(DEV).bfloat16(), H * 64,
+                 dqkv, dqkv[:, H * 64:], dqkv[:, 2 * H * 64:], ld, rows, S, H, scale, **kw)
+    for i, (n, t) in enumerate((("dQ", q), ("dK", k), ("dV", v))):
+        w = t.grad.transpose(1, 2)
+        close(dqkv[:, i * H * 64:(i + 1) * H * 64].float().view(rows, S, H, 64), w, 2e-2, 2e-2 * w.abs().max().item() + 1e-3, f"{n} drop S={S}")
+
+
+@pytest.mark.parametrize("M,force_small,row_mult", [(700, True, 1), (256 * 300 + 77, False, 1), (256 * 300, False, 3)])
+def test_gemm_nt_epilogue_dropout(ops, M, force_small, row_mult):
+    """Dropout in the NT-GEMM epilogue (after the activation, before the residual add), 128- and 256-tile kernels, row_mult > 1
+    (only every row_mult-th row of the logical tensor is materialised), and its interplay with the ReLU sign bits."""
+    N, K, p = 512, 256, 0.1
+    A = bf(rnd(M, K, seed=21)); B = bf(rnd(N, K, seed=22, scale=0.1)); bias = rnd(N, seed=23, scale=0.1); res = bf(rnd(M, N, seed=24))
+    drop = ops.Dropout(seed=77, stream=5, p=p, row_mult=row_mult)
+    idx = (np.arange(M, dtype=np.uint64)[:, None] * np.uint64(row_mult * N)) + np.arange(N, dtype=np.uint64)[None, :]
+    keep = _keep_np(77, 5, p, idx).float()
+    assert abs(keep.mean().item() - 0.9) < 5e-3
+    d = lambda t: t.to(DEV).bfloat16()
+    ops.gemm_force_small_tile(force_small)
+    try:
+        y = ops.gemm_nt(d(A), d(B), M, N, K, bias=bias.to(DEV), residual=d(res), drop=drop)
+        want = bf((A @ B.t() + bias) * keep / (1 - p) + res)
+        close(y.float(), want, 1e-2, 2e-2, "sub-layer output dropout")
+        bits = torch.zeros(ops.relu_bits_bytes(M, N), device=DEV, dtype=torch.uint8)
+        h = ops.gemm_nt(d(A), d(B), M, N, K, bias=bias.to(DEV), act=ops.ACT_RELU, relu_bits_out=bits, drop=drop)
+        want_h = torch.relu(A @ B.t() + bias) * keep / (1 - p)
+        close(h.float(), want_h, 1e-2, 2e-2, "activation dropout")
+        assert ((h.float() == 0) | (keep.to(DEV) > 0)).all()            # every dropped element is exactly zero
+        dY = d(bf(rnd(M, K, seed=25))); W = d(bf(rnd(N, K, seed=26, scale=0.1)))
+        a = ops.gemm_nt(dY, W, M, N, K, relu_mask=h, alpha=1 / (1 - p))
+        b = ops.gemm_nt(dY, W, M, N, K, relu_bits=bits, alpha=1 / (1 - p))
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))   # bits encode (pre-activation > 0 AND kept)
+    finally:
+        ops.gemm_force_small_tile(False)
+
+
+def test_norm_bwd_dropout_output(ops):
+    """norm_bwd's second output = dx * keep / (1-p): the gradient of the dropped-out sub-layer output feeding the residual stream."""
+    M, D, p, rm = 1000, 512, 0.1, 181
+    x, dy = bf(rnd(M, D, seed=31)), bf(rnd(M, D, seed=32))
+    gamma, beta = 1 + 0.1 * rnd(D, seed=33), 0.1 * rnd(D, seed=34)
+    d = lambda t: t.to(DEV).bfloat16()
+    y, mean, rstd = ops.norm_fwd(d(x), gamma.to(DEV), beta.to(DEV), 1e-5, M)
+    dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    drop = ops.Dropout(seed=5, stream=1, p=p, row_mult=rm)
+    dxd = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    dx = ops.norm_bwd(d(dy), d(x), gamma.to(DEV), beta.to(DEV), mean, rstd, M, dg, db, dx_drop=dxd, drop=drop)
+    idx = (np.arange(M, dtype=np.uint64)[:, None] * np.uint64(rm * D)) + np.arange(D, dtype=np.uint64)[None, :]
+    keep = _keep_np(5, 1, p, idx).to(DEV)
+    assert ((dxd.float() == 0) | keep).all()
+    close(dxd.float()[keep], (dx.float() / (1 - p))[keep], 1e-2, 1e-3, "dx_drop kept elements")

@@ -30,6 +30,7 @@ def model():
     m = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV)
     fill_state_dict(m, seed=7)
     m.sync_weights()
+    m.eval()        # golden vectors are eval-mode (the reference's train-mode dropout is covered by test_train_mode_dropout_vs_oracle)
     return m
 
 
@@ -159,3 +160,74 @@ def test_acting_path_kv_cache_vs_reference(model):
     assert model._kv[0].shape[0] == 2
     for t in model.towers:
         t._kv = None
+
+
+@pytest.mark.parametrize("prune_last", [True, False])
+def test_train_mode_dropout_vs_oracle(model, prune_last):
+    """The reference keeps the policy in train() mode (allenact_dino_transformer.py:193): dropout 0.1 on the attention
+    probabilities, both sub-layer outputs and the feed-forward activation of every fusion layer.  The HIP path regenerates its
+    keep-masks from element indices (include/svla.h: svla_dropout); the oracle applies the SAME masks (oracle.ref_model.hash_dropout),
+    so train-mode outputs and gradients must agree like the eval-mode ones do -- forward, backward, pruned and full last layer."""
+    from oracle import ref_loss, ref_model
+    from oracle.detfill import fill_state_dict, grad_probe
+    from safevla_amd.losses import SafePPOLogGrad, SafePPOValue
+    from safevla_amd.text import GoalTokenizer
+
+    g = _load("g5_samelen.npz")
+    T, B = 3, 2                                   # a slice of the fixture keeps the fp32 CPU oracle at seconds
+    cut = lambda v: v[:T, :B]
+    obs_np = {k[4:]: cut(v) for k, v in g.items() if k.startswith("obs:")}
+    batch_np = {k[6:]: cut(v) for k, v in g.items() if k.startswith("batch:")}
+    pa_np, mk_np = cut(g["prev_actions"]), cut(g["masks"])
+    model.train()
+    seeds = []
+    for k, t in enumerate(model.towers):
+        t.prune_last = prune_last
+        t.drop_seed_base, t._fwd_count = 1000 + k, 0
+        seeds.append(((1000 + k) * 0x9E3779B1 + 1 * 0x85EBCA77) & 0xFFFFFFFF)
+    try:
+        model.zero_grad()
+        aco, _ = model({k: torch.from_numpy(v).to(DEV) for k, v in obs_np.items()}, None, torch.from_numpy(pa_np).to(DEV), torch.from_numpy(mk_np).to(DEV))
+        batch = {k: torch.from_numpy(v).to(DEV) for k, v in batch_np.items()}
+        loss = SafePPOLogGrad(clip_param=0.1, value_loss_coef=0.5, entropy_coef=0.0, use_clipped_value_loss=False,
+                              action_loss_schedule=None, discrete_critics=False, normalize_advantage=False)
+        total, info = loss.loss(0, batch, aco, lagrangian_multiplier=torch.tensor(0.37))
+        c_total, _ = SafePPOValue(clip_param=0.1, use_clipped_value_loss=False).loss(0, batch, aco)
+        (total + c_total).backward()
+    finally:
+        model.eval()
+        for t in model.towers:
+            t.prune_last = True
+    # ---- oracle, train mode, same masks
+    ref = ref_model.RefSafeActorCritic(GoalTokenizer(), max_batch=B, dropout=0.1)
+    fill_state_dict(ref, seed=7)
+    ref.train()
+    for tower, seed in zip([ref, ref.critic_tsfm, ref.c_critic_tsfm], seeds):
+        tower.visual_encoder.text_encoder.eval()          # T5 noise is not part of this comparison
+        for l in tower.visual_encoder.fusion_xformer.layers:
+            l.hash_seed = seed
+    out, _ = ref({k: torch.from_numpy(v) for k, v in obs_np.items()}, None, torch.from_numpy(pa_np), torch.from_numpy(mk_np))
+    rel = lambda a, b: np.abs(a - b).max() / (np.abs(b).max() + 1e-12)
+    e_l = rel(aco.distributions.logits.detach().float().cpu().numpy(), torch.log_softmax(out["logits"], -1).detach().numpy())
+    e_v = rel(aco.values.detach().cpu().numpy(), out["values"].detach().numpy())
+    print(f"[dropout prune_last={prune_last}] rel-to-max err: logits {e_l:.3e} values {e_v:.3e}")
+    assert e_l < 3e-2 and e_v < 3e-2, (e_l, e_v)
+    assert rel(aco.c_values.detach().cpu().numpy(), out["c_values"].detach().numpy()) < 3e-2
+    # eval-mode outputs differ clearly: the masks really are applied
+    with torch.no_grad():
+        ev, _ = model({k: torch.from_numpy(v).to(DEV) for k, v in obs_np.items()}, None, torch.from_numpy(pa_np).to(DEV), torch.from_numpy(mk_np).to(DEV))
+    assert rel(ev.values.cpu().numpy(), out["values"].detach().numpy()) > 5e-2
+    rb = {k: torch.from_numpy(v) for k, v in batch_np.items()}
+    r_total, _ = ref_loss.safe_ppo_log_grad(out["logits"], out["values"], rb, 0.37, clip_param=0.1, value_loss_coef=0.5, entropy_coef=0.0,
+                                            use_clipped_value_loss=False)
+    r_c = ref_loss.safe_ppo_value(out["c_values"], rb["c_returns"])
+    (r_total + r_c).backward()
+    named, rnamed = dict(model.named_parameters()), dict(ref.named_parameters())
+    errs = []
+    for n in g["grad_names"]:
+        n = str(n)
+        nrm, prj = grad_probe(n, named[n].grad)
+        wn, wp = grad_probe(n, rnamed[n].grad)
+        errs.append((abs(nrm - wn) / (wn + 1e-12), n))
+    errs.sort(reverse=True)
+    assert np.median([e for e, _ in errs]) < 2e-2 and errs[0][0] < 1e-1, errs[:5]
