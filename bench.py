@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--env-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eval-mode", action="store_true", help="dropout off (the reference trains with the policy in train() mode: default here too)")
     args = ap.parse_args()
 
     from safevla_amd import ops, parallel
@@ -182,6 +183,9 @@ def main():
     dev = torch.device("cuda", local)
     torch.manual_seed(1234 + rank)
     model = SafeDinoLLAMATxNavActorCriticSeparate(device=dev)
+    model.train(not args.eval_mode)
+    for k, t in enumerate(model.towers):
+        t.drop_seed_base += 7919 * rank          # independent dropout noise per rank
     if world > 1:  # identical initial weights on every rank
         torch.distributed.broadcast(model.arena.flat_p, src=0)
         for t in model.towers:
@@ -260,7 +264,8 @@ def main():
                "config": {"workload": f"C4-shard: {args.task}, T={T}-step rollout x {B} envs/GPU (BASELINE configs[3] per-GPU shard), "
                                       f"L={args.L} goal tokens, S={S} fusion tokens, 3 towers x 4 epochs x 1 minibatch, Adam+clip",
                           "global_envs": B * world, "rollout_steps": T, "rows_per_gpu": R, "parallelism": f"dp{world}",
-                          "stage_losses": list(cfg.stage_losses), "weights": "random-init, reference geometry (168.9 M params)"},
+                          "stage_losses": list(cfg.stage_losses), "weights": "random-init, reference geometry (168.9 M params)",
+                          "dropout": 0.0 if args.eval_mode else 0.1},
                "reference_equivalent_tflop_per_update": round(algo / 1e12, 1),
                "note": "reference_equivalent counts SURVEY 8(d) FLOPs of the reference's schedule; the engine executes fewer (last fusion "
                        "layer only for the consumed token, T5 once per unique goal) -- see roofline.executed_mfma_*",

@@ -159,6 +159,11 @@ int svla_vit_tokens(const svla_bf16* patch, const float* cls, const float* pos, 
 int svla_adaptive_pool_tokens(const svla_bf16* x, int B, int skip, int gh, int gw, int C, int oh, int ow, int cam, int ncam,
                               svla_bf16* tok_out, float* chw_out, void* stream);
 
+/* In-place dropout of a [rows, N] bf16 activation, element index row*N + col: the two stand-alone sites of the frozen T5 encoder
+ * (after the token embedding, after the final layer norm) that stays in train() mode with the rest of the policy
+ * (allenact_dino_transformer.py:193,599-603). */
+int svla_dropout_bf16(svla_bf16* x, long rows, int N, const svla_dropout* drop, void* stream);
+
 /* ---- optimiser (Adam lr 2e-5, max_grad_norm 0.5: training/online/dinov2_vits_tsfm_base.py:331-334; weight_decay > 0 = the
  * decoupled AdamW of the imitation-learning trainer, training/offline/train_pl.py:283-287) ---------------------------------- */
 int svla_sumsq_f32(const float* g, long n, double* out, void* stream);

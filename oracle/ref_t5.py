@@ -102,20 +102,29 @@ class RefT5Encoder(nn.Module):
         tab = self.encoder.block[0].layer[0].SelfAttention.relative_attention_bias.weight  # (buckets, h)
         return tab[bucket].permute(2, 0, 1)  # (h, L, L)
 
+    hash_seed = None    # tests: apply the counter-based dropout masks of include/svla.h (streams as in model.T5Frozen.encode)
+    drop_p = 0.1
+
     @torch.no_grad()
     def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
         U, L = input_ids.shape
-        x = self.shared(input_ids)
+        if self.hash_seed is not None and self.training:
+            from .ref_model import hash_dropout
+            drop = lambda t, k, attn=0: hash_dropout(t, self.hash_seed, k, self.drop_p, attn)
+        else:
+            drop = lambda t, k, attn=0: t
+        x = drop(self.shared(input_ids), 62)
         bias = self.position_bias(L, x.device)[None]  # (1,h,L,L)
         bias = bias + (1.0 - attention_mask[:, None, None, :].float()) * torch.finfo(torch.float32).min
-        for blk in self.encoder.block:
+        for bi, blk in enumerate(self.encoder.block):
+            s0 = 64 + 4 * bi
             sa, ln0 = blk.layer[0].SelfAttention, blk.layer[0].layer_norm
             n = ln0(x)
             q = sa.q(n).view(U, L, self.h, self.dk).transpose(1, 2)
             k = sa.k(n).view(U, L, self.h, self.dk).transpose(1, 2)
             v = sa.v(n).view(U, L, self.h, self.dk).transpose(1, 2)
-            p = F.softmax(q @ k.transpose(-1, -2) + bias, dim=-1)  # note: no 1/sqrt(dk) in T5
-            x = x + sa.o((p @ v).transpose(1, 2).reshape(U, L, self.h * self.dk))
+            p = drop(F.softmax(q @ k.transpose(-1, -2) + bias, dim=-1), s0, L)  # note: no 1/sqrt(dk) in T5
+            x = x + drop(sa.o((p @ v).transpose(1, 2).reshape(U, L, self.h * self.dk)), s0 + 1)
             ff, ln1 = blk.layer[1].DenseReluDense, blk.layer[1].layer_norm
-            x = x + ff.wo(F.relu(ff.wi(ln1(x))))
-        return self.encoder.final_layer_norm(x)
+            x = x + drop(ff.wo(drop(F.relu(ff.wi(ln1(x))), s0 + 2)), s0 + 3)
+        return drop(self.encoder.final_layer_norm(x), 63)

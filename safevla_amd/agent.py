@@ -79,6 +79,7 @@ class InferenceAgentVIDA(AbstractAgent):
                 actor_critic.load_state_dict(ckpt, strict=False)
             else:
                 raise ValueError(f"Unknown checkpoint format; found keys {list(ckpt.keys())[:10]}")
+        actor_critic.eval()     # AllenAct's InferenceAgent runs the policy in eval mode (mode="test", inference_agent.py:98-102)
         agent = cls(actor_critic, device=device, greedy_sampling=greedy_sampling, **kw)
         agent.reset()
         return agent

@@ -472,3 +472,32 @@ extern "C" int svla_vit_tokens(const bf16_t* patch, const float* cls, const floa
     hipLaunchKernelGGL(vit_tokens_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, patch, cls, pos, B, NP, C, y);
     return svla_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// In-place dropout of a [rows, N] bf16 activation (N % 8 == 0) with the counter-based masks of include/svla.h: the two
+// stand-alone sites of the frozen T5 encoder (after the token embedding and after the final layer norm; HF T5Stack), whose
+// other dropouts ride in the GEMM / attention epilogues.
+__global__ void dropout_rows_kernel(bf16_t* __restrict__ x, long n8, int N, DropCfg drop) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        u32x4 w = *(u32x4*)(x + i * 8);
+        const unsigned long long e0 = (unsigned long long)i * 8;       // row_mult == 1: flat index
+        const unsigned keep = drop_keep4(drop, e0) | (drop_keep4(drop, e0 + 4) << 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float lo = ((keep >> (2 * e)) & 1u) ? bf_lo(w[e]) * drop.scale : 0.f;
+            const float hi = ((keep >> (2 * e + 1)) & 1u) ? bf_hi(w[e]) * drop.scale : 0.f;
+            w[e] = pack_bf2(lo, hi);
+        }
+        *(u32x4*)(x + i * 8) = w;
+    }
+}
+extern "C" int svla_dropout_bf16(bf16_t* x, long rows, int N, const svla_dropout* drop, void* stream) {
+    if (rows <= 0 || N <= 0 || (N % 8)) return SVLA_EINVAL;
+    const DropCfg c = drop_cfg(drop);
+    if (!c.thr) return SVLA_OK;
+    const long n8 = rows * N / 8;
+    long blocks = (n8 + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dropout_rows_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, n8, N, c);
+    return svla_launch_status();
+}
+

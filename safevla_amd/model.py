@@ -118,6 +118,7 @@ class Tower(nn.Module):
         # The reference leaves the policy in train() mode (allenact_dino_transformer.py:193): nn.TransformerEncoderLayer's
         # dropout 0.1 is active in rollouts and updates.  Same here: ``.eval()`` turns it off (parity fixtures are eval-mode).
         self.dropout_p = 0.1
+        self.t5_dropout = True      # the frozen text encoder's own dropout (also active in the reference's train mode)
         self.drop_seed_base = 0x5AFE + 977 * len(arena.specs)   # distinct per tower; settable for reproducible tests
         self._fwd_count = 0
         dec = arena.declare
@@ -255,7 +256,7 @@ class Tower(nn.Module):
         x = torch.empty(R, S, D, device=self.device_, dtype=BF16)
         _, va_mean, va_rstd = ops.norm_fwd(a1, ve.visual_adapter[1].weight, ve.visual_adapter[1].bias, 1e-5, M2, relu=True,
                                            tok=self._camtok, tok_group=NPATCH, y=x, ymap=(2 * NPATCH, S, 1))
-        t5 = ve.text_encoder.encode(prep.ids, prep.attn_mask)                    # [U*L, 512] bf16, frozen
+        t5 = ve.text_encoder.encode(prep.ids, prep.attn_mask, drop_seed=c["drop_seed"] if self.t5_dropout else None, drop_p=self.dropout_p)   # [U*L, 512] bf16, frozen
         ta = ops.gemm_nt(t5, w["ta"], U * L, D, 512, bias=ve.text_adapter[0].bias)
         tf, ta_mean, ta_rstd = ops.norm_fwd(ta, ve.text_adapter[1].weight, ve.text_adapter[1].bias, 1e-5, U * L, relu=True)
         ops.fusion_fill(ve.fusion_token, tf, prep.gid, x, R, S, L, TEXT_OFF)
@@ -538,25 +539,37 @@ class T5Frozen(nn.Module):
             self._bias_cache[L] = tab[bucket].permute(2, 0, 1).contiguous().float()
         return self._bias_cache[L]
 
+    T5_STREAM = 64      # dropout stream ids of the text encoder: 62 embedding, 63 final, 64 + 4*block + {0 probs, 1 attn out, 2 ff act, 3 ff out}
+
     @torch.no_grad()
-    def encode(self, ids: torch.Tensor, attn_mask: torch.Tensor) -> torch.Tensor:
-        """ids, attn_mask [U, L] int64 (device) -> last_hidden_state [U*L, 512] bf16."""
+    def encode(self, ids: torch.Tensor, attn_mask: torch.Tensor, drop_seed: Optional[int] = None, drop_p: float = 0.1) -> torch.Tensor:
+        """ids, attn_mask [U, L] int64 (device) -> last_hidden_state [U*L, 512] bf16.
+
+        ``drop_seed``: the text encoder is frozen (no_grad) but NOT in eval mode in the reference -- the policy's ``self.train()``
+        (allenact_dino_transformer.py:193) switches HF T5's dropout 0.1 on too -- so in train mode its six
+        dropout sites per block / stack are applied here as well.  One realisation per unique goal and forward pass (the reference
+        re-encodes the goal for every (t, b) row and so draws a fresh mask per row)."""
         if self._rt is None:
             self.sync()
         U, L = ids.shape
         n = U * L
+        site = (lambda k: ops.Dropout(drop_seed, k, drop_p)) if drop_seed is not None and drop_p > 0 else (lambda k: None)
         x = ops.embed_gather(self.shared.weight, ids.reshape(-1).contiguous())
+        ops.dropout_(x, site(62))
         bias = self.position_bias(L)
         kvalid = attn_mask.to(torch.uint8).contiguous()
-        for b, rt in zip(self.encoder.block, self._rt):
+        for i, (b, rt) in enumerate(zip(self.encoder.block, self._rt)):
+            s0 = self.T5_STREAM + 4 * i
             nrm, _, _ = ops.norm_fwd(x, b.layer[0].layer_norm.weight, None, 1e-6, n, rms=True, save_stats=False)
             qkv = ops.gemm_nt(nrm, rt["qkv"], n, 3 * D, D)
-            ao, _ = ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, U, L, self.h, 1.0, bias=bias, kvalid=kvalid, save_lse=False)
-            x = ops.gemm_nt(ao, rt["o"], n, D, D, residual=x)
+            ao, _ = ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, U, L, self.h, 1.0, bias=bias, kvalid=kvalid, save_lse=False,
+                                 drop=site(s0))
+            x = ops.gemm_nt(ao, rt["o"], n, D, D, residual=x, drop=site(s0 + 1))
             nrm, _, _ = ops.norm_fwd(x, b.layer[1].layer_norm.weight, None, 1e-6, n, rms=True, save_stats=False)
-            hdn = ops.gemm_nt(nrm, rt["wi"], n, 2048, D, act=ops.ACT_RELU)
-            x = ops.gemm_nt(hdn, rt["wo"], n, D, 2048, residual=x)
+            hdn = ops.gemm_nt(nrm, rt["wi"], n, 2048, D, act=ops.ACT_RELU, drop=site(s0 + 2))
+            x = ops.gemm_nt(hdn, rt["wo"], n, D, 2048, residual=x, drop=site(s0 + 3))
         out, _, _ = ops.norm_fwd(x, self.encoder.final_layer_norm.weight, None, 1e-6, n, rms=True, save_stats=False)
+        ops.dropout_(out, site(63))
         return out
 
 

@@ -131,6 +131,15 @@ def _d(drop):
     return None if drop is None or drop.c.p <= 0 else ctypes.cast(ctypes.pointer(drop.c), ctypes.c_void_p)
 
 
+def dropout_(x, drop):
+    """In-place dropout of a contiguous [rows, N] bf16 tensor (element index = flat index)."""
+    if drop is None:
+        return x
+    _chk(x, BF16, "x")
+    lib().call("svla_dropout_bf16", _p(x), x.numel() // x.shape[-1], x.shape[-1], _d(drop), _stream())
+    return x
+
+
 # ------------------------------------------------------------------------------------------------ GEMMs
 def gemm_nt(A, B, M, N, K, bias=None, residual=None, relu_mask=None, act=ACT_NONE, out=None, out_f32=False, alpha=1.0,
             lda=None, ldb=None, ldc=None, ldr=None, ldm=None, relu_bits_out=None, relu_bits=None, drop=None):

@@ -184,6 +184,7 @@ def test_train_mode_dropout_vs_oracle(model, prune_last):
     for k, t in enumerate(model.towers):
         t.prune_last = prune_last
         t.drop_seed_base, t._fwd_count = 1000 + k, 0
+        t.t5_dropout = False      # text-encoder noise is compared separately (test_t5_train_mode_dropout_vs_oracle)
         seeds.append(((1000 + k) * 0x9E3779B1 + 1 * 0x85EBCA77) & 0xFFFFFFFF)
     try:
         model.zero_grad()
@@ -198,6 +199,7 @@ def test_train_mode_dropout_vs_oracle(model, prune_last):
         model.eval()
         for t in model.towers:
             t.prune_last = True
+            t.t5_dropout = True
     # ---- oracle, train mode, same masks
     ref = ref_model.RefSafeActorCritic(GoalTokenizer(), max_batch=B, dropout=0.1)
     fill_state_dict(ref, seed=7)
@@ -231,3 +233,35 @@ def test_train_mode_dropout_vs_oracle(model, prune_last):
         errs.append((abs(nrm - wn) / (wn + 1e-12), n))
     errs.sort(reverse=True)
     assert np.median([e for e, _ in errs]) < 2e-2 and errs[0][0] < 1e-1, errs[:5]
+
+
+def test_t5_train_mode_dropout_vs_oracle(model):
+    """The frozen T5 encoder stays in train mode with the rest of the policy: its dropout sites (embedding,
+    attention probabilities, both residual branches, feed-forward activation, final norm) with the shared counter-based masks."""
+    from oracle.detfill import fill_state_dict
+    from oracle.ref_t5 import RefT5Encoder
+    from safevla_amd.model import T5Frozen
+
+    t5 = T5Frozen(torch.device(DEV))
+    fill_state_dict(t5, seed=11)
+    with torch.no_grad():
+        for b in t5.encoder.block:
+            b.layer[0].SelfAttention.q.weight.mul_(0.25)     # un-saturated softmax, as in test_t5_encoder_vs_oracle
+    t5.sync()
+    ref = RefT5Encoder().train()
+    ref.load_state_dict({k: v.detach().cpu() for k, v in t5.state_dict().items()})
+    ref.hash_seed = 4242
+    rs = np.random.RandomState(3)
+    U, L = 5, 11
+    ids = torch.from_numpy(rs.randint(3, 32000, size=(U, L)).astype(np.int64))
+    am = torch.ones(U, L, dtype=torch.int64)
+    for u, n in enumerate([11, 4, 7, 9, 6]):
+        ids[u, n - 1] = 1; ids[u, n:] = 0; am[u, n:] = 0
+    got = t5.encode(ids.to(DEV), am.to(DEV), drop_seed=4242).float().view(U, L, 512).cpu().numpy()
+    want = ref(ids, am).numpy()
+    plain = t5.encode(ids.to(DEV), am.to(DEV)).float().view(U, L, 512).cpu().numpy()
+    valid = am.numpy().astype(bool)
+    err = np.abs(got - want)[valid].max() / np.abs(want[valid]).max()
+    assert err < 3e-2, err
+    assert np.abs(plain - want)[valid].max() / np.abs(want[valid]).max() > 0.2      # dropout really changes the features
+    assert np.mean(got[valid] == 0) > 0.08                                          # final-site zeros (p = 0.1)
