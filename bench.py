@@ -237,14 +237,14 @@ def main():
         executed = sum(v["flops"] for v in allk.values())
         traffic = None   # HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/, collected offline)
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01f_pmc_hbm_traffic.json")))["kernels"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_hbm_traffic.json")))["kernels"]
             inst = [v for k, v in pm.items() if "gemm_nt256" in k]      # one entry per epilogue instantiation: launch-weighted mean
             traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in inst) / sum(v["launches"] for v in inst))
         except Exception:
             pass
         roof = {"bound": "mfma", "kernel": "gemm_nt256k64_bf16_kernel (svla_gemm_nt_bf16, persistent 256x256 tile, BK=64)", "achieved": round(g["tflops"], 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(g["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/r01f_pmc_hbm_traffic.json; launch-weighted over the epilogue instantiations)",
+                "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/r01g_pmc_hbm_traffic.json; launch-weighted over the epilogue instantiations)",
                 "launches_per_update": g["launches"], "avg_launch_ms": round(g["avg_ms"], 4), "flops_per_launch": g["flops"] / max(1, g["launches"]),
                 "share_of_update": round(g["total_s"] / (ms * 1e-3), 3),
                 "other_mfma_kernels": {k: {"achieved_tflops": round(v["tflops"], 1), "launches": v["launches"], "avg_launch_ms": round(v["avg_ms"], 4),
