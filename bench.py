@@ -119,7 +119,7 @@ def acting_bench(model, st, B, dev, n=24):
             "note": "per env step: 2 frames (224x384) through DINOv2 ViT-S/14 + one KV-cached 3-tower step; synthetic frames"}
 
 
-def cpu_baseline(T=32, B=8, L=12):
+def cpu_baseline(T=32, B=8, L=12, train_mode=True):
     """fp32 CPU port (oracle) of the same update on a bounded sample: one epoch = 3-tower forward, SafePPOLogGrad +
     SafePPOValue, backward, clip 0.5, Adam; env-steps/s = T*B / (4 epochs)."""
     import numpy as np
@@ -136,7 +136,10 @@ def cpu_baseline(T=32, B=8, L=12):
             ids = torch.randint(3, 32000, (len(goals), L))
             return {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
 
-    m = ref_model.RefSafeActorCritic(_Tok(), max_steps=500, max_batch=B).eval()
+    m = ref_model.RefSafeActorCritic(_Tok(), max_steps=500, max_batch=B, dropout=0.1 if train_mode else 0.0)
+    m.train(train_mode)       # the same mode as the GPU leg (the reference trains with dropout 0.1 on); T5 stays deterministic
+    for t in (m, m.critic_tsfm, m.c_critic_tsfm):
+        t.visual_encoder.text_encoder.eval()
     params = [p for n_, p in m.named_parameters() if "text_encoder" not in n_]
     opt = torch.optim.Adam(params, lr=2e-5)
     obs = {"rgb_dinov2": torch.randn(T, B, 384, 7, 12), "manipulation_rgb_dinov2": torch.randn(T, B, 384, 7, 12),
@@ -154,7 +157,7 @@ def cpu_baseline(T=32, B=8, L=12):
     opt.step()
     dt = time.time() - t0
     return {"value": T * B / (4.0 * dt), "unit": "env-steps/s", "cores": n, "kind": "port",
-            "sample": f"fp32 torch-CPU oracle, 1 of 4 epochs timed on T={T} x B={B} rows ({dt:.1f} s), L={L}, dropout off, scaled x4"}
+            "sample": f"fp32 torch-CPU oracle, 1 of 4 epochs timed on T={T} x B={B} rows ({dt:.1f} s), L={L}, " + ("train mode (dropout 0.1)" if train_mode else "eval mode") + ", scaled x4"}
 
 
 def main():
@@ -256,7 +259,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_roofline:
         acting = acting_bench(model, st, B, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(L=args.L)
+        cpu = cpu_baseline(L=args.L, train_mode=not args.eval_mode)
     if rank == 0:
         out = {"metric": "env-steps/sec through PPO-Lagrangian update", "value": round(env_steps / (ms * 1e-3), 1), "unit": "env-steps/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
