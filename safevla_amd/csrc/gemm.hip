@@ -1,16 +1,20 @@
 // bf16 MFMA GEMMs for the linear layers of the policy (gfx950, v_mfma_f32_32x32x16_bf16, fp32 accumulate).
 //
-//   svla_gemm_nt_bf16 : C[M,N] = epi(A[M,K] . B[N,K]^T)   forward linears and, with pre-transposed weights,
-//                       the input-gradient GEMMs (dX = dY . W).  Epilogue: +bias[n], ReLU/GELU, ReLU-mask from a
-//                       saved activation, +residual, bf16 or fp32 output.
-//   svla_gemm_tn_f32acc: dW[N,K] += sum_m dY[m,n] X[m,k]   weight-gradient GEMM: reduction over the (huge) row
-//                       dimension, split across workgroups, fp32 atomics into the fp32 gradient buffer.
+//   svla_gemm_nt_bf16 : C[M,N] = epi(alpha * A[M,K] . B[N,K]^T)   forward linears and, with pre-transposed weights, the
+//                       input-gradient GEMMs (dX = dY . W).  Epilogue: +bias[n], ReLU/GELU, train-mode dropout, ReLU mask (bf16
+//                       activation or 1-bit), +residual, bf16 or fp32 output, optional ReLU sign-bit output.
+//   svla_gemm_tn_f32acc: dW[N,K] += sum_m dY[m,n] X[m,k]   weight-gradient GEMM: reduction over the (huge) row dimension split
+//                       across workgroups, fp32 atomics into the fp32 gradient arena, fused bias gradient.
 //
-// Shapes on this path: M = rows x tokens (1e5..2e6), N,K in {384,512,1536,2048}: A streams from HBM once, the
-// weights stay L2-resident.  Tile 128x128x64, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 tiles.
-// global_load_lds (LDS-DMA) double-buffered pipeline (one barrier per K-tile), XOR swizzle on the DMA source
-// address + on the ds_read_b128 fragment loads (bank-conflict free), XCD-aware tile order so
-// the N-tiles that share an A panel run back-to-back on one XCD's L2, LDS-staged epilogue with 16-byte stores.
+// Shapes on this path: M = rows x tokens (1e5..2e6), N,K in {384,512,1536,2048}: A streams from HBM once, the weights stay
+// L2-resident.  Four kernels:
+//   gemm_nt256k64_bf16_kernel : persistent 256x256x64 tile, 8 waves -- every big row-streaming NT GEMM (the roofline kernel)
+//   gemm_nt_bf16_kernel       : 128x128x32 tile, 4 waves, 4-stage LDS-DMA pipeline -- small M*N, fp32 outputs
+//   gemm_tn256_bf16_kernel    : 256x256 output tile, 64-row stages, transposed ds_read_b64_tr_b16 fragments -- big dW
+//   gemm_tn_bf16_kernel       : 128x128 output tile, register-staged -- small dW, K % 256 != 0
+// Common idioms: global_load_lds (LDS-DMA) staging with the XOR swizzle applied on the DMA SOURCE address (the DMA writes
+// lane-linear) and on the fragment ds_reads (bank-conflict free, measured), counted s_waitcnt vmcnt + raw s_barrier, XCD-aware
+// tile order so the tiles that share an operand panel run on one XCD's L2.
 #include "common.h"
 #include <cstdlib>
 
