@@ -187,8 +187,6 @@ def main():
     torch.manual_seed(1234 + rank)
     model = SafeDinoLLAMATxNavActorCriticSeparate(device=dev)
     model.train(not args.eval_mode)
-    for k, t in enumerate(model.towers):
-        t.drop_seed_base += 7919 * rank          # independent dropout noise per rank
     if world > 1:  # identical initial weights on every rank
         torch.distributed.broadcast(model.arena.flat_p, src=0)
         for t in model.towers:

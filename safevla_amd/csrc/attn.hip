@@ -758,6 +758,8 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) attn_bwd_dkv_exact_kernel(Attn
     const RowBase Qrow = att_row_base(Qs, lane), Grow = att_row_base(Gs, lane);
     const TrBase Qtr = att_tr_base(Qs, lane), Gtr = att_tr_base(Gs, lane);
     const int nw = (Sq + 31) / 32;                        // query-tile pairs holding any real query
+    const unsigned long long drow0 = att_drop_row(p, r, h, 0);   // dropout element index of (query 0, key 0) of this (row, head)
+    const int S4 = (S + 3) & ~3;
 #pragma unroll
     for (int t = 0; t < MAXKT; ++t) {
         const int kt = wid + 4 * t;
@@ -792,7 +794,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) attn_bwd_dkv_exact_kernel(Attn
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int q = w * 32 + e2 * 16 + 4 * g + e;
-                            const bool kp = att_keep1(p.drop, att_drop_row(p, r, h, q < Sq ? q : 0) + keyl);
+                            const bool kp = att_keep1(p.drop, drow0 + (unsigned)((q < Sq ? q : 0) * S4 + keyl));
                             pd[e] = kp ? pr[e] * p.drop.scale : 0.f;       // dropped-out probabilities feed dV
                             dp[e] = kp ? dp[e] * p.drop.scale : 0.f;       // and dP = keep/(1-p) * (dO V^T)
                         }

@@ -55,6 +55,9 @@ class PPOLagEngine:
         self._gnorm_sq = torch.zeros(1, device=dev, dtype=torch.float64)
         self._sums = torch.zeros(5, device=dev, dtype=torch.float64)   # v_sq, action, -entropy, (pad), c_v_sq
         self.gemm_flops = 0
+        if parallel.is_dist():      # independent dropout noise per rank (every rank holds different environments)
+            for t in model.towers:
+                t.drop_seed_base += 7919 * torch.distributed.get_rank()
 
     # ---- one minibatch: forward/backward of the three towers with fused losses ------------------------------------
     def _accumulate(self, batch: Dict, n_total: int, lam: float):
