@@ -89,6 +89,7 @@ class EarlyFusionCnnTransformer(Tower):
         ops.cast_bf16(ar.flat_p, ar.flat_bf16)
         self.refresh_transposes()
         self.visual_encoder.text_encoder.sync()
+        self._t5_cache = (None, None)
 
     def zero_grad(self, set_to_none: bool = False):
         self.arena.flat_g.zero_()
