@@ -119,6 +119,37 @@ def acting_bench(model, st, B, dev, n=24):
             "note": "per env step: 2 frames (224x384) through DINOv2 ViT-S/14 + one KV-cached 3-tower step; synthetic frames"}
 
 
+def north_star_probe(model, dev, rows_T=32, rows_B=8, L=64):
+    """Secondary number named by BASELINE.json's north_star: MFMA-roofline fraction of the policy forward+backward at batch 256
+    with a 64-token instruction (3 towers, fused losses, no optimiser step; pre-encoded features -- the frozen ViT is not part of
+    the reference's update path).  Algorithmic FLOPs per SURVEY 8(d) / measured time / 2.5 PFLOP/s."""
+    from safevla_amd.engine import PPOLagConfig, PPOLagEngine
+    from safevla_amd.synth_env import SynthSpec, fill_synthetic_rollout
+
+    st, nxt, ep = fill_synthetic_rollout(model, SynthSpec(T=rows_T, B=rows_B, L=L, task="Fetch", seed=99), device=dev)
+    eng = PPOLagEngine(model, PPOLagConfig())
+    st.compute_returns(nxt["next_value"], nxt["next_c_value"])
+    batch = st.batch_slice(0, rows_B)
+    R = rows_T * rows_B
+
+    def once():
+        model.zero_grad()
+        eng._accumulate(batch, R, 0.1)
+
+    once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        once()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    U = int(st.observations["goal_token_ids"][:rows_T].reshape(R, -1).unique(dim=0).shape[0])
+    fl = flops_per_update(R, 169 + L, L, U, 1)
+    return {"rows": R, "goal_tokens": L, "ms_fwd_bwd_3_towers": round(ms, 2), "algorithmic_tflop": round(fl / 1e12, 2),
+            "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 1), "frac_of_bf16_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "note": "north_star secondary target (>= 0.70) -- small batch: 256 rows x 233 tokens"}
+
+
 def cpu_baseline(T=32, B=8, L=12, train_mode=True):
     """fp32 CPU port (oracle) of the same update on a bounded sample: one epoch = 3-tower forward, SafePPOLogGrad +
     SafePPOValue, backward, clip 0.5, Adam; env-steps/s = T*B / (4 epochs)."""
@@ -254,8 +285,10 @@ def main():
                 "executed_mfma_tflops_sustained": round(executed / (ms * 1e-3) / 1e12, 1)}
     cpu = None
     acting = None
+    ns = None
     if rank == 0 and world == 1 and not args.no_roofline:
         acting = acting_bench(model, st, B, dev)
+        ns = north_star_probe(model, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(L=args.L, train_mode=not args.eval_mode)
     if rank == 0:
@@ -271,7 +304,7 @@ def main():
                "note": "reference_equivalent counts SURVEY 8(d) FLOPs of the reference's schedule; the engine executes fewer (last fusion "
                        "layer only for the consumed token, T5 once per unique goal) -- see roofline.executed_mfma_*",
                "loss": {k: (round(v, 5) if isinstance(v, float) else v) for k, v in info.items()},
-               "roofline": roof, "cpu_baseline": cpu, "acting": acting}
+               "roofline": roof, "cpu_baseline": cpu, "acting": acting, "north_star_batch256": ns}
         print(json.dumps(out), flush=True)
 
 

@@ -18,7 +18,14 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    # the current HIP stream handle of the current device; the raw getter avoids building a torch.cuda.Stream object per launch
+    # (2.8 us -> 0.3 us on the launch-bound acting path)
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
