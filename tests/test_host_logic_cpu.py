@@ -1,5 +1,6 @@
 """Host logic that needs no GPU: Lagrange multiplier mirror vs the oracle, env sharding, tokenizer, API containers."""
 import numpy as np
+import pytest
 import torch
 
 from oracle.ref_rollout import RefLagrange
@@ -64,3 +65,30 @@ def test_agent_action_vocabulary(monkeypatch):
     assert len(names) == 20 and len(set(names)) == 20 and names[:5] == ["m", "r", "l", "b", "end"] and names[-1] == "d"
     monkeypatch.setenv("LONG_ACTION_NAME", "1")
     assert a.get_action_list()[:3] == ["move_ahead", "rotate_right", "rotate_left"]
+
+
+def test_goal_tokenizer_sentencepiece_hook(tmp_path):
+    """the real text path is a sentencepiece model (t5-small's spiece.model: not available offline).  The hook
+    is exercised with a tiny unigram model trained here: ids come from sentencepiece, EOS (= 1, T5 convention) is appended, batches
+    are padded with 0 and masked like HF's ``padding=True``."""
+    spm = pytest.importorskip("sentencepiece")
+    from safevla_amd.text import EOS_ID, PAD_ID, GoalTokenizer, bytes_to_str, str_to_bytes
+
+    corpus = tmp_path / "corpus.txt"
+    goals = ["find a mug", "navigate to the red chair and pick up the cup", "go to the kitchen", "pick up the apple on the table",
+             "fetch a bowl from the living room", "locate a houseplant"]
+    corpus.write_text("\n".join(goals * 20))
+    prefix = str(tmp_path / "toy")
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=prefix, vocab_size=48, model_type="unigram", pad_id=0, eos_id=1, unk_id=2,
+                                   bos_id=-1, hard_vocab_limit=False, minloglevel=2)
+    tok = GoalTokenizer(spiece_model=prefix + ".model")
+    sp = spm.SentencePieceProcessor(model_file=prefix + ".model")
+    for gtxt in goals[:3]:
+        ids = tok.encode(bytes_to_str(str_to_bytes(gtxt, 1000).reshape(-1)))          # through the byte-string sensor format
+        assert ids[-1] == EOS_ID and ids[:-1] == list(sp.encode(gtxt)) and all(i > PAD_ID for i in ids)
+        assert sp.decode(ids[:-1]) == gtxt
+    enc = tok(goals[:3])
+    assert enc["input_ids"].shape == enc["attention_mask"].shape
+    for row, m in zip(enc["input_ids"], enc["attention_mask"]):
+        n = int(m.sum())
+        assert (row[n:] == PAD_ID).all() and row[n - 1] == EOS_ID and (m[:n] == 1).all()
