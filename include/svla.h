@@ -24,8 +24,9 @@ typedef uint16_t svla_bf16;
  *   keep = ((e & 1) ? r >> 16 : r & 0xffff) >= (uint32)(p * 65536 + 0.5);   kept values are scaled by 1 / (1 - p)
  * with e = the element's flat index in its site's logical tensor: (row * row_mult) * N + col for [rows, N] activations (row_mult
  * > 1 when only every row_mult-th row of the logical tensor is materialised), ((row*H + head)*S + query)*S4 + key for attention
- * probabilities with the key stride S rounded up to a multiple of 4.  lowbias32(x): x ^= x>>16; x *= 0x7FEB352D; x ^= x>>15; x *= 0x846CA68B; x ^= x>>16.  NULL / p == 0: no dropout. */
-typedef struct svla_dropout { unsigned seed, stream; float p; int row_mult; } svla_dropout;
+ * probabilities with the key stride S rounded up to a multiple of 4.  seed_dev != NULL: the pass seed is read from device memory
+ * when the kernel starts instead of `seed` (a captured HIP graph of the launch-bound acting step replays with fresh noise).  lowbias32(x): x ^= x>>16; x *= 0x7FEB352D; x ^= x>>15; x *= 0x846CA68B; x ^= x>>16.  NULL / p == 0: no dropout. */
+typedef struct svla_dropout { unsigned seed, stream; float p; int row_mult; const unsigned* seed_dev; } svla_dropout;
 
 /* ---- rollout statistics ------------------------------------------------------------------------------ */
 /* Reward + cost GAE reverse scan.  Replaces AllenAct-fork RolloutStorage.compute_returns(use_gae=True) [3P];

@@ -119,6 +119,7 @@ __device__ __forceinline__ bool masked(const AttnArgs& p, int q, int key, const 
 // of the last key tile is masked and the softmax runs in the exp2 domain with the scale folded in.
 template <int NKT, bool GENERIC>
 __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
+    p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16;
     bf16_t* Ks = (bf16_t*)smem;
@@ -246,6 +247,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
 // while it computes the current item from LDS: global latency is off the critical path after the first item.
 template <int NKT>
 __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_persist_kernel(AttnArgs p, int nitems) {
+    p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16, IT = SP * 8 / ATT_THREADS, MAXQT = (NKT + 3) / 4;
     bf16_t* Ks = (bf16_t*)smem;
@@ -388,6 +390,7 @@ __device__ __forceinline__ float dot8(bf16x8 a, bf16x8 b) {
 
 template <int NKT, bool GENERIC>
 __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dq_kernel(AttnArgs p) {
+    p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16;
     bf16_t* Ks = (bf16_t*)smem;
@@ -493,6 +496,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_dq_kernel(AttnArgs p) {
 
 template <int NKT, bool GENERIC>
 __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 1) attn_bwd_dkv_kernel(AttnArgs p) {
+    p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16;
     bf16_t* Qs = (bf16_t*)smem;
@@ -633,6 +637,7 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 1) attn_bwd_dkv_k
 // D = rowsum(dO * O) is computed once (dQ kernel) and handed to the dK/dV kernel through a workspace instead of re-reading O.
 template <int NKT>
 __global__ void __launch_bounds__(ATT_THREADS, 3) attn_bwd_dq_exact_kernel(AttnArgs p) {
+    p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16, MAXQT = (NKT + 3) / 4;
     bf16_t* Ks = (bf16_t*)smem;
@@ -724,6 +729,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) attn_bwd_dq_exact_kernel(AttnA
 
 template <int NKT>
 __global__ void __launch_bounds__(ATT_THREADS, 3) attn_bwd_dkv_exact_kernel(AttnArgs p) {
+    p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16, MAXKT = (NKT + 3) / 4;
     bf16_t* Qs = (bf16_t*)smem;

@@ -66,16 +66,23 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 static inline int svla_launch_status() { return (int)hipGetLastError(); }
 
 // ---- counter-based dropout (definition in include/svla.h: svla_dropout) ----------------------------------------------------
-struct svla_dropout { unsigned seed, stream; float p; int row_mult; };
-struct DropCfg { unsigned key, thr; float scale; int row_mult; };   // thr == 0: off
+struct svla_dropout { unsigned seed, stream; float p; int row_mult; const unsigned* seed_dev; };
+struct DropCfg { unsigned key, thr; float scale; int row_mult; const unsigned* seed_dev; unsigned stream_key; };   // thr == 0: off
 __host__ __device__ inline DropCfg drop_cfg(const svla_dropout* d) {
-    DropCfg c{0u, 0u, 1.f, 1};
+    DropCfg c{0u, 0u, 1.f, 1, nullptr, 0u};
     if (d && d->p > 0.f) {
-        c.key = d->seed ^ (d->stream * 0xC2B2AE3Du);
+        c.stream_key = d->stream * 0xC2B2AE3Du;
+        c.key = d->seed ^ c.stream_key;
+        c.seed_dev = d->seed_dev;
         c.thr = (unsigned)(d->p * 65536.f + 0.5f);
         c.scale = 1.f / (1.f - d->p);
         c.row_mult = d->row_mult > 0 ? d->row_mult : 1;
     }
+    return c;
+}
+// device-resident pass seed (HIP-graph replays): resolve once at kernel start
+__device__ __forceinline__ DropCfg drop_resolve(DropCfg c) {
+    if (c.thr && c.seed_dev) c.key = *c.seed_dev ^ c.stream_key;
     return c;
 }
 // 32 random bits for the element pair (e >> 1): low half -> even element, high half -> odd element

@@ -58,6 +58,7 @@ __device__ __forceinline__ size_t relu_bits_word(int m, int n, int N) { return (
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
 __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p) {
+    p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* As = (bf16_t*)smem;                 // [NST][BM][BK]
     bf16_t* Bs = As + NST * BM * BK;            // [NST][BN][BK]
@@ -291,6 +292,7 @@ __device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((row 
 // pieces is ~100 KiB of code (128 inlined erff bodies ...) that evicts the main loop from the instruction cache once per tile.
 template <int ACT, int AUX>
 __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(GemmNtArgs p) {
+    p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* As = (bf16_t*)smem;                    // [NS64][256][64]
     bf16_t* Bs = As + NS64 * 256 * BK64;           // [NS64][256][64]

@@ -478,6 +478,7 @@ extern "C" int svla_vit_tokens(const bf16_t* patch, const float* cls, const floa
 // stand-alone sites of the frozen T5 encoder (after the token embedding and after the final layer norm; HF T5Stack), whose
 // other dropouts ride in the GEMM / attention epilogues.
 __global__ void dropout_rows_kernel(bf16_t* __restrict__ x, long n8, int N, DropCfg drop) {
+    drop = drop_resolve(drop);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
         u32x4 w = *(u32x4*)(x + i * 8);
         const unsigned long long e0 = (unsigned long long)i * 8;       // row_mult == 1: flat index

@@ -88,6 +88,7 @@ __global__ void norm_bwd_kernel(const bf16_t* __restrict__ dy, RowMap dymap, con
                                 int relu, int tok_group, const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
                                 RowMap dxmap, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                 float* __restrict__ dtok, bf16_t* __restrict__ dx_drop, DropCfg drop) {
+    drop = drop_resolve(drop);
     constexpr int VPL = D / 64;
     __shared__ float red[4][4 * D];  // [wave][dgamma | dbeta | dtok0 | dtok1]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;

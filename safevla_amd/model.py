@@ -225,7 +225,8 @@ class Tower(nn.Module):
 
     def _site_fn(self, seed):
         p = self.dropout_p
-        return (lambda i, k, rm=1: ops.Dropout(seed, 4 * i + k, p, rm)) if seed is not None else (lambda i, k, rm=1: None)
+        sd = getattr(self, "_seed_dev", None)      # captured acting graph: the pass seed lives in device memory (fresh noise per replay)
+        return (lambda i, k, rm=1: ops.Dropout(seed, 4 * i + k, p, rm, seed_dev=sd)) if seed is not None else (lambda i, k, rm=1: None)
 
     def g(self, p):  # fp32 grad view of a parameter
         return self.arena.slab(p, self.arena.flat_g)
@@ -313,15 +314,27 @@ class Tower(nn.Module):
             # (its current episode), allenact_dino_transformer.py:388-397
             t = self.time_step_counter
             self._ensure_caches(B)
-            start = torch.clamp(t - prep.time_step, min=0)
-            kvalid = (torch.arange(t + 1, device=self.device_)[None, :] >= start[:, None]).to(torch.uint8).contiguous()
+            t_dev = getattr(self, "_t_dev", None)
+            if t_dev is None:
+                start = torch.clamp(t - prep.time_step, min=0)
+                kvalid = (torch.arange(t + 1, device=self.device_)[None, :] >= start[:, None]).to(torch.uint8).contiguous()
+                S_att = t + 1
+            else:
+                # captured-graph form: the step counter lives in device memory, so every kernel argument is step-independent --
+                # attention runs over the whole cache window and the mask hides the slots beyond the counter
+                ar = self._ar_steps
+                kvalid = ((ar[None, :] <= t_dev) & (ar[None, :] >= torch.clamp(t_dev - prep.time_step, min=0)[:, None])).to(torch.uint8).contiguous()
+                S_att = self.max_steps
             for i, l in enumerate(self.decoder.layers):
                 n1, _, _ = ops.norm_fwd(xd, l.attention_norm.weight, None, 1e-5, B, rms=True, save_stats=False)
                 qkv = ops.gemm_nt(n1, w[f"d{i}.qkv"], B, 3 * D, D)
                 cache = self._kv[i]
-                cache[:B, t].copy_(qkv[:, D:])
+                if t_dev is None:
+                    cache[:B, t].copy_(qkv[:, D:])
+                else:
+                    cache[:B].index_copy_(1, t_dev.view(1), qkv[:, D:].unsqueeze(1))
                 cv = cache.view(-1, 2 * D)
-                ao, _ = ops.attn_fwd(qkv, cv, cv[:, D:], 2 * D, B, t + 1, 8, 0.125, kvalid=kvalid, save_lse=False, Sq=1, ldq=3 * D,
+                ao, _ = ops.attn_fwd(qkv, cv, cv[:, D:], 2 * D, B, S_att, 8, 0.125, kvalid=kvalid, save_lse=False, Sq=1, ldq=3 * D,
                                      kv_rows=self.max_steps)
                 h = ops.gemm_nt(ao, w[f"d{i}.wo"], B, D, D, residual=xd)
                 n2, _, _ = ops.norm_fwd(h, l.ffn_norm.weight, None, 1e-5, B, rms=True, save_stats=False)
@@ -718,9 +731,81 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
         p.S = TEXT_OFF + p.L
         return p
 
+    # ---- captured acting step -------------------------------------------------------------------------------------------
+    def enable_acting_graphs(self, on: bool = True):
+        """Single-step (acting) forwards are bound by kernel-launch issue from Python (~190 launches, ~4 ms at 32 envs for ~1.5 ms of
+        GPU work).  With this switch the three-tower step is captured once per (envs, goal length) as a HIP graph and replayed:
+        the step counter, the KV-cache write slot and the dropout seeds live in device memory, the observation tensors are copied
+        into static buffers.  Same kernels, same arithmetic (attention runs over the whole cache window behind the mask)."""
+        self._acting_graphs = {} if on else None
+
+    def _acting_step_graph(self, prep: Prep):
+        B, L = prep.B, prep.L
+        key = (B, L, self.training)
+        st = self._acting_graphs.get(key)
+        dev = self.device_
+        if st is None:
+            st = Prep()
+            st.T, st.B, st.R, st.U, st.L, st.S = 1, B, B, B, L, TEXT_OFF + L
+            st.tokens = torch.zeros(B, 2, NPATCH, DINO, device=dev, dtype=BF16)
+            st.prev_actions = torch.zeros(B, device=dev, dtype=torch.int64)
+            st.masks = torch.zeros(B, device=dev, dtype=F32)
+            st.hand = torch.zeros(B, device=dev, dtype=torch.int64)
+            st.time_step = torch.zeros(B, device=dev, dtype=torch.int64)
+            st.traj_bt = torch.zeros(B, 1, device=dev, dtype=torch.int32)
+            st.ids = torch.zeros(B, L, device=dev, dtype=torch.int64)
+            st.attn_mask = torch.ones(B, L, device=dev, dtype=torch.int64)
+            st.gid = torch.arange(B, device=dev, dtype=torch.int32)
+            st.t_dev = torch.zeros((), device=dev, dtype=torch.int64)
+            st.graph = None
+            for k, t in enumerate(self.towers):
+                t._ensure_caches(B)
+                t._ar_steps = torch.arange(t.max_steps, device=dev)
+                if getattr(t, "_seed_dev_buf", None) is None:
+                    t._seed_dev_buf = torch.tensor([(t.drop_seed_base * 0x9E3779B1) & 0x7FFFFFFF], device=dev, dtype=torch.int32)
+            self._acting_graphs[key] = st
+        # per-step inputs -> static buffers
+        st.tokens.copy_(prep.tokens); st.prev_actions.copy_(prep.prev_actions); st.masks.copy_(prep.masks); st.hand.copy_(prep.hand)
+        st.time_step.copy_(prep.time_step)
+        st.ids.copy_(prep.ids[prep.gid.long()]); st.attn_mask.copy_(prep.attn_mask[prep.gid.long()])
+        st.t_dev.fill_(self.time_step_counter)
+
+        def body():
+            outs = []
+            for t in self.towers:
+                t._t_dev, t._seed_dev = st.t_dev, t._seed_dev_buf
+                t._seed_dev_buf.add_(0x3C6EF35)          # fresh dropout noise per replay (wraps in int32)
+                keep = t.time_step_counter
+                lg, vl, _ = t.run_forward(st, need_grad=False)
+                t.time_step_counter = keep               # the host counter is advanced once per step below
+                t._t_dev, t._seed_dev = None, None
+                outs.append((lg, vl))
+            return outs
+
+        if st.graph is None:
+            s_ = torch.cuda.Stream()
+            s_.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s_):                  # warm-up outside capture (lazy initialisations, allocator)
+                body()
+            torch.cuda.current_stream().wait_stream(s_)
+            st.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(st.graph):
+                st.outs = body()
+        st.graph.replay()
+        for t in self.towers:
+            t.time_step_counter += 1
+        return st.outs[0][0].clone(), st.outs[1][1].clone(), st.outs[2][1].clone()
+
     # ---- reference forward API -------------------------------------------------------------------------------------
     def forward(self, observations, memory, prev_actions, masks):
         prep = self.prepare(observations, prev_actions, masks)
+        if (prep.T == 1 and getattr(self, "_acting_graphs", None) is not None and not torch.is_grad_enabled()
+                and self.time_step_counter < self.max_steps - 1 and all(t.time_step_counter == self.time_step_counter for t in self.towers)):
+            logits, values, c_values = self._acting_step_graph(prep)
+            with torch.no_grad():
+                fc = self.c_critic_tsfm.critic.fc
+                extras = {"weight_norm": fc.weight.norm(2).reshape(1), "bias_norm": fc.bias.norm(2).reshape(1)}
+            return SafeActorCriticOutput(distributions=CategoricalDistr(logits), values=values, c_values=c_values, extras=extras), memory
         if prep.T == 1 and torch.is_grad_enabled():
             raise RuntimeError("single-step (acting) forwards run under torch.no_grad(), as in the reference's rollout collection")
         logits, _ = _TowerFn.apply(self._anchor, self, prep, True, False)

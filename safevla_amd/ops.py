@@ -117,17 +117,20 @@ def norm_bwd(dy, x, gamma, beta, mean, rstd, rows, dgamma, dbeta, D=512, rms=Fal
 
 # ------------------------------------------------------------------------------------------------ dropout descriptor
 class _SvlaDropout(ctypes.Structure):
-    _fields_ = [("seed", ctypes.c_uint), ("stream", ctypes.c_uint), ("p", ctypes.c_float), ("row_mult", ctypes.c_int)]
+    _fields_ = [("seed", ctypes.c_uint), ("stream", ctypes.c_uint), ("p", ctypes.c_float), ("row_mult", ctypes.c_int),
+                ("seed_dev", ctypes.c_void_p)]
 
 
 class Dropout:
     """``svla_dropout`` of include/svla.h: one dropout site of one forward pass (seed = the pass, stream = the site)."""
 
-    def __init__(self, seed: int, stream: int, p: float, row_mult: int = 1):
-        self.c = _SvlaDropout(seed & 0xFFFFFFFF, stream & 0xFFFFFFFF, float(p), int(row_mult))
+    def __init__(self, seed: int, stream: int, p: float, row_mult: int = 1, seed_dev=None):
+        """``seed_dev``: 1-element int32/uint32 device tensor holding the pass seed (read when the kernel starts; for captured graphs)."""
+        self.seed_dev = seed_dev          # keep the tensor alive
+        self.c = _SvlaDropout(seed & 0xFFFFFFFF, stream & 0xFFFFFFFF, float(p), int(row_mult), None if seed_dev is None else seed_dev.data_ptr())
 
     def with_row_mult(self, row_mult: int) -> "Dropout":
-        return Dropout(self.c.seed, self.c.stream, self.c.p, row_mult)
+        return Dropout(self.c.seed, self.c.stream, self.c.p, row_mult, self.seed_dev)
 
     @property
     def scale(self) -> float:

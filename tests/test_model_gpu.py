@@ -265,3 +265,48 @@ def test_t5_train_mode_dropout_vs_oracle(model):
     assert err < 3e-2, err
     assert np.abs(plain - want)[valid].max() / np.abs(want[valid]).max() > 0.2      # dropout really changes the features
     assert np.mean(got[valid] == 0) > 0.08                                          # final-site zeros (p = 0.1)
+
+
+def test_acting_graph_replay_equals_eager_acting(model):
+    """The captured single-step graph (device-resident step counter / KV slot / dropout seed, attention over the whole cache window
+    behind the mask) must reproduce the eager acting path step for step, across an episode boundary, and keep running in train mode."""
+    gu = _load("g5_samelen.npz")
+    obs = {k[4:]: torch.from_numpy(v).to(DEV) for k, v in gu.items() if k.startswith("obs:")}
+    pa, mk = torch.from_numpy(gu["prev_actions"]).to(DEV), torch.from_numpy(gu["masks"]).to(DEV)
+    T = pa.shape[0]
+
+    def run(graph):
+        for t in model.towers:
+            t.time_step_counter, t._kv = 0, None
+        model.enable_acting_graphs(graph)
+        out = []
+        with torch.no_grad():
+            for t in range(T):
+                o, _ = model({k: v[t:t + 1] for k, v in obs.items()}, None, pa[t:t + 1], mk[t:t + 1])
+                out.append((o.distributions.logits.float().cpu(), o.values.cpu(), o.c_values.cpu()))
+        model.enable_acting_graphs(False)
+        return out
+
+    eager, graph = run(False), run(True)
+    for t, (a, b) in enumerate(zip(eager, graph)):
+        for x, y in zip(a, b):
+            assert torch.allclose(x, y, rtol=0, atol=2e-2 * max(1.0, x.abs().max().item())), (t, (x - y).abs().max())
+    assert all(t.time_step_counter == T for t in model.towers)
+    # train mode: replays draw fresh dropout noise (device-resident seed) -> same inputs, different outputs
+    model.train()
+    try:
+        for t in model.towers:
+            t.time_step_counter, t._kv = 0, None
+        model.enable_acting_graphs(True)
+        with torch.no_grad():
+            a, _ = model({k: v[0:1] for k, v in obs.items()}, None, pa[0:1], mk[0:1])
+            for t in model.towers:
+                t.time_step_counter = 0
+            b, _ = model({k: v[0:1] for k, v in obs.items()}, None, pa[0:1], mk[0:1])
+        assert (a.values - b.values).abs().max() > 1e-3
+        assert torch.isfinite(a.distributions.logits).all() and torch.isfinite(b.values).all()
+    finally:
+        model.enable_acting_graphs(False)
+        model.eval()
+        for t in model.towers:
+            t._kv, t.time_step_counter = None, 0
