@@ -408,24 +408,33 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
             const int st = g % NS64;
             const bf16_t* Ab = As + st * 256 * BK64;
             const bf16_t* Bb = Bs + st * 256 * BK64;
-#pragma unroll
-            for (int kk = 0; kk < BK64 / 16; ++kk) {
-                bf16x8 fa[4], fb[2];
+            // Fragment reads are software-pipelined by hand: the reads of k-step kk+1 are issued BEFORE the MFMAs of k-step kk (two
+            // register sets), so an LDS latency is exposed once per K-tile instead of before every group of 4 MFMAs (what the compiler's
+            // own schedule did: ds_read x4 -> s_waitcnt lgkmcnt(0) -> 4 MFMA -> ...).
+            bf16x8 fa[2][4], fb[2][2];
+            auto load_frags = [&](int kk, bf16x8 (&A4)[4], bf16x8 (&B2)[2]) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int r_ = wm * 128 + t * 32 + fr;
-                    fa[t] = *(const bf16x8*)(Ab + r_ * BK64 + swz64(r_, kk * 2 + fh) * 8);
+                    A4[t] = *(const bf16x8*)(Ab + r_ * BK64 + swz64(r_, kk * 2 + fh) * 8);
                 }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int r_ = wn * 64 + t * 32 + fr;
-                    fb[t] = *(const bf16x8*)(Bb + r_ * BK64 + swz64(r_, kk * 2 + fh) * 8);
+                    B2[t] = *(const bf16x8*)(Bb + r_ * BK64 + swz64(r_, kk * 2 + fh) * 8);
                 }
+            };
+            load_frags(0, fa[0], fb[0]);
+#pragma unroll
+            for (int kk = 0; kk < BK64 / 16; ++kk) {
+                if (kk + 1 < BK64 / 16) load_frags(kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = mfma32(fb[j], fa[i], acc[i][j]);
+                        acc[i][j] = mfma32(fb[kk & 1][j], fa[kk & 1][i], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (p.dbg & 2) {
