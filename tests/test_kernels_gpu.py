@@ -601,3 +601,47 @@ def test_norm_bwd_dropout_output(ops):
     keep = _keep_np(5, 1, p, idx).to(DEV)
     assert ((dxd.float() == 0) | keep).all()
     close(dxd.float()[keep], (dx.float() / (1 - p))[keep], 1e-2, 1e-3, "dx_drop kept elements")
+
+
+# ------------------------------------------------------------------------------------------------ error behaviour / edge cases
+def test_invalid_arguments_are_refused_not_computed(ops):
+    """Every entry point validates its arguments and returns SVLA_EINVAL (-1) -> the binding raises; nothing is launched."""
+    from safevla_amd._lib import SvlaError
+    bf = torch.bfloat16
+    A = torch.zeros(64, 64, device=DEV, dtype=bf); W = torch.zeros(128, 64, device=DEV, dtype=bf)
+    with pytest.raises(SvlaError):
+        ops.gemm_nt(A, W[:100], 64, 100, 64)                       # N not a multiple of 128
+    with pytest.raises(SvlaError):
+        ops.gemm_nt(A[:, :40], W[:, :40], 64, 128, 40)             # K not a multiple of 32
+    with pytest.raises(SvlaError):
+        ops.gemm_nt(A, W, 64, 128, 64, act=7)                      # unknown activation
+    with pytest.raises(SvlaError):                                 # a bit mask cannot be combined with a residual
+        ops.gemm_nt(A, W, 64, 128, 64, residual=torch.zeros(64, 128, device=DEV, dtype=bf),
+                    relu_bits=torch.zeros(ops.relu_bits_bytes(64, 128), device=DEV, dtype=torch.uint8))
+    qkv = torch.zeros(2 * 600, 3 * 64, device=DEV, dtype=bf)
+    with pytest.raises(SvlaError):
+        ops.attn_fwd(qkv, qkv[:, 64:], qkv[:, 128:], 192, 2, 600, 1, 0.125)       # S > 512
+    with pytest.raises(SvlaError):
+        ops.attn_fwd(qkv, qkv[:, 64:], qkv[:, 128:], 192, 2, 16, 1, 0.125, mask_mode=ops.MASK_BLOCK_CAUSAL)   # block-causal without traj ids
+    with pytest.raises(SvlaError):
+        ops.norm_fwd(torch.zeros(4, 256, device=DEV, dtype=bf), torch.ones(256, device=DEV), None, 1e-5, 4, D=256)  # only D = 384 / 512 are built
+    with pytest.raises((ValueError, TypeError)):
+        ops.gemm_nt(A.float(), W, 64, 128, 64)                     # wrong dtype is caught before the C call
+
+
+def test_degenerate_sizes(ops):
+    """Smallest legal problems: one row, one env, one step, one key."""
+    # GAE with T = 1, B = 1
+    one = lambda v: torch.tensor([[v]], device=DEV, dtype=torch.float32)
+    ret, adv, cret, cadv = ops.gae_scan(one(1.0), one(2.0), one(0.5), one(0.25), torch.ones(2, 1, device=DEV), torch.tensor([0.7], device=DEV),
+                                        torch.tensor([0.1], device=DEV), 0.99, 0.95)
+    assert abs(adv.item() - (1.0 + 0.99 * 0.7 - 0.5)) < 1e-6 and abs(ret.item() - (adv.item() + 0.5)) < 1e-6
+    assert abs(cadv.item() - (2.0 + 0.99 * 0.1 - 0.25)) < 1e-6
+    # GEMM with a single row (128-tile kernel, ragged everywhere)
+    A = bf(rnd(1, 64, seed=1)); W = bf(rnd(128, 64, seed=2))
+    y = ops.gemm_nt(A.to(DEV).bfloat16(), W.to(DEV).bfloat16(), 1, 128, 64)
+    close(y.float(), A @ W.t(), 1e-2, 1e-2, "1-row gemm")
+    # attention with one key / one query
+    qkv = bf(rnd(1, 3 * 64, seed=3)).to(DEV).bfloat16()
+    o, lse = ops.attn_fwd(qkv, qkv[:, 64:], qkv[:, 128:], 192, 1, 1, 1, 0.125)
+    close(o.float(), qkv[:, 128:].float(), 1e-2, 1e-2, "S = 1 attention returns V")
