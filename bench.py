@@ -160,7 +160,7 @@ def north_star_probe(model, dev, rows_T=32, rows_B=8, L=64):
             "note": "north_star secondary target (>= 0.70) -- small batch: 256 rows x 233 tokens"}
 
 
-def cpu_baseline(T=32, B=8, L=12, train_mode=True):
+def cpu_baseline(T=32, B=8, L=12, train_mode=True, threads=None):
     """fp32 CPU port (oracle) of the same update on a bounded sample: one epoch = 3-tower forward, SafePPOLogGrad +
     SafePPOValue, backward, clip 0.5, Adam; env-steps/s = T*B / (4 epochs)."""
     import numpy as np
@@ -168,7 +168,7 @@ def cpu_baseline(T=32, B=8, L=12, train_mode=True):
     from oracle import ref_loss, ref_model
     from safevla_amd.text import GoalTokenizer
 
-    n = min(16, os.cpu_count() or 1)   # more threads only add fork/join overhead on these op sizes (measured: 256 threads 40x slower)
+    n = threads or min(16, os.cpu_count() or 1)   # more threads only add fork/join overhead on these op sizes (measured: 256 threads 40x slower)
     torch.set_num_threads(n)
     torch.manual_seed(0)
 
@@ -301,6 +301,8 @@ def main():
         ns = north_star_probe(model, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(L=args.L, train_mode=not args.eval_mode)
+        one = cpu_baseline(T=8, B=2, L=args.L, train_mode=not args.eval_mode, threads=1)     # also at n = 1
+        cpu["single_thread"] = {"value": one["value"], "unit": one["unit"], "sample": one["sample"]}
     if rank == 0:
         out = {"metric": "env-steps/sec through PPO-Lagrangian update", "value": round(env_steps / (ms * 1e-3), 1), "unit": "env-steps/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
