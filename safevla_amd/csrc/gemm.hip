@@ -48,7 +48,8 @@ struct GemmNtArgs {
     unsigned char* bits_out;          // act == ReLU: also write the output's sign bits (blocked layout, see relu_bits_word)
     const unsigned char* bits_in;     // ReLU mask given as such bits instead of a bf16 activation tensor (relu_mask)
     DropCfg drop;                     // train-mode dropout after the activation, before the residual add (thr == 0: off)
-    int dbg;          // timing-only ablations of the 256-tile kernel (tools/ab_gemm.py): 1 = no C stores, 2 = no epilogue
+    int dbg;          // timing-only ablations of the 256-tile kernel (tools/ab_gemm.py, tools/shape_gemm.py): 1 = no C stores,
+                      // 2 = no epilogue, 64 = no fragment reads / MFMAs (operand DMA stream + barriers alone)
 };
 
 // ReLU sign bits live in a kernel-private blocked layout: [ceil(M/32)][N/64][32 rows][8 bytes]: the 64 bits of (row m, 64-column
@@ -424,6 +425,7 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
                     B2[t] = *(const bf16x8*)(Bb + r_ * BK64 + swz64(r_, kk * 2 + fh) * 8);
                 }
             };
+            if (p.dbg & 64) continue;          // timing-only: DMA stream + barriers alone (what does the operand fetch path sustain?)
             load_frags(0, fa[0], fb[0]);
 #pragma unroll
             for (int kk = 0; kk < BK64 / 16; ++kk) {
