@@ -6,8 +6,11 @@
 A "step" = ONE full PPO-Lagrangian update over a synthetic rollout already resident in HBM:
   reward+cost GAE  ->  lambda update  ->  update_repeats(4) x [3 towers x (forward, fused loss, backward),
   all-reduce of the flat gradient arena, global-norm clip + Adam].
-Workload at N=1 = one GPU's shard of BASELINE.json configs[3] ("Fetch, 256 envs sharded 8xMI355X, 256-step rollout"):
-T=256 steps x 32 envs per GPU, 12 goal tokens; weak scaling (32 envs per GPU at every N).
+Workload at N=1 = BASELINE.json configs[2] (C3, the largest single-GPU configuration): PickUp, 64 envs x 256 steps, cost
+constraint active (cost_limit 2.31964, lambda moves), 12 goal tokens, gradient accumulation over 2 chunks of 32 envs.
+N > 1: the same 64 envs x 256 steps on EVERY GPU (weak scaling; C4 = "256 envs over 8 GPUs" is the 32-envs/GPU point and is
+reported, with C2 and the 64-token probe, under "secondary" at N=1).  `--gpus N` without a torchrun environment re-executes
+itself under torch.distributed.run (one rank per GPU, RCCL) and fails loudly if fewer than N GPUs are visible.
 Prints ONE JSON line (rank 0) with the roofline of the dominant kernel (the bf16 MFMA GEMM, timed with HIP events on
 its launch stream in a separate instrumented update) and a CPU baseline (the fp32 oracle port on the host cores, bounded
 sample).  The oracle is only the checker/baseline leg here -- the measured path is the HIP library.
@@ -160,16 +163,11 @@ def north_star_probe(model, dev, rows_T=32, rows_B=8, L=64):
             "note": "north_star secondary target (>= 0.70) -- small batch: 256 rows x 233 tokens"}
 
 
-def cpu_baseline(T=32, B=8, L=12, train_mode=True, threads=None):
-    """fp32 CPU port (oracle) of the same update on a bounded sample: one epoch = 3-tower forward, SafePPOLogGrad +
-    SafePPOValue, backward, clip 0.5, Adam; env-steps/s = T*B / (4 epochs)."""
-    import numpy as np
-
+def _oracle_epochs(T, B, L, train_mode, device="cpu", epochs=1, autocast=False):
+    """`epochs` x [3-tower forward, SafePPOLogGrad + SafePPOValue, backward, clip 0.5, Adam] of the fp32 torch restatement (oracle port) on
+    `device` with stock PyTorch ops; returns seconds.  The checker / baseline leg only -- never the measured product path."""
     from oracle import ref_loss, ref_model
-    from safevla_amd.text import GoalTokenizer
 
-    n = threads or min(16, os.cpu_count() or 1)   # more threads only add fork/join overhead on these op sizes (measured: 256 threads 40x slower)
-    torch.set_num_threads(n)
     torch.manual_seed(0)
 
     class _Tok:  # fixed-length synthetic ids, same as the GPU workload
@@ -177,77 +175,104 @@ def cpu_baseline(T=32, B=8, L=12, train_mode=True, threads=None):
             ids = torch.randint(3, 32000, (len(goals), L))
             return {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
 
-    m = ref_model.RefSafeActorCritic(_Tok(), max_steps=500, max_batch=B, dropout=0.1 if train_mode else 0.0)
+    m = ref_model.RefSafeActorCritic(_Tok(), max_steps=500, max_batch=B, dropout=0.1 if train_mode else 0.0).to(device)
     m.train(train_mode)       # the same mode as the GPU leg (the reference trains with dropout 0.1 on); T5 stays deterministic
     for t in (m, m.critic_tsfm, m.c_critic_tsfm):
         t.visual_encoder.text_encoder.eval()
     params = [p for n_, p in m.named_parameters() if "text_encoder" not in n_]
     opt = torch.optim.Adam(params, lr=2e-5)
-    obs = {"rgb_dinov2": torch.randn(T, B, 384, 7, 12), "manipulation_rgb_dinov2": torch.randn(T, B, 384, 7, 12),
-           "natural_language_spec": torch.zeros(T, B, 1000, dtype=torch.uint8), "time_step": torch.arange(T)[:, None].expand(T, B).contiguous(),
-           "traj_index": torch.zeros(T, B, dtype=torch.int64), "an_object_is_in_hand": torch.zeros(T, B, 1, dtype=torch.int64)}
+    dv = lambda x: x.to(device)
+    obs = {"rgb_dinov2": dv(torch.randn(T, B, 384, 7, 12)), "manipulation_rgb_dinov2": dv(torch.randn(T, B, 384, 7, 12)),
+           "natural_language_spec": dv(torch.zeros(T, B, 1000, dtype=torch.uint8)), "time_step": dv(torch.arange(T)[:, None].expand(T, B).contiguous()),
+           "traj_index": dv(torch.zeros(T, B, dtype=torch.int64)), "an_object_is_in_hand": dv(torch.zeros(T, B, 1, dtype=torch.int64))}
     batch = {"actions": torch.randint(0, 20, (T, B)), "old_action_log_probs": torch.full((T, B), -3.0), "adv_targ": torch.randn(T, B, 1),
              "c_adv_targ": torch.randn(T, B, 1), "returns": torch.randn(T, B, 1), "values": torch.randn(T, B, 1), "c_returns": torch.randn(T, B, 1)}
-    pa, mk = torch.randint(0, 20, (T, B)), torch.ones(T, B, 1)
+    batch = {k: dv(v) for k, v in batch.items()}
+    pa, mk = dv(torch.randint(0, 20, (T, B))), dv(torch.ones(T, B, 1))
+    is_gpu = str(device) != "cpu"
+
+    def epoch():
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast and is_gpu):
+            out, _ = m(obs, None, pa, mk)
+        total, _ = ref_loss.safe_ppo_log_grad(out["logits"].float(), out["values"].float(), batch, 0.1)
+        (total + ref_loss.safe_ppo_value(out["c_values"].float(), batch["c_returns"])).backward()
+        torch.nn.utils.clip_grad_norm_(params, 0.5)
+        opt.step()
+
+    if is_gpu:               # one untimed epoch: rocBLAS / MIOpen handle creation and kernel selection
+        epoch()
+        torch.cuda.synchronize()
     t0 = time.time()
-    opt.zero_grad()
-    out, _ = m(obs, None, pa, mk)
-    total, _ = ref_loss.safe_ppo_log_grad(out["logits"], out["values"], batch, 0.1)
-    (total + ref_loss.safe_ppo_value(out["c_values"], batch["c_returns"])).backward()
-    torch.nn.utils.clip_grad_norm_(params, 0.5)
-    opt.step()
-    dt = time.time() - t0
+    for _ in range(epochs):
+        epoch()
+    if is_gpu:
+        torch.cuda.synchronize()
+    return time.time() - t0
+
+
+def cpu_baseline(T=32, B=8, L=12, train_mode=True, threads=None):
+    """fp32 CPU port (oracle) of the same update on a bounded sample: one epoch = 3-tower forward, SafePPOLogGrad +
+    SafePPOValue, backward, clip 0.5, Adam; env-steps/s = T*B / (4 epochs)."""
+    n = threads or min(16, os.cpu_count() or 1)   # more threads only add fork/join overhead on these op sizes (measured: 256 threads 40x slower)
+    torch.set_num_threads(n)
+    dt = _oracle_epochs(T, B, L, train_mode)
     return {"value": T * B / (4.0 * dt), "unit": "env-steps/s", "cores": n, "kind": "port",
             "sample": f"fp32 torch-CPU oracle, 1 of 4 epochs timed on T={T} x B={B} rows ({dt:.1f} s), L={L}, " + ("train mode (dropout 0.1)" if train_mode else "eval mode") + ", scaled x4"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--T", type=int, default=256)
-    ap.add_argument("--envs-per-gpu", type=int, default=32)
-    ap.add_argument("--L", type=int, default=12)
-    ap.add_argument("--task", default="Fetch")
-    ap.add_argument("--env-chunk", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--eval-mode", action="store_true", help="dropout off (the reference trains with the policy in train() mode: default here too)")
-    args = ap.parse_args()
+def cpu_c1_full(train_mode=True):
+    """BASELINE configs[0] (C1: 4 envs x 32 steps) timed IN FULL on the host CPU: all 4 epochs of the update."""
+    n = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(n)
+    dt = _oracle_epochs(32, 4, 4, train_mode, epochs=4)
+    return {"value": 32 * 4 / dt, "unit": "env-steps/s", "cores": n, "kind": "port", "seconds_per_update": round(dt, 1),
+            "sample": "C1 in full: 4 envs x 32 steps, L=4, 4 epochs x 3 towers, fp32 torch-CPU oracle, " + ("train mode" if train_mode else "eval mode")}
 
-    from safevla_amd import ops, parallel
-    from safevla_amd.engine import PPOLagConfig, PPOLagEngine
-    from safevla_amd.model import SafeDinoLLAMATxNavActorCriticSeparate
-    from safevla_amd.synth_env import SynthSpec, fill_synthetic_rollout
 
-    rank, local, world = parallel.init_from_env()
-    assert world == max(1, args.gpus) or world == 1, (world, args.gpus)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    torch.manual_seed(1234 + rank)
-    model = SafeDinoLLAMATxNavActorCriticSeparate(device=dev)
-    model.train(not args.eval_mode)
-    if world > 1:  # identical initial weights on every rank
-        torch.distributed.broadcast(model.arena.flat_p, src=0)
-        for t in model.towers:
-            for p in t.visual_encoder.text_encoder.parameters():
-                torch.distributed.broadcast(p.data, src=0)
-        model.sync_weights()
-    T, B = args.T, args.envs_per_gpu
-    cfg = PPOLagConfig(env_chunk=args.env_chunk or None)
-    eng = PPOLagEngine(model, cfg)
-    st, nxt, ep = fill_synthetic_rollout(model, SynthSpec(T=T, B=B, L=args.L, task=args.task, seed=1234 + rank), device=dev)
+def stock_rocm_baseline(dev, L=12, train_mode=True, T=64, B=8):
+    """SURVEY 8(d) / BASELINE.md 2.3 intermediate baseline: the same restatement on the MI355X through stock PyTorch-ROCm ops (rocBLAS /
+    MIOpen / eager elementwise kernels; no custom HIP kernel), fp32 as the reference runs it and under bf16 autocast."""
+    out = {"sample": f"oracle port on cuda, 1 of 4 epochs timed on T={T} x B={B} rows after one warm-up epoch, L={L}, scaled x4", "unit": "env-steps/s"}
+    for name, ac in (("fp32", False), ("bf16_autocast", True)):
+        dt = _oracle_epochs(T, B, L, train_mode, device=dev, autocast=ac)
+        out[name] = round(T * B / (4.0 * dt), 1)
+    torch.cuda.empty_cache()
+    return out
+
+
+def _self_spawn(args):
+    """`python bench.py --gpus N` outside torchrun: re-exec under torch.distributed.run, one rank per GPU (RCCL).  Never
+    falls back to fewer ranks: a box with < N GPUs is an error."""
+    import socket
+    import subprocess
+
+    n_vis = torch.cuda.device_count()
+    if n_vis < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_vis} GPU(s) visible -- refusing to run fewer ranks than requested")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), SVLA_BENCH_SPAWNED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def timed_updates(eng, st, nxt, ep, steps, warmup, world, dev):
+    """W untimed + K timed full updates, bracketed by barrier + synchronize, MAX over ranks.  Returns (ms per update, last info)."""
+    from safevla_amd import parallel
 
     def step():
         return eng.update(st, nxt["next_value"], nxt["next_c_value"], ep["episode_cost_sum"], ep["n_episodes"])
 
-    for _ in range(args.warmup):
+    info = None
+    for _ in range(warmup):
         info = step()
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         info = step()
     parallel.barrier()
     torch.cuda.synchronize()
@@ -256,7 +281,72 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = tt.item()
-    ms = dt / args.steps * 1e3
+    return dt / steps * 1e3, info, step
+
+
+def secondary_config(model, dev, name, task, T, B, L, env_chunk, cost_limit):
+    """Another BASELINE configuration through the same engine (1 warm-up + 1 timed update; parity-test cases, not the bench line)."""
+    from safevla_amd.engine import PPOLagConfig, PPOLagEngine
+    from safevla_amd.synth_env import SynthSpec, fill_synthetic_rollout
+
+    st, nxt, ep = fill_synthetic_rollout(model, SynthSpec(T=T, B=B, L=L, task=task, seed=4321), device=dev)
+    eng = PPOLagEngine(model, PPOLagConfig(env_chunk=env_chunk, cost_limit=cost_limit))
+    ms, info, _ = timed_updates(eng, st, nxt, ep, 1, 1, 1, dev)
+    S = 169 + L
+    U = int(st.observations["goal_token_ids"][:T].reshape(T * B, -1).unique(dim=0).shape[0])
+    return {"workload": name, "task": task, "rollout_steps": T, "envs": B, "goal_tokens": L, "env_chunk": env_chunk, "ms_per_update": round(ms, 2),
+            "env_steps_per_s": round(T * B / (ms * 1e-3), 1),
+            "reference_equivalent_tflops": round(flops_per_update(T * B, S, L, U, 4) / (ms * 1e-3) / 1e12, 1),
+            "lagrangian_multiplier": round(info["lagrangian_multiplier"], 6), "Jc": round(info["Jc"], 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--T", type=int, default=256)
+    ap.add_argument("--envs-per-gpu", type=int, default=64)
+    ap.add_argument("--L", type=int, default=12)
+    ap.add_argument("--task", default="PickUp")
+    ap.add_argument("--env-chunk", type=int, default=32)
+    ap.add_argument("--cost-limit", type=float, default=2.31964)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--eval-mode", action="store_true", help="dropout off (the reference trains with the policy in train() mode: default here too)")
+    ap.add_argument("--cpu-c1-full", action="store_true", help="only time BASELINE configs[0] (4 envs x 32 steps) IN FULL on the host CPU and exit")
+    args = ap.parse_args()
+
+    if args.cpu_c1_full:
+        print(json.dumps({"cpu_c1_full": cpu_c1_full(not args.eval_mode)}), flush=True)
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_spawn(args)
+
+    from safevla_amd import ops, parallel
+    from safevla_amd.engine import PPOLagConfig, PPOLagEngine
+    from safevla_amd.model import SafeDinoLLAMATxNavActorCriticSeparate
+    from safevla_amd.synth_env import SynthSpec, fill_synthetic_rollout
+
+    rank, local, world = parallel.init_from_env()
+    if world != max(1, args.gpus):
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per requested GPU")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.manual_seed(1234)          # identical frozen text encoder / initial weights on every rank ...
+    model = SafeDinoLLAMATxNavActorCriticSeparate(device=dev)
+    model.train(not args.eval_mode)
+    if world > 1:                    # ... and made certain by a broadcast of every parameter and buffer
+        parallel.broadcast_model_(model)
+    torch.manual_seed(1234 + rank)   # per-rank streams from here on (sampling, synthetic environments)
+    T, B = args.T, args.envs_per_gpu
+    chunk = args.env_chunk if 0 < args.env_chunk < B else None
+    cfg = PPOLagConfig(env_chunk=chunk, cost_limit=args.cost_limit)
+    eng = PPOLagEngine(model, cfg)
+    st, nxt, ep = fill_synthetic_rollout(model, SynthSpec(T=T, B=B, L=args.L, task=args.task, seed=1234 + rank), device=dev)
+
+    ms, info, step = timed_updates(eng, st, nxt, ep, args.steps, args.warmup, world, dev)
     env_steps = T * B * world
     S, R = 169 + args.L, T * B
     U = int(st.observations["goal_token_ids"][:T].reshape(R, -1).unique(dim=0).shape[0])
@@ -277,47 +367,69 @@ def main():
         allk = gt.summary()
         g = allk["gemm_nt256"]
         executed = sum(v["flops"] for v in allk.values())
-        traffic = None   # HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/, collected offline)
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_hbm_traffic.json")))["kernels"]
-            inst = [v for k, v in pm.items() if "gemm_nt256" in k]      # one entry per epilogue instantiation: launch-weighted mean
-            traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in inst) / sum(v["launches"] for v in inst))
-        except Exception:
-            pass
+        traffic, traffic_src = None, None   # HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/, collected offline)
+        for cand in ("r02_pmc_hbm_traffic.json", "r01g_pmc_hbm_traffic.json"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", cand)))["kernels"]
+                inst = [v for k, v in pm.items() if "gemm_nt256" in k]      # one entry per epilogue instantiation: launch-weighted mean
+                traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in inst) / sum(v["launches"] for v in inst))
+                traffic_src = cand
+                break
+            except Exception:
+                pass
         roof = {"bound": "mfma", "kernel": "gemm_nt256k64_bf16_kernel (svla_gemm_nt_bf16, persistent 256x256 tile, BK=64)", "achieved": round(g["tflops"], 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(g["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/r01g_pmc_hbm_traffic.json; launch-weighted over the epilogue instantiations)",
+                "traffic_unit": f"HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/{traffic_src}; launch-weighted over the epilogue instantiations)",
                 "launches_per_update": g["launches"], "avg_launch_ms": round(g["avg_ms"], 4), "flops_per_launch": g["flops"] / max(1, g["launches"]),
                 "share_of_update": round(g["total_s"] / (ms * 1e-3), 3),
                 "other_mfma_kernels": {k: {"achieved_tflops": round(v["tflops"], 1), "launches": v["launches"], "avg_launch_ms": round(v["avg_ms"], 4),
                                            "share_of_update": round(v["total_s"] / (ms * 1e-3), 3)} for k, v in allk.items() if k != "gemm_nt256"},
                 "executed_mfma_tflop_per_update": round(executed / 1e12, 1),
-                "executed_mfma_tflops_sustained": round(executed / (ms * 1e-3) / 1e12, 1)}
+                "executed_mfma_tflops_sustained": round(executed / (ms * 1e-3) / 1e12, 1),
+                "executed_mfma_frac_of_peak": round(executed / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
     cpu = None
     acting = None
     ns = None
-    if rank == 0 and world == 1 and not args.no_roofline:
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        del eng, step
         acting = acting_bench(model, st, B, dev)
+        del st, nxt
+        torch.cuda.empty_cache()
         ns = north_star_probe(model, dev)
+        secondary = [secondary_config(model, dev, "C4-shard: one GPU's 32 envs of BASELINE configs[3] (Fetch, 256 envs over 8 GPUs)", "Fetch", 256, 32, 12, None, 2.31964),
+                     secondary_config(model, dev, "C2: BASELINE configs[1] (ObjectNav, 32 envs x 128 steps)", "ObjectNav", 128, 32, 12, None, 2.31964),
+                     secondary_config(model, dev, "C5-shard: mixed ObjectNav+PickUp+Fetch sampler (env e -> task e mod 3), 64-token instructions, 32 envs/GPU", "Mixed", 256, 32, 64, 16, 2.31964)]
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(L=args.L, train_mode=not args.eval_mode)
         one = cpu_baseline(T=8, B=2, L=args.L, train_mode=not args.eval_mode, threads=1)     # also at n = 1
         cpu["single_thread"] = {"value": one["value"], "unit": one["unit"], "sample": one["sample"]}
+        try:
+            cpu["stock_pytorch_rocm"] = stock_rocm_baseline(dev, L=args.L, train_mode=not args.eval_mode)
+        except Exception as e:          # the intermediate baseline must never take the bench line down
+            cpu["stock_pytorch_rocm"] = {"error": repr(e)[:200]}
     if rank == 0:
         out = {"metric": "env-steps/sec through PPO-Lagrangian update", "value": round(env_steps / (ms * 1e-3), 1), "unit": "env-steps/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
+               "n_gpus": world, "rccl_ranks": (torch.distributed.get_world_size() if world > 1 else 1),
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"C4-shard: {args.task}, T={T}-step rollout x {B} envs/GPU (BASELINE configs[3] per-GPU shard), "
-                                      f"L={args.L} goal tokens, S={S} fusion tokens, 3 towers x 4 epochs x 1 minibatch, Adam+clip",
-                          "global_envs": B * world, "rollout_steps": T, "rows_per_gpu": R, "parallelism": f"dp{world}",
+               "config": {"workload": f"C3: {args.task}, {B} envs/GPU x T={T}-step rollout, cost constraint active (cost_limit {args.cost_limit}) "
+                                      f"(BASELINE configs[2]{'' if world == 1 else ', replicated per GPU: weak scaling'}), "
+                                      f"L={args.L} goal tokens, S={S} fusion tokens, 3 towers x 4 epochs x 1 minibatch"
+                                      f"{'' if chunk is None else f' in {B // chunk} env-chunks of {chunk}'}, Adam+clip",
+                          "global_envs": B * world, "rollout_steps": T, "rows_per_gpu": R, "parallelism": f"dp{world}", "env_chunk": chunk,
                           "stage_losses": list(cfg.stage_losses), "weights": "random-init, reference geometry (168.9 M params)",
                           "dropout": 0.0 if args.eval_mode else 0.1},
                "reference_equivalent_tflop_per_update": round(algo / 1e12, 1),
                "note": "reference_equivalent counts SURVEY 8(d) FLOPs of the reference's schedule; the engine executes fewer (last fusion "
                        "layer only for the consumed token, T5 once per unique goal) -- see roofline.executed_mfma_*",
                "loss": {k: (round(v, 5) if isinstance(v, float) else v) for k, v in info.items()},
-               "roofline": roof, "cpu_baseline": cpu, "acting": acting, "north_star_batch256": ns}
+               "roofline": roof, "cpu_baseline": cpu, "acting": acting, "north_star_batch256": ns, "secondary": secondary}
         print(json.dumps(out), flush=True)
+    if world > 1:
+        parallel.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

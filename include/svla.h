@@ -44,9 +44,17 @@ int svla_ppo_lag_loss_fwd_bwd_f32(const float* logits, const float* values, cons
                                   int rows, int A, float lam, float clip, float value_coef, float action_w, float ent_coef,
                                   int use_clipped_value, float inv_n, float* dlogits, float* dvalues, double* sums,
                                   void* stream);
-/* PPOValue / SafePPOValue [3P AllenAct fork]; call sites training/online/dinov2_vits_tsfm_base.py:337-342. */
-int svla_value_mse_fwd_bwd_f32(const float* values, const float* returns, int rows, float coef, float inv_n, float* dvalues,
-                               double* sums, void* stream);
+/* PPOValue / SafePPOValue [3P AllenAct fork]; call sites training/online/dinov2_vits_tsfm_base.py:337-342.  old_values != NULL:
+ * the clipped form (use_clipped_value_loss=True; the expression of customized_loss.py:374-380 with clip_param = clip). */
+int svla_value_mse_fwd_bwd_f32(const float* values, const float* returns, const float* old_values, float clip, int rows, float coef,
+                               float inv_n, float* dvalues, double* sums, void* stream);
+/* HL-Gauss discrete critic: HLGaussLoss.forward / transform_to_probs / transform_from_probs (utils/loss_functions.py:7-30) and the
+ * value read-out of DiscreteCriticHead.forward (architecture/models/allenact_transformer_models/allenact_dino_transformer.py:743-766),
+ * forward + backward fused.  logits [rows, NB] (NB <= 256); values_out[r] = sum_j softmax_j * bin_centre_j (optional);
+ * target != NULL: sums[0] += cross-entropy(logits[r], hl_gauss_probs(target[r])), dlogits = coef * inv_n * d/dlogits of it;
+ * dvalue != NULL: dlogits += dvalue[r] * d values_out[r] / d logits (an MSE-type loss on the read-out value). */
+int svla_hlgauss_fwd_bwd_f32(const float* logits, const float* target, const float* dvalue, int rows, int NB, float vmin, float vmax,
+                             float sigma, float coef, float inv_n, float* values_out, float* dlogits, double* sums, void* stream);
 /* Imitation-learning action loss: nn.CrossEntropyLoss(ignore_index=-1), mean over non-ignored rows
  * (architecture/models/transformer_models/early_fusion_tsfm_models.py:93,115-117).  sums[0] += sum of row losses;
  * dlogits = (softmax - onehot) / *n_valid (device scalar). */
@@ -96,6 +104,16 @@ int svla_gemm_tn_f32acc(const svla_bf16* dY, long ldy, const svla_bf16* X, long 
                         int K, void* stream);
 /* db[N] += sum_m dY[m*row_stride, :] (bias gradients; row_stride > 1 picks one token of every [S, D] group). */
 int svla_colsum_bf16(const svla_bf16* dY, long ldy, int M, int N, int row_stride, float* db, void* stream);
+
+/* fp32 strided GEMM: C[m*ldc + n] (+)= epi(alpha * sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk]), epi = +bias[n] -> act (0 none, 1 ReLU,
+ * 2 GELU) -> dropout -> zero where mask[m*ldm + n] <= 0 -> +residual[m*ldr + n]; accumulate: C += (weight gradients).  The small fp32
+ * heads that are not MFMA-shaped (DiscreteCriticHead / MLPCriticHead, allenact_dino_transformer.py:720-766) and every linear layer of
+ * the policy in the fp32 verification mode (same cited layers as svla_gemm_nt_bf16 / svla_gemm_tn_f32acc). */
+int svla_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn, long sbk, const float* bias, const float* residual,
+                  long ldr, const float* mask, long ldm, float* C, long ldc, int M, int N, int K, int act, int accumulate, float alpha,
+                  const svla_dropout* drop, void* stream);
+/* out[n] += sum_m X[m*row_stride*ldx + n]: bias gradients of the fp32 path. */
+int svla_colsum_f32(const float* X, long ldx, int M, int N, int row_stride, float* out, void* stream);
 
 /* ---- attention ---------------------------------------------------------------------------------------------- */
 /* softmax(scale * Q K^T [+ bias] [mask]) V per (row, head), head_dim 64, tokens of one row contiguous (row*S + s).

@@ -39,7 +39,7 @@ class RefPositionalEncoder(nn.Module):
 
     def forward(self, position):  # (A,B) int -> (A,B,d)
         ang = position.unsqueeze(-1) * self.div_term
-        pe = torch.zeros(*position.shape, self.d_model)
+        pe = torch.zeros(*position.shape, self.d_model, device=position.device)
         pe[..., 0::2] = torch.sin(ang)
         pe[..., 1::2] = torch.cos(ang)
         return pe
@@ -237,6 +237,7 @@ class RefGoalEncoder(nn.Module):
 
     def text_features(self, goal_bytes):
         ids, am = self.tokenize(goal_bytes)
+        ids, am = ids.to(goal_bytes.device), am.to(goal_bytes.device)     # (the stock-PyTorch-ROCm baseline leg runs this port on the GPU)
         with torch.no_grad():
             emb = self.text_encoder(ids, am)
         return self.text_adapter(emb)

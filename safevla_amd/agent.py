@@ -10,6 +10,7 @@ update path's own.
 """
 import json
 import os
+import warnings
 from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
@@ -64,23 +65,58 @@ class InferenceAgentVIDA(AbstractAgent):
         self.steps_taken_in_task = 0
         self.last_action_flat = None
 
+    IL_VIT_PREFIX = "model.visual_encoder.image_encoder.model."      # where a Lightning IL checkpoint keeps its DINOv2 weights
+
     @classmethod
-    def build_agent(cls, actor_critic, device="cuda", greedy_sampling: bool = False, ckpt_path: Optional[str] = None, **kw):
+    def build_agent(cls, actor_critic, device="cuda", greedy_sampling: bool = False, ckpt_path: Optional[str] = None,
+                    spiece_model: Optional[str] = None, vit_weights: Optional[str] = None, **kw):
         """ckpt formats auto-detected like upstream (:128-165): Lightning ``state_dict`` (IL), AllenAct ``model_state_dict``, or a
-        bare state dict."""
+        bare state dict.
+
+        The reference pulls two more assets from the network that a checkpoint does not (or only partly) contain: the ``t5-small``
+        sentencepiece vocabulary and the frozen DINOv2 ViT-S/14 weights (torch.hub).  ``spiece_model`` = path of ``spiece.model``;
+        ``vit_weights`` = path of a DINOv2 ViT-S/14 ``state_dict`` (hub names).  A Lightning IL checkpoint that carries its image
+        encoder (``model.visual_encoder.image_encoder.model.*``) fills the ViT from there.  Running real weights on the offline
+        stand-ins (word-hash token ids, random-init ViT) produces meaningless actions, so that combination WARNS loudly."""
+        vit_sd = None
         if ckpt_path is not None:
             ckpt = torch.load(ckpt_path, map_location="cpu")
             if "state_dict" in ckpt:
-                checkpoint.load_pl_ckpt_allenact(actor_critic, ckpt["state_dict"])
+                checkpoint.load_pl_ckpt_allenact(actor_critic, ckpt)
                 actor_critic.sync_weights()
+                vit_sd = {k[len(cls.IL_VIT_PREFIX):]: v for k, v in ckpt["state_dict"].items() if k.startswith(cls.IL_VIT_PREFIX)} or None
             elif "model_state_dict" in ckpt:
                 actor_critic.load_state_dict(ckpt["model_state_dict"], strict=False)
             elif any(k.startswith(("visual_encoder.", "actor.", "decoder.")) for k in ckpt):
                 actor_critic.load_state_dict(ckpt, strict=False)
             else:
                 raise ValueError(f"Unknown checkpoint format; found keys {list(ckpt.keys())[:10]}")
+        if spiece_model is not None:
+            from .text import GoalTokenizer
+
+            actor_critic.tokenizer = GoalTokenizer(spiece_model)
+            actor_critic._goal_cache.clear()
+        if vit_weights is not None:
+            vit_sd = torch.load(vit_weights, map_location="cpu")
         actor_critic.eval()     # AllenAct's InferenceAgent runs the policy in eval mode (mode="test", inference_agent.py:98-102)
         agent = cls(actor_critic, device=device, greedy_sampling=greedy_sampling, **kw)
+        if vit_sd is not None:
+            missing, unexpected = agent.nav_pre.vit.load_state_dict(vit_sd, strict=False)
+            if missing:
+                warnings.warn(f"DINOv2 weights: {len(missing)} tensors not found (e.g. {missing[:3]}); those stay random-init")
+            agent.nav_pre.vit.sync()
+            if agent.manip_pre.vit is not agent.nav_pre.vit:
+                agent.manip_pre.vit.load_state_dict(vit_sd, strict=False)
+                agent.manip_pre.vit.sync()
+        if ckpt_path is not None:
+            stand_ins = []
+            if getattr(actor_critic.tokenizer, "_sp", None) is None:
+                stand_ins.append("word-hash goal tokenizer (pass spiece_model=<t5-small spiece.model>)")
+            if vit_sd is None and kw.get("nav_preprocessor") is None:
+                stand_ins.append("random-init DINOv2 ViT (pass vit_weights=<dinov2_vits14 state_dict>)")
+            if stand_ins:
+                warnings.warn("checkpoint loaded but offline stand-ins are active: " + "; ".join(stand_ins) +
+                              " -- the policy's inputs do not match what it was trained on, actions are meaningless", RuntimeWarning)
         agent.reset()
         return agent
 

@@ -3,7 +3,7 @@
 allenact_dino_transformer.py:470-475).  Same attribute names so losses / engines written against the
 reference read these objects unchanged."""
 from dataclasses import dataclass, field
-from typing import Any, Dict, Optional
+from typing import Any, Dict, NamedTuple, Optional
 
 import torch
 
@@ -47,3 +47,31 @@ class SafeActorCriticOutput:
     values: torch.Tensor
     c_values: torch.Tensor
     extras: Dict[str, Any] = field(default_factory=dict)
+
+
+class SafeRLStepResult(NamedTuple):
+    """What ``Task.step(action)`` returns in the reference (AllenAct-fork type [3P], constructed at
+    /root/reference/tasks/abstract_task.py:369-381): the RLStepResult fields plus the per-step safety ``cost``
+    (= number of triggered safety predicates, abstract_task.py:321-333)."""
+    observation: Optional[Any]
+    reward: Optional[float]
+    cost: Optional[float]
+    done: Optional[bool]
+    info: Optional[Dict[str, Any]]
+
+    def clone(self, new_info: Dict[str, Any]):
+        return SafeRLStepResult(observation=new_info.get("observation", self.observation), reward=new_info.get("reward", self.reward),
+                                cost=new_info.get("cost", self.cost), done=new_info.get("done", self.done), info=new_info.get("info", self.info))
+
+    def merge(self, other: "SafeRLStepResult"):
+        pick = lambda a, b: b if b is not None else a
+        return SafeRLStepResult(*[pick(a, b) for a, b in zip(self, other)])
+
+
+class Box(NamedTuple):
+    """Stand-in for ``gym.spaces.Box`` (gym is not a dependency here): the ``observation_space`` attribute the reference's
+    preprocessors expose (architecture/allenact_preprocessors/dino_preprocessors.py:90-99)."""
+    low: float
+    high: float
+    shape: tuple
+    dtype: str = "float32"

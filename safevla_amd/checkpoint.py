@@ -13,8 +13,10 @@ import torch
 
 def load_pl_ckpt_allenact(model, ckpt, ckpt_prefix: str = "model.", verbose: bool = False):
     """Load an imitation-learning (Lightning) checkpoint into ONE tower (or the 3-tower model's actor tower).
-    ``ckpt``: path or an already-loaded dict with a ``state_dict`` entry."""
-    sd = torch.load(ckpt, map_location="cpu")["state_dict"] if isinstance(ckpt, str) else ckpt["state_dict"]
+    ``ckpt``: path, an already-loaded Lightning checkpoint (dict with a ``state_dict`` entry) or that state dict itself."""
+    if isinstance(ckpt, str):
+        ckpt = torch.load(ckpt, map_location="cpu")
+    sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt          # whole Lightning checkpoint or its bare state dict
     sd = {k.replace("actor.weight", "actor.linear.weight").replace("actor.bias", "actor.linear.bias"): v for k, v in sd.items()}
     new = model.state_dict()
     loaded = [k for k in new if ckpt_prefix + k in sd]
@@ -63,7 +65,8 @@ def save_checkpoint(path: str, model, engine=None, total_steps: int = 0, extra: 
     ck = {"model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "total_steps": int(total_steps)}
     if engine is not None:
         ar = model.arena
-        ck["optimizer_state"] = {"exp_avg": ar.flat_m.cpu(), "exp_avg_sq": ar.flat_v.cpu(), "step": engine.opt_step}
+        ck["optimizer_state"] = {"exp_avg": ar.flat_m.cpu(), "exp_avg_sq": ar.flat_v.cpu(), "step": engine.opt_step,
+                                 "tower_steps": list(engine.tower_steps)}
         ck["lagrange"] = engine.lagrange.state_dict()
     if extra:
         ck.update(extra)
@@ -80,6 +83,7 @@ def load_checkpoint(path_or_dict, model, engine=None, drop_critic_tsfm: bool = F
         ar = model.arena
         ar.flat_m.copy_(ck["optimizer_state"]["exp_avg"]); ar.flat_v.copy_(ck["optimizer_state"]["exp_avg_sq"])
         engine.opt_step = int(ck["optimizer_state"]["step"])
+        engine.tower_steps = [int(x) for x in ck["optimizer_state"].get("tower_steps", [engine.opt_step] * 3)]
         if "lagrange" in ck:
             engine.lagrange.load_state_dict(ck["lagrange"])
     return res

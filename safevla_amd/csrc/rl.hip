@@ -156,24 +156,126 @@ extern "C" int svla_ppo_lag_loss_fwd_bwd_f32(const float* logits, const float* v
 }
 
 // PPOValue / SafePPOValue [3P]: 0.5*mean((returns - values)^2); sums[0] += sum sq err; dvalues = coef*(v-ret)*inv_n.
-__global__ void value_mse_kernel(const float* __restrict__ values, const float* __restrict__ returns, int rows, float coef,
-                                 float inv_n, float* __restrict__ dvalues, double* __restrict__ sums) {
+// old_values != NULL: upstream AllenAct's clipped form (use_clipped_value_loss=True, the same expression as
+// customized_loss.py:374-380): 0.5*mean(max((v-ret)^2, (clip(v, old +- clip_param) - ret)^2)).
+__global__ void value_mse_kernel(const float* __restrict__ values, const float* __restrict__ returns,
+                                 const float* __restrict__ old_values, float clip, int rows, float coef, float inv_n,
+                                 float* __restrict__ dvalues, double* __restrict__ sums) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     float s = 0.f;
     if (r < rows) {
-        const float d = values[r] - returns[r];
-        s = d * d;
-        dvalues[r] = coef * d * inv_n;
+        const float v = values[r], rt = returns[r];
+        const float d = v - rt;
+        if (old_values) {
+            const float ov = old_values[r], dv = v - ov;
+            const float vc = ov + fminf(fmaxf(dv, -clip), clip);
+            const float l1 = d * d, l2 = (vc - rt) * (vc - rt);
+            s = fmaxf(l1, l2);
+            const float gv = (l1 >= l2) ? d : ((dv >= -clip && dv <= clip) ? (vc - rt) : 0.f);
+            dvalues[r] = coef * gv * inv_n;
+        } else {
+            s = d * d;
+            dvalues[r] = coef * d * inv_n;
+        }
     }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) atomicAdd(&sums[0], (double)s);
 }
 
-extern "C" int svla_value_mse_fwd_bwd_f32(const float* values, const float* returns, int rows, float coef, float inv_n,
-                                          float* dvalues, double* sums, void* stream) {
+extern "C" int svla_value_mse_fwd_bwd_f32(const float* values, const float* returns, const float* old_values, float clip, int rows,
+                                          float coef, float inv_n, float* dvalues, double* sums, void* stream) {
     if (rows <= 0) return SVLA_EINVAL;
-    hipLaunchKernelGGL(value_mse_kernel, dim3((rows + 127) / 128), dim3(128), 0, (hipStream_t)stream, values, returns, rows,
-                       coef, inv_n, dvalues, sums);
+    hipLaunchKernelGGL(value_mse_kernel, dim3((rows + 127) / 128), dim3(128), 0, (hipStream_t)stream, values, returns, old_values, clip,
+                       rows, coef, inv_n, dvalues, sums);
+    return svla_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// HL-Gauss discrete critic (utils/loss_functions.py:7-30 + DiscreteCriticHead.forward, allenact_dino_transformer.py:743-766), one
+// wave per row, forward + backward fused:
+//   p = softmax(logits[r, :NB]);   value[r] = sum_j p_j * centre_j,  centre_j = (edge_j + edge_{j+1}) / 2,
+//   edge_j = torch.linspace(vmin, vmax, NB + 1)[j] (fp32, hl_edge below);
+//   target != NULL:  q_j = (erf((edge_{j+1} - t) / (sqrt(2) sigma)) - erf((edge_j - t) / (sqrt(2) sigma))) / z,
+//                    z = erf((edge_NB - t)/..) - erf((edge_0 - t)/..);   loss_r = -sum_j q_j log p_j  (F.cross_entropy with
+//                    probability targets);  sums[0] += loss_r;  dlogits = coef * inv_n * (p * sum(q) - q)
+//   dvalue != NULL:  dlogits += dvalue[r] * p_j * (centre_j - value[r])     (gradient through transform_from_probs(softmax))
+// torch.linspace(vmin, vmax, NB + 1)[j] as PyTorch computes it in fp32 (symmetric: from the start in the lower half, from the end above)
+__device__ __forceinline__ float hl_edge(int j, int NB, float vmin, float vmax, float step) {
+    return (j < (NB + 1) / 2) ? vmin + step * (float)j : vmax - step * (float)(NB - j);
+}
+
+__global__ void hlgauss_kernel(const float* __restrict__ logits, const float* __restrict__ target, const float* __restrict__ dvalue,
+                               int rows, int NB, float vmin, float vmax, float sigma, float coef, float inv_n,
+                               float* __restrict__ values_out, float* __restrict__ dlogits, double* __restrict__ sums) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* x = logits + (size_t)r * NB;
+    const float step = (vmax - vmin) / (float)NB;
+    float z[4], mx = -INFINITY;             // NB <= 256: up to 4 bins per lane
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = lane + 64 * u;
+        z[u] = j < NB ? x[j] : -INFINITY;
+        mx = fmaxf(mx, z[u]);
+    }
+    mx = wave_max(mx);
+    float se = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) se += (lane + 64 * u < NB) ? expf(z[u] - mx) : 0.f;
+    se = wave_sum(se);
+    const float lse = mx + logf(se);
+    float val = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = lane + 64 * u;
+        if (j < NB) {
+            const float e0 = hl_edge(j, NB, vmin, vmax, step), e1 = hl_edge(j + 1, NB, vmin, vmax, step);
+            val += expf(z[u] - lse) * (0.5f * (e0 + e1));
+        }
+    }
+    val = wave_sum(val);
+    if (values_out && lane == 0) values_out[r] = val;
+    float q[4] = {0.f, 0.f, 0.f, 0.f}, qs = 0.f, loss = 0.f;
+    if (target) {
+        const float t = target[r];
+        const float inv = 1.f / (1.41421356237309515f * sigma);
+        const float zt = erff((vmax - t) * inv) - erff((vmin - t) * inv);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = lane + 64 * u;
+            if (j < NB) {
+                const float e0 = hl_edge(j, NB, vmin, vmax, step), e1 = hl_edge(j + 1, NB, vmin, vmax, step);
+                q[u] = (erff((e1 - t) * inv) - erff((e0 - t) * inv)) / zt;
+                qs += q[u];
+                loss -= q[u] * (z[u] - lse);
+            }
+        }
+        qs = wave_sum(qs);
+        loss = wave_sum(loss);
+        if (sums && lane == 0) atomicAdd(&sums[0], (double)loss);
+    }
+    if (dlogits) {
+        const float dv = dvalue ? dvalue[r] : 0.f;
+        const float cl = target ? coef * inv_n : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = lane + 64 * u;
+            if (j < NB) {
+                const float p = expf(z[u] - lse);
+                const float e0 = hl_edge(j, NB, vmin, vmax, step), e1 = hl_edge(j + 1, NB, vmin, vmax, step);
+                dlogits[(size_t)r * NB + j] = cl * (p * qs - q[u]) + dv * p * (0.5f * (e0 + e1) - val);
+            }
+        }
+    }
+}
+
+extern "C" int svla_hlgauss_fwd_bwd_f32(const float* logits, const float* target, const float* dvalue, int rows, int NB, float vmin,
+                                        float vmax, float sigma, float coef, float inv_n, float* values_out, float* dlogits, double* sums,
+                                        void* stream) {
+    if (rows <= 0 || NB <= 0 || NB > 256 || !(vmax > vmin) || !(sigma > 0.f)) return SVLA_EINVAL;
+    hipLaunchKernelGGL(hlgauss_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, target, dvalue, rows, NB, vmin,
+                       vmax, sigma, coef, inv_n, values_out, dlogits, sums);
     return svla_launch_status();
 }
 

@@ -11,6 +11,16 @@ One update = GAE(reward+cost) -> lambda update -> update_repeats x num_mini_batc
 Towers run one after another (each tower's loss depends only on its own outputs), so only one tower's activations are
 resident at a time; env-chunking gives exact gradient accumulation because every loss is a mean over rows
 (inv_n = 1 / global rows).
+
+Data parallel: each tower owns one contiguous, aligned range of the flat gradient arena; as soon as a tower's backward
+of the LAST env-chunk has been issued its range is all-reduced asynchronously (RCCL runs on its own stream), overlapping the
+next tower's forward + backward; the optimiser step waits for the three handles.  Host syncs per update: ONE at the very start
+(the [sum cost, #episodes] all-reduce feeding the host-side lambda, before any kernel of the update is queued) and ONE at the end
+(the info scalars); the global row count of a minibatch is reduced once per storage geometry and cached.
+
+Adam bookkeeping follows torch.optim.Adam under ``zero_grad(set_to_none=True)`` (what the reference engine runs): a tower whose
+loss is not in the current stage's loss list has ``grad is None`` for all of its parameters, so the optimiser skips it -- its
+moments freeze and its per-parameter step count does not advance.  Here: per-tower step counters, inactive ranges are skipped.
 """
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -50,17 +60,34 @@ class PPOLagEngine:
     def __init__(self, model: SafeDinoLLAMATxNavActorCriticSeparate, cfg: PPOLagConfig):
         self.model, self.cfg = model, cfg
         self.lagrange = Lagrange(cfg.cost_limit, cfg.lambda_init, cfg.lambda_lr, cfg.lambda_optimizer, cfg.lambda_upper_bound)
-        self.opt_step = 0
+        self.opt_step = 0                     # optimiser steps taken (any tower)
+        self.tower_steps = [0, 0, 0]          # torch.optim.Adam's per-parameter ``step`` (identical within a tower)
+        self._pending = []                    # async all-reduce handles of the current minibatch
+        self._count_cache = {}
         dev = model.device_
         self._gnorm_sq = torch.zeros(1, device=dev, dtype=torch.float64)
-        self._sums = torch.zeros(5, device=dev, dtype=torch.float64)   # v_sq, action, -entropy, (pad), c_v_sq
+        self._sums = torch.zeros(5, device=dev, dtype=torch.float64)   # v_sq, action, -entropy, hl-gauss CE (discrete critic), c_v_sq
         self.gemm_flops = 0
         if parallel.is_dist():      # independent dropout noise per rank (every rank holds different environments)
             for t in model.towers:
                 t.drop_seed_base += 7919 * torch.distributed.get_rank()
 
     # ---- one minibatch: forward/backward of the three towers with fused losses ------------------------------------
-    def _accumulate(self, batch: Dict, n_total: int, lam: float):
+    def active_towers(self) -> Tuple[bool, bool, bool]:
+        """(actor, reward critic, cost critic): which towers receive a gradient under the current stage's loss list."""
+        names = set(self.cfg.stage_losses)
+        discrete = self.model.critic_type == "discrete"
+        return ("ppo_log_loss" in names, ("ppo_log_loss" in names and not discrete) or "ppo_value_loss" in names,
+                "safe_ppo_value_loss" in names or ("ppo_log_loss" in names and discrete))
+
+    def _reduce_tower_async(self, k: int):
+        if parallel.is_dist():
+            a, b = self.model.arena.tower_ranges[k]
+            self._pending.append(parallel.allreduce_sum_async(self.model.arena.flat_g[a:b]))
+
+    def _accumulate(self, batch: Dict, n_total: int, lam: float, last: bool = False):
+        """``last``: this is the final env-chunk of the minibatch -- each tower's gradient range is handed to the asynchronous
+        all-reduce right after that tower's backward has been issued."""
         cfg, m = self.cfg, self.model
         T, Bc = batch["actions"].shape
         R = T * Bc
@@ -69,6 +96,7 @@ class PPOLagEngine:
         f = lambda t: t.reshape(R).contiguous()
         names = set(cfg.stage_losses)
         sums = self._sums
+        ret_ = f(batch["returns"])
         if "ppo_log_loss" in names:
             # actor: clipped surrogate on the lambda-mixed advantage (+ entropy); critic: value_loss_coef * 0.5 * mse
             logits, _, c = m.run_forward(prep, need_grad=True)
@@ -78,30 +106,73 @@ class PPOLagEngine:
                                                 cfg.action_weight, cfg.entropy_coef, False, inv_n, sums=sums[0:3])
             m.run_backward(prep, c, dl.view(T, Bc, N_ACTIONS), None)
             del c, logits, dl
-        if "ppo_log_loss" in names or "ppo_value_loss" in names:
+            if last:
+                self._reduce_tower_async(0)
+        discrete = m.critic_type == "discrete"
+        if ("ppo_log_loss" in names and not discrete) or "ppo_value_loss" in names:
             coef = cfg.value_loss_coef if "ppo_log_loss" in names else 1.0
             tw = m.critic_tsfm
             _, values, c = tw.run_forward(prep, need_grad=True)
             _, dv = ops.value_mse_fwd_bwd(values.reshape(R), f(batch["returns"]), coef, inv_n, sums=sums[0:1])
             tw.run_backward(prep, c, None, dv.view(T, Bc, 1))
             del c, values, dv
-        if "safe_ppo_value_loss" in names:
+            if last:
+                self._reduce_tower_async(1)
+        if "safe_ppo_value_loss" in names or ("ppo_log_loss" in names and discrete):
             tw = m.c_critic_tsfm
             _, c_values, c = tw.run_forward(prep, need_grad=True)
-            _, dv = ops.value_mse_fwd_bwd(c_values.reshape(R), f(batch["c_returns"]), 1.0, inv_n, sums=sums[4:5])
-            tw.run_backward(prep, c, None, dv.view(T, Bc, 1))
-            del c, c_values, dv
+            dv = dfl = None
+            if "safe_ppo_value_loss" in names:
+                _, dv = ops.value_mse_fwd_bwd(c_values.reshape(R), f(batch["c_returns"]), 1.0, inv_n, sums=sums[4:5])
+                dv = dv.view(T, Bc, 1)
+            if "ppo_log_loss" in names and discrete:
+                # the reference's own data flow with critic_type="discrete": SafePPOLogGrad's value term is HL-Gauss(extras["full_logits"],
+                # returns) and the 3-tower wrapper's extras are the COST-critic tower's (customized_loss.py:364-370, separate_actor_critic.py:31-36)
+                lf, fl = tw.critic.loss_fn, tw._last_full_logits
+                _, dfl, _ = ops.hlgauss_fwd_bwd(fl.reshape(R, fl.shape[-1]), ret_, None, lf.min_value, lf.max_value, lf.sigma, 0.5 * cfg.value_loss_coef, inv_n,
+                                                want_values=False, sums=sums[3:4])
+                dfl = dfl.view(T, Bc, -1)
+            tw.run_backward(prep, c, None, dv, dfl)
+            del c, c_values, dv, dfl
+            if last:
+                self._reduce_tower_async(2)
 
-    def optimizer_step(self):
+    def optimizer_step(self, reduced: bool = False):
+        """Global-norm clip + Adam over the ranges of the towers that received a gradient.  ``reduced``: the per-tower asynchronous
+        all-reduces were already started by ``_accumulate(last=True)`` (wait for them); otherwise reduce the active ranges here."""
         cfg, ar = self.cfg, self.model.arena
-        parallel.allreduce_sum_(ar.flat_g)
+        active = self.active_towers()
+        if reduced:
+            for w in self._pending:
+                w.wait()
+        elif parallel.is_dist():
+            for k, on in enumerate(active):
+                if on:
+                    a, b = ar.tower_ranges[k]
+                    parallel.allreduce_sum_(ar.flat_g[a:b])
+        self._pending = []
         self._gnorm_sq.zero_()
-        ops.sumsq(ar.flat_g, self._gnorm_sq)
+        for k, on in enumerate(active):       # clip_grad_norm_ sees the parameters that have a gradient
+            if on:
+                a, b = ar.tower_ranges[k]
+                ops.sumsq(ar.flat_g[a:b], self._gnorm_sq)
         self.opt_step += 1
-        ops.adam_step(ar.flat_p, ar.flat_g, ar.flat_m, ar.flat_v, ar.flat_bf16, cfg.lr, self.opt_step, cfg.adam_betas[0], cfg.adam_betas[1],
-                      cfg.adam_eps, gnorm_sq=self._gnorm_sq, max_norm=cfg.max_grad_norm)
-        for t in self.model.towers:
-            t.refresh_transposes()
+        for k, on in enumerate(active):
+            if not on:
+                continue
+            a, b = ar.tower_ranges[k]
+            self.tower_steps[k] += 1
+            ops.adam_step(ar.flat_p[a:b], ar.flat_g[a:b], ar.flat_m[a:b], ar.flat_v[a:b], ar.flat_bf16[a:b], cfg.lr, self.tower_steps[k],
+                          cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps, gnorm_sq=self._gnorm_sq, max_norm=cfg.max_grad_norm)
+            self.model.towers[k].refresh_transposes()
+
+    def _global_rows(self, local_rows: int, dev) -> int:
+        """Rows of the minibatch over all ranks: reduced once per local geometry, then cached (no per-minibatch host sync)."""
+        if not parallel.is_dist():
+            return int(local_rows)
+        if local_rows not in self._count_cache:
+            self._count_cache[local_rows] = parallel.global_count(local_rows, dev)
+        return self._count_cache[local_rows]
 
     # ---- one full PPO-Lagrangian update on a filled storage --------------------------------------------------------------
     def update(self, storage: RolloutStorage, next_value: torch.Tensor, next_c_value: torch.Tensor,
@@ -119,18 +190,18 @@ class PPOLagEngine:
             order = torch.randperm(cfg.num_mini_batch, generator=generator).tolist() if cfg.num_mini_batch > 1 else [0]
             for i in order:
                 b0, b1 = bounds[i], bounds[i + 1]
-                n_total = parallel.global_count(T * (b1 - b0), dev)
+                n_total = self._global_rows(T * (b1 - b0), dev)
                 m.zero_grad()
                 self._sums.zero_()
                 chunk = cfg.env_chunk or (b1 - b0)
                 for c0 in range(b0, b1, chunk):
-                    self._accumulate(storage.batch_slice(c0, min(b1, c0 + chunk)), n_total, lam)
-                self.optimizer_step()
+                    self._accumulate(storage.batch_slice(c0, min(b1, c0 + chunk)), n_total, lam, last=c0 + chunk >= b1)
+                self.optimizer_step(reduced=True)
                 parallel.allreduce_sum_(self._sums)
                 info_acc += self._sums / n_total
                 n_mb += 1
-        s = (info_acc / n_mb).cpu().tolist()      # the update's only host sync
-        value, action, ent, c_value = 0.5 * s[0], s[1], s[2], 0.5 * s[4]
+        s = (info_acc / n_mb).cpu().tolist()      # host sync at the end of the update (the other one is the Jc reduction at its start)
+        value, action, ent, c_value = 0.5 * (s[3] if m.critic_type == "discrete" else s[0]), s[1], s[2], 0.5 * s[4]
         return {"ppo_total": cfg.value_loss_coef * value + cfg.action_weight * action + cfg.entropy_coef * ent, "value": value,
                 "action": action, "entropy": ent, "c_value": c_value, "lagrangian_multiplier": lam, "Jc": Jc,
-                "env_steps": parallel.global_count(T * B, dev)}
+                "env_steps": self._global_rows(T * B, dev)}

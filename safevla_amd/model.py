@@ -27,6 +27,7 @@ import torch.nn as nn
 
 from . import ops
 from .api import CategoricalDistr, SafeActorCriticOutput
+from .losses import HLGaussLoss
 from .text import GoalTokenizer, bytes_to_str
 
 N_ACTIONS = 20
@@ -56,8 +57,20 @@ class _Arena:
     def declare(self, owner: nn.Module, name: str, shape, init: str):
         self.specs.append((owner, name, tuple(shape), init))
 
+    def begin_tower(self, align: int = 256):
+        """Start a new tower's contiguous range on an ``align``-element boundary (16-byte aligned bf16 weight views for the LDS-DMA
+        loads of every tower -- one tower has an odd number of trainable elements -- and per-tower all-reduce / Adam ranges)."""
+        n = sum(int(np.prod(s[2])) for s in self.specs)
+        pad = (-n) % align
+        if pad:
+            self.specs.append((None, "_pad", (pad,), "zeros"))
+        self._tower_starts = getattr(self, "_tower_starts", []) + [n + pad]
+
     def build(self, device):
         total = sum(int(np.prod(s[2])) for s in self.specs)
+        total += (-total) % 256
+        starts = getattr(self, "_tower_starts", [0])
+        self.tower_ranges = [(a, b) for a, b in zip(starts, starts[1:] + [total])]
         self.total = total
         self.flat_p = torch.zeros(total, device=device, dtype=F32)
         self.flat_g = torch.zeros(total, device=device, dtype=F32)
@@ -68,6 +81,9 @@ class _Arena:
         g = torch.Generator().manual_seed(0)
         for owner, name, shape, init in self.specs:
             n = int(np.prod(shape))
+            if owner is None:        # alignment padding: stays zero (zero gradient => Adam never moves it)
+                off += n
+                continue
             view = self.flat_p[off:off + n].view(shape)
             view.copy_(_init_tensor(shape, init, g).to(device))
             p = nn.Parameter(view, requires_grad=True)
@@ -108,8 +124,12 @@ def _init_tensor(shape, init, g):
 class Tower(nn.Module):
     """``DinoLLAMATxNavActorCritic`` (full-sensor configuration of dinov2_vits_tsfm_base.py:234-270)."""
 
-    def __init__(self, arena: _Arena, device, n_fusion_layers=3, n_decoder_layers=3, max_steps=500):
+    def __init__(self, arena: _Arena, device, n_fusion_layers=3, n_decoder_layers=3, max_steps=500, critic_type="linear"):
         super().__init__()
+        if critic_type not in ("linear", "mlp", "discrete"):
+            print(f"Unknown critic type: {critic_type}")
+            raise NotImplementedError
+        self.critic_type = critic_type
         self.arena = arena
         self.device_ = device
         self.max_steps = max_steps
@@ -173,8 +193,20 @@ class Tower(nn.Module):
         self.decoder.output = _NS(); dec(self.decoder.output, "weight", (D, D), "lin")
         self.actor = _NS(); self.actor.linear = _NS()
         dec(self.actor.linear, "weight", (N_ACTIONS, D), "actor"); dec(self.actor.linear, "bias", (N_ACTIONS,), "zeros")
-        self.critic = _NS(); self.critic.fc = _NS()
-        dec(self.critic.fc, "weight", (1, D), "critic"); dec(self.critic.fc, "bias", (1,), "zeros")
+        # critic heads of allenact_dino_transformer.py:147-162 (LinearCriticHead [3P] / MLPCriticHead :720-740 / DiscreteCriticHead :743-766)
+        self.critic = _NS()
+        if critic_type == "linear":
+            self.critic.fc = _NS()
+            dec(self.critic.fc, "weight", (1, D), "critic"); dec(self.critic.fc, "bias", (1,), "zeros")
+            self._head_dims = []
+        else:
+            dims = [D, 256, 101] if critic_type == "discrete" else [D, 256, 256, 1]
+            self.critic.fc = _seq(2 * (len(dims) - 1) - 1)              # Linear, ReLU, Linear[, ReLU, Linear]: state_dict keys fc.0 / fc.2 [/ fc.4]
+            for j in range(len(dims) - 1):
+                dec(self.critic.fc[2 * j], "weight", (dims[j + 1], dims[j]), "critic"); dec(self.critic.fc[2 * j], "bias", (dims[j + 1],), "zeros")
+            self._head_dims = dims
+            if critic_type == "discrete":   # "bins = 101 ... -5 to 15 ... sigma=0.15" (:152-156)
+                self.critic.loss_fn = HLGaussLoss(min_value=-5.0, max_value=15.0, num_bins=101, sigma=0.15)
         self._wt: Dict[str, torch.Tensor] = {}
 
     # ---- weight views -------------------------------------------------------------------------------------
@@ -359,13 +391,58 @@ class Tower(nn.Module):
         nf, _, rf = ops.norm_fwd(xd, self.decoder.norm.weight, None, 1e-5, R, rms=True, save_stats=need_grad)
         beliefs = ops.gemm_nt(nf, w["dout"], R, D, D, out_f32=True)             # fp32, rows (b*T + t)
         logits = ops.small_linear_fwd(beliefs, self.actor.linear.weight, self.actor.linear.bias, T, B)   # rows (t*B + b)
-        values = ops.small_linear_fwd(beliefs, self.critic.fc.weight, self.critic.fc.bias, T, B)
+        full_logits = None
+        if self.critic_type == "linear":
+            values = ops.small_linear_fwd(beliefs, self.critic.fc.weight, self.critic.fc.bias, T, B)
+        else:
+            values, full_logits, c["head"] = self._critic_head_fwd(beliefs, T, B)
         c.update(dec=dl, xd_last=xd, nf=nf, rf=rf, beliefs=beliefs, xf_last=xf)
+        self._last_full_logits = full_logits        # [T, B, 101] fp32 (critic_type == "discrete"), read by the 3-tower wrapper / engine
         return logits.view(T, B, N_ACTIONS), values.view(T, B, 1), (c if need_grad else None)
 
+    # ---- MLP / discrete critic heads (fp32, strided-GEMM kernel; rows come in decoder order b*T + t, leave in (t*B + b)) --------
+    def _critic_head_fwd(self, beliefs, T, B):
+        R, dims, fc = T * B, self._head_dims, self.critic.fc
+        hs = [beliefs]
+        for j in range(len(dims) - 1):
+            last = j == len(dims) - 2
+            hs.append(ops.gemm_f32(hs[-1], fc[2 * j].weight, R, dims[j + 1], dims[j], bias=fc[2 * j].bias, act=ops.ACT_NONE if last else ops.ACT_RELU))
+        out_tb = hs[-1].view(B, T, dims[-1]).transpose(0, 1).contiguous()           # -> rows (t*B + b)
+        if self.critic_type == "discrete":
+            values, _, _ = ops.hlgauss_fwd_bwd(out_tb.view(R, dims[-1]), None, None, self.critic.loss_fn.min_value, self.critic.loss_fn.max_value,
+                                               self.critic.loss_fn.sigma, want_grad=False)
+            return values, out_tb, hs
+        return out_tb.reshape(R), None, hs
+
+    def _critic_head_bwd(self, hs, T, B, dvalues, dfull, dbel, accumulate_dx):
+        """dvalues [T,B,1] and/or dfull [T,B,101] -> parameter grads (arena) and dbel [R,512] (rows b*T + t)."""
+        R, dims, fc, g = T * B, self._head_dims, self.critic.fc, self.g
+        if self.critic_type == "discrete":
+            lf = self.critic.loss_fn
+            flog_tb = hs[-1].view(B, T, dims[-1]).transpose(0, 1).contiguous().view(R, dims[-1])
+            d_tb = None
+            if dvalues is not None:      # gradient through the read-out value = sum softmax * centres
+                _, d_tb, _ = ops.hlgauss_fwd_bwd(flog_tb, None, dvalues.reshape(R).contiguous(), lf.min_value, lf.max_value, lf.sigma, want_values=False)
+            if dfull is not None:
+                d_tb = dfull.reshape(R, dims[-1]) if d_tb is None else d_tb + dfull.reshape(R, dims[-1])
+        else:
+            d_tb = dvalues.reshape(R, 1)
+        dy = d_tb.view(T, B, dims[-1]).transpose(0, 1).contiguous().view(R, dims[-1]).float()     # back to decoder order
+        for j in reversed(range(len(dims) - 1)):
+            n_out, n_in, x = dims[j + 1], dims[j], hs[j]
+            w = fc[2 * j].weight
+            ops.gemm_f32(dy, x, n_out, n_in, R, sa=(1, n_out), sb=(1, n_in), out=g(w), accumulate=True)      # dW += dY^T X
+            ops.colsum_f32(dy, g(fc[2 * j].bias), R, n_out)
+            if j == 0:
+                ops.gemm_f32(dy, w, R, n_in, n_out, sb=(1, n_in), out=dbel, accumulate=accumulate_dx)       # dX = dY W
+            else:
+                dy = ops.gemm_f32(dy, w, R, n_in, n_out, sb=(1, n_in), mask=x)                              # ... through the ReLU
+
     # ---- backward -----------------------------------------------------------------------------------------------
-    def run_backward(self, prep: "Prep", c, dlogits: Optional[torch.Tensor], dvalues: Optional[torch.Tensor]):
-        """Accumulates parameter gradients into the arena's flat grad buffer."""
+    def run_backward(self, prep: "Prep", c, dlogits: Optional[torch.Tensor], dvalues: Optional[torch.Tensor],
+                     dfull_logits: Optional[torch.Tensor] = None):
+        """Accumulates parameter gradients into the arena's flat grad buffer.  ``dfull_logits``: gradient of the discrete critic's
+        bin logits (HL-Gauss loss), critic_type == "discrete" only."""
         T, B, R, S, L, U = prep.T, prep.B, prep.R, prep.S, prep.L, prep.U
         ve, w, wt, dw, g = self.visual_encoder, self._w, self._wt, self._dw, self.g
         M2, M = R * 2 * NPATCH, R * S
@@ -376,7 +453,11 @@ class Tower(nn.Module):
             ops.small_linear_bwd(c["beliefs"], self.actor.linear.weight, dlogits.reshape(R, N_ACTIONS).contiguous(), dbel,
                                  g(self.actor.linear.weight), g(self.actor.linear.bias), T, B, accumulate_dx=False)
             first = False
-        if dvalues is not None:
+        if self.critic_type != "linear":
+            if dvalues is not None or dfull_logits is not None:
+                self._critic_head_bwd(c["head"], T, B, dvalues, dfull_logits, dbel, accumulate_dx=not first)
+                first = False
+        elif dvalues is not None:
             ops.small_linear_bwd(c["beliefs"], self.critic.fc.weight, dvalues.reshape(R, 1).contiguous(), dbel,
                                  g(self.critic.fc.weight), g(self.critic.fc.bias), T, B, accumulate_dx=not first)
             first = False
@@ -607,12 +688,15 @@ class _TowerFn(torch.autograd.Function):
         logits, values, saved = tower.run_forward(prep, need_grad=need)
         ctx.tower, ctx.prep, ctx.saved = tower, prep, saved
         ctx.want = (want_logits, want_values)
-        return logits, values
+        full = tower._last_full_logits
+        ctx.has_full = full is not None
+        return logits, values, (full if full is not None else logits.new_zeros(0))
 
     @staticmethod
-    def backward(ctx, dlogits, dvalues):
+    def backward(ctx, dlogits, dvalues, dfull):
         wl, wv = ctx.want
-        ctx.tower.run_backward(ctx.prep, ctx.saved, dlogits.contiguous() if wl else None, dvalues.contiguous() if wv else None)
+        ctx.tower.run_backward(ctx.prep, ctx.saved, dlogits.contiguous() if wl else None, dvalues.contiguous() if wv else None,
+                               dfull.contiguous() if (wv and ctx.has_full) else None)
         ctx.saved = None
         return None, None, None, None, None
 
@@ -623,15 +707,18 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
     def __init__(self, device="cuda", tokenizer: Optional[GoalTokenizer] = None, max_steps: int = 500,
                  goal_sensor_uuid="natural_language_spec", rgb_dino_preprocessor_uuid="rgb_dinov2",
                  manipulation_rgb_dino_preprocessor_uuid="manipulation_rgb_dinov2", an_object_is_in_hand_uuid="an_object_is_in_hand",
-                 time_step_uuid="time_step", traj_idx_uuid="traj_index", **unused):
+                 time_step_uuid="time_step", traj_idx_uuid="traj_index", critic_type: str = "linear", **unused):
         if not torch.cuda.is_available():
             raise RuntimeError("safevla_amd needs an MI355X: there is no CPU or eager fallback for the policy kernels")
         ops.lib()  # fail loudly if the HIP extension is missing
         arena = _Arena()
         device = torch.device(device)
-        super().__init__(arena, device, max_steps=max_steps)
-        self.critic_tsfm = Tower(arena, device, max_steps=max_steps)
-        self.c_critic_tsfm = Tower(arena, device, max_steps=max_steps)
+        arena.begin_tower()
+        super().__init__(arena, device, max_steps=max_steps, critic_type=critic_type)      # every tower is built from the same kwargs
+        arena.begin_tower()
+        self.critic_tsfm = Tower(arena, device, max_steps=max_steps, critic_type=critic_type)
+        arena.begin_tower()
+        self.c_critic_tsfm = Tower(arena, device, max_steps=max_steps, critic_type=critic_type)
         arena.build(device)
         self.towers = [self, self.critic_tsfm, self.c_critic_tsfm]
         for t in self.towers:
@@ -802,16 +889,31 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
         if (prep.T == 1 and getattr(self, "_acting_graphs", None) is not None and not torch.is_grad_enabled()
                 and self.time_step_counter < self.max_steps - 1 and all(t.time_step_counter == self.time_step_counter for t in self.towers)):
             logits, values, c_values = self._acting_step_graph(prep)
-            with torch.no_grad():
-                fc = self.c_critic_tsfm.critic.fc
-                extras = {"weight_norm": fc.weight.norm(2).reshape(1), "bias_norm": fc.bias.norm(2).reshape(1)}
-            return SafeActorCriticOutput(distributions=CategoricalDistr(logits), values=values, c_values=c_values, extras=extras), memory
+            return SafeActorCriticOutput(distributions=CategoricalDistr(logits), values=values, c_values=c_values, extras={}), memory
         if prep.T == 1 and torch.is_grad_enabled():
             raise RuntimeError("single-step (acting) forwards run under torch.no_grad(), as in the reference's rollout collection")
-        logits, _ = _TowerFn.apply(self._anchor, self, prep, True, False)
-        _, values = _TowerFn.apply(self._anchor, self.critic_tsfm, prep, False, True)
-        _, c_values = _TowerFn.apply(self._anchor, self.c_critic_tsfm, prep, False, True)
-        with torch.no_grad():
-            fc = self.c_critic_tsfm.critic.fc
-            extras = {"weight_norm": fc.weight.norm(2).reshape(1), "bias_norm": fc.bias.norm(2).reshape(1)}
+        logits, _, _ = _TowerFn.apply(self._anchor, self, prep, True, False)
+        _, values, _ = _TowerFn.apply(self._anchor, self.critic_tsfm, prep, False, True)
+        _, c_values, c_full = _TowerFn.apply(self._anchor, self.c_critic_tsfm, prep, False, True)
+        # the diagnostics in ``extras`` are consumed by the losses only (update batches); single-step acting forwards skip them
+        extras = self._extras(c_values, c_full) if prep.T > 1 else {}
         return SafeActorCriticOutput(distributions=CategoricalDistr(logits), values=values, c_values=c_values, extras=extras), memory
+
+    def _extras(self, c_values, c_full=None):
+        """``extras`` of the COST-critic tower, which is what the 3-tower wrapper hands on (separate_actor_critic.py:31-36); keys per
+        allenact_dino_transformer.py:425-463: total_norm (the tower's gradient norm as left by the previous backward), stop_grad_values
+        (or stop_grad_logits / full_logits / loss_func for the discrete critic), weight_norm / bias_norm / weight_grad_norm of the last
+        critic layer.  Device tensors (the reference builds host tensors with one sync each)."""
+        tw = self.c_critic_tsfm
+        with torch.no_grad():
+            fc = tw.critic.fc if tw.critic_type == "linear" else tw.critic.fc[-1]
+            a, b = self.arena.tower_ranges[2]
+            sq = torch.zeros(1, device=self.device_, dtype=torch.float64)
+            ops.sumsq(self.arena.flat_g[a:b], sq)
+            extras = {"total_norm": sq.sqrt().float(), "weight_norm": fc.weight.norm(2).reshape(1), "bias_norm": fc.bias.norm(2).reshape(1),
+                      "weight_grad_norm": tw.g(fc.weight).norm(2).reshape(1)}
+        if tw.critic_type == "discrete" and c_full is not None and c_full.numel():
+            extras.update(full_logits=c_full, stop_grad_logits=c_full.detach(), loss_func=tw.critic.loss_fn)
+        else:
+            extras["stop_grad_values"] = c_values.detach()
+        return extras

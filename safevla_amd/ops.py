@@ -66,13 +66,47 @@ def ppo_lag_loss_fwd_bwd(logits, values, actions, old_logp, adv, c_adv, returns,
     return sums, dlogits, dvalues
 
 
-def value_mse_fwd_bwd(values, returns, coef, inv_n, sums=None):
+def value_mse_fwd_bwd(values, returns, coef, inv_n, sums=None, old_values=None, clip=0.0):
+    """``old_values`` given: the clipped value loss (max of the plain and the clipped squared error)."""
     R = values.numel()
     dvalues = torch.empty(R, device=values.device, dtype=F32)
     if sums is None:
         sums = torch.zeros(1, device=values.device, dtype=torch.float64)
-    lib().call("svla_value_mse_fwd_bwd_f32", _p(values), _p(returns), R, float(coef), float(inv_n), _p(dvalues), _p(sums), _stream())
+    lib().call("svla_value_mse_fwd_bwd_f32", _p(values), _p(returns), _p(old_values), float(clip), R, float(coef), float(inv_n),
+               _p(dvalues), _p(sums), _stream())
     return sums, dvalues
+
+
+def hlgauss_fwd_bwd(logits, target=None, dvalue=None, vmin=-5.0, vmax=15.0, sigma=0.15, coef=1.0, inv_n=1.0, want_values=True,
+                    want_grad=True, sums=None):
+    """logits [R, NB] fp32 -> (values [R] or None, dlogits [R, NB] or None, sums[1] double)."""
+    _chk(logits, F32, "logits")
+    R, NB = logits.shape
+    values = torch.empty(R, device=logits.device, dtype=F32) if want_values else None
+    dlogits = torch.empty_like(logits) if want_grad else None
+    if sums is None and target is not None:
+        sums = torch.zeros(1, device=logits.device, dtype=torch.float64)
+    lib().call("svla_hlgauss_fwd_bwd_f32", _p(logits), _p(target), _p(dvalue), R, NB, float(vmin), float(vmax), float(sigma), float(coef),
+               float(inv_n), _p(values), _p(dlogits), _p(sums), _stream())
+    return values, dlogits, sums
+
+
+def gemm_f32(A, B, M, N, K, sa=None, sb=None, bias=None, act=ACT_NONE, residual=None, mask=None, out=None, accumulate=False, alpha=1.0,
+             drop=None, ldc=None, ldr=None, ldm=None):
+    """fp32 strided GEMM: out[M,N] (+)= epi(alpha * A(m,k) B(n,k)); ``sa`` = (row stride, k stride) of A (default: [M,K] row-major),
+    ``sb`` = (n stride, k stride) of B (default: [N,K] row-major, i.e. ``x @ W.T``)."""
+    _chk(A, F32, "A"); _chk(B, F32, "B")
+    sa = sa or (K, 1)
+    sb = sb or (K, 1)
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=F32)
+    lib().call("svla_gemm_f32", _p(A), int(sa[0]), int(sa[1]), _p(B), int(sb[0]), int(sb[1]), _p(bias), _p(residual), int(ldr or N),
+               _p(mask), int(ldm or N), _p(out), int(ldc or N), M, N, K, int(act), int(bool(accumulate)), float(alpha), _d(drop), _stream())
+    return out
+
+
+def colsum_f32(X, out, M, N, row_stride=1, ldx=None):
+    lib().call("svla_colsum_f32", _p(X), int(ldx or N), M, N, int(row_stride), _p(out), _stream())
 
 
 def small_linear_fwd(x, W, bias, T=0, B=0):

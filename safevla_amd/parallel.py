@@ -54,10 +54,41 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, local, world
 
 
+def broadcast_model_(model, src: int = 0):
+    """Identical replicas: broadcast the trainable arena AND every other parameter / buffer (the frozen T5 text encoder is drawn from
+    the global RNG at construction, so ranks seeded differently would otherwise hold different frozen encoders), then refresh the
+    bf16 mirrors.  No-op on a single rank."""
+    if not is_dist():
+        return
+    ar = model.arena
+    dist.broadcast(ar.flat_p, src=src)
+    lo, hi = ar.flat_p.data_ptr(), ar.flat_p.data_ptr() + ar.flat_p.numel() * ar.flat_p.element_size()
+    seen = set()
+    for t in list(model.parameters()) + list(model.buffers()):
+        if lo <= t.data_ptr() < hi or t.data_ptr() in seen:       # arena views / tied tensors
+            continue
+        seen.add(t.data_ptr())
+        dist.broadcast(t.data, src=src)
+    model.sync_weights()
+
+
 def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     if is_dist():
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def allreduce_sum_async(t: torch.Tensor, group=None):
+    """SUM all-reduce started on the backend's own stream (RCCL: overlaps with kernels issued afterwards on the compute stream);
+    ``.wait()`` on the handle orders the compute stream behind it."""
+    if not is_dist():
+        return _Done()
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
 
 
 def global_count(local: int, device, group=None) -> int:

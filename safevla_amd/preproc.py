@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .api import Box
 from .model import _NS
 
 DINO_RGB_MEANS = (0.48145466, 0.4578275, 0.40821073)
@@ -37,6 +38,7 @@ class DataAugmentationPreprocessor:
             raise NotImplementedError("torchvision augmentation lists are simulator-side configuration (off for synthetic runs)")
         self.input_uuids, self.uuid, self.device = [rgb_input_uuid], output_uuid, torch.device(device)
         self.mean, self.stdev, self.normalize = mean, stdev, normalize
+        self.observation_space = Box(-float("inf"), float("inf"), (height, width, 3))        # dino_preprocessors.py:205-214
 
     def to(self, device):
         self.device = torch.device(device)
@@ -143,6 +145,8 @@ class DinoViTPreprocessor:
         assert dino_model_type == "dinov2_vits14", "only the shipped ViT-S/14 geometry is built"
         self.input_uuids, self.uuid, self.device = [rgb_input_uuid], output_uuid, torch.device(device)
         self.vit = DinoViT(self.device)
+        flatten = kw.get("flatten", True)
+        self.observation_space = Box(-float("inf"), float("inf"), (7 * 12, 384) if flatten else (7, 12, 384))   # dino_preprocessors.py:55-59,90-99
 
     def to(self, device):
         return self

@@ -55,6 +55,7 @@ class RolloutStorage:
         self.actions = torch.zeros(T, B, device=dev, dtype=torch.int64)
         self.prev_actions = torch.zeros(T + 1, B, device=dev, dtype=torch.int64)
         self.adv_targ = self.c_adv_targ = None
+        self._norm = None
         self.step = 0
         self._insert_obs(obs, 0)
         self.masks[0] = 0.0   # first step of a fresh storage: no previous action (AllenAct convention)
@@ -109,22 +110,48 @@ class RolloutStorage:
         self.returns[:T].copy_(ret.view(T, B, 1))
         self.c_returns[:T].copy_(c_ret.view(T, B, 1))
         self.adv_targ, self.c_adv_targ = adv.view(T, B, 1), c_adv.view(T, B, 1)
+        self._norm = None
 
-    def batched_experience_generator(self, num_mini_batch: int = 1, generator: Optional[torch.Generator] = None) -> Iterator[Dict]:
+    def normalized_advantages(self):
+        """``norm_adv_targ`` = (adv - mean) / (std + 1e-5) with the moments taken over ALL samplers of all ranks (upstream AllenAct's
+        ``adv_stats_callback`` [3P]; unbiased std like ``Tensor.std()``), same for the cost advantages.  Lazy: the shipped pipeline
+        runs with ``normalize_advantage=False`` (dinov2_vits_tsfm_base.py:321) and never asks for it."""
+        if self._norm is None:
+            from . import parallel
+
+            out = []
+            for a in (self.adv_targ, self.c_adv_targ):
+                ad = a.double()
+                mom = torch.stack([ad.sum(), (ad * ad).sum(), torch.tensor(float(a.numel()), device=a.device, dtype=torch.float64)])
+                parallel.allreduce_sum_(mom)
+                mean = mom[0] / mom[2]
+                var = (mom[1] - mom[2] * mean * mean) / torch.clamp(mom[2] - 1, min=1.0)
+                out.append(((ad - mean) / (var.clamp(min=0).sqrt() + 1e-5)).float())
+            self._norm = tuple(out)
+        return self._norm
+
+    def batched_experience_generator(self, num_mini_batch: int = 1, generator: Optional[torch.Generator] = None,
+                                     normalized: bool = True) -> Iterator[Dict]:
         """Mini-batches split the *env* axis into contiguous groups (random order), all T steps of each group."""
         T, B = self.T, self.B
         assert B >= num_mini_batch
         order = torch.randperm(num_mini_batch, generator=generator).tolist() if num_mini_batch > 1 else [0]
         bounds = [round(i * B / num_mini_batch) for i in range(num_mini_batch + 1)]
         for i in order:
-            yield self.batch_slice(bounds[i], bounds[i + 1])
+            yield self.batch_slice(bounds[i], bounds[i + 1], normalized=normalized)
 
-    def batch_slice(self, b0: int, b1: int) -> Dict:
+    def batch_slice(self, b0: int, b1: int, normalized: bool = False) -> Dict:
+        """``normalized``: also provide ``norm_adv_targ`` / ``c_norm_adv_targ`` (a loss built with ``normalize_advantage=True`` reads
+        them; without them it raises a KeyError instead of silently training on raw advantages)."""
         T = self.T
         s = slice(b0, b1)
-        return dict(
+        extra = {}
+        if normalized:
+            na, nca = self.normalized_advantages()
+            extra = dict(norm_adv_targ=na[:, s], c_norm_adv_targ=nca[:, s])
+        return dict(**extra, 
             observations={k: v[:T, s] for k, v in self.observations.items()}, memory=None, prev_actions=self.prev_actions[:T, s],
             masks=self.masks[:T, s], actions=self.actions[:, s], old_action_log_probs=self.action_log_probs[:, s],
             values=self.value_preds[:T, s], c_values=self.c_value_preds[:T, s], returns=self.returns[:T, s],
             c_returns=self.c_returns[:T, s], adv_targ=self.adv_targ[:, s], c_adv_targ=self.c_adv_targ[:, s],
-            norm_adv_targ=self.adv_targ[:, s], c_norm_adv_targ=self.c_adv_targ[:, s], bsize=T * (b1 - b0))
+            bsize=T * (b1 - b0))

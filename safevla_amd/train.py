@@ -42,7 +42,11 @@ def build_parser():
     # synthetic-run controls (not in the reference)
     ap.add_argument("--num_steps", type=int, default=128, help="rollout length (reference: TrainingSettings(num_steps=128))")
     ap.add_argument("--total_steps", type=int, default=0, help="stop after this many env steps (0: run the full stage schedule)")
-    ap.add_argument("--task", default="ObjectNav")
+    ap.add_argument("--task", default="ObjectNav", help="ObjectNav | PickUp | Fetch | Mixed (env e -> task e mod 3)")
+    ap.add_argument("--collect", default="acting", choices=["acting", "teacher"],
+                    help="acting: step the synthetic vector env through the KV-cached single-step policy like the reference engine; "
+                         "teacher: fill the storage with one full-sequence pass (benchmark mode)")
+    ap.add_argument("--goal_tokens", type=int, default=12)
     return ap
 
 
@@ -59,14 +63,18 @@ def main(argv=None):
     from .checkpoint import init_towers_from_il, load_checkpoint, save_checkpoint
     from .engine import PPOLagConfig, PPOLagEngine
     from .model import SafeDinoLLAMATxNavActorCriticSeparate
-    from .synth_env import SynthSpec, fill_synthetic_rollout
+    from .storage import RolloutStorage
+    from .synth_env import SynthSpec, SynthVectorEnv, collect_rollout, fill_synthetic_rollout
 
     rank, local, world = parallel.init_from_env()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    torch.manual_seed((args.seed or 0) + rank)
-    _, B = parallel.shard_envs(args.num_train_processes, world, rank)
+    # rank-independent seed while the model is built: the frozen T5 encoder and the arena are drawn from the global RNG and every
+    # replica must hold the same function; per-rank streams (sampling, synthetic environments) start afterwards
+    torch.manual_seed(args.seed or 0)
+    env0, B = parallel.shard_envs(args.num_train_processes, world, rank)
     model = SafeDinoLLAMATxNavActorCriticSeparate(device=dev, max_steps=args.max_steps)
+    torch.manual_seed((args.seed or 0) + 1 + rank)
     if args.il_ckpt_path:
         init_towers_from_il(model, args.il_ckpt_path)
     cfg = PPOLagConfig(lr=args.lr, cost_limit=args.cost_limit if args.cost_limit is not None else 1e9)
@@ -76,18 +84,29 @@ def main(argv=None):
         ck = torch.load(args.checkpoint, map_location="cpu")
         load_checkpoint(ck, model, eng)
         step = int(ck.get("total_steps", 0))
-    if world > 1:
-        torch.distributed.broadcast(model.arena.flat_p, src=0)
-        model.sync_weights()
+    parallel.broadcast_model_(model)      # belt and braces: every parameter and buffer (incl. the frozen text encoder) from rank 0
     os.makedirs(args.output_dir, exist_ok=True)
     budget = args.total_steps or int(1e9)
     next_save = step + args.save_interval
     T = args.num_steps
+    env = st = None
+    if args.collect == "acting":
+        env = SynthVectorEnv(B, L=args.goal_tokens, task=args.task, seed=1234 + rank, max_steps=args.max_steps, device=dev, env_offset=env0)
+        st = RolloutStorage(T, device=dev, store_tokens=True)
+        st.initialize(env.reset(), num_samplers=B)
     while step < budget:
         t0 = time.time()
-        st, nxt, ep = fill_synthetic_rollout(model, SynthSpec(T=T, B=B, task=args.task, seed=1234 + rank + step, max_steps=args.max_steps), device=dev)
+        if env is not None:
+            nxt = collect_rollout(model, env, st, T)
+            s_, n_ = env.pop_episode_costs()
+            ep = dict(episode_cost_sum=s_, n_episodes=n_)
+        else:
+            st, nxt, ep = fill_synthetic_rollout(model, SynthSpec(T=T, B=B, L=args.goal_tokens, task=args.task, seed=1234 + rank + step,
+                                                                  max_steps=args.max_steps, env_offset=env0), device=dev)
         cfg.stage_losses = stage_for(step)
         info = eng.update(st, nxt["next_value"], nxt["next_c_value"], ep["episode_cost_sum"], ep["n_episodes"])
+        if env is not None:
+            st.after_updates()
         step += info["env_steps"]
         if rank == 0:
             info.update(training_step=step, env_steps_per_s=info["env_steps"] / (time.time() - t0), stage=list(cfg.stage_losses))

@@ -1,0 +1,100 @@
+"""The ENGINE at BASELINE.json's full sizes (no -m gpu test ran the engine above 18 rows):
+C2 = ObjectNav, 32 envs x 128 steps; C3 = PickUp, 64 envs x 256 steps, cost constraint active, 2 env-chunks of 32.
+No oracle can run these sizes in seconds, so the checks are size-independent properties: exactness of the env-chunked gradient
+accumulation, finiteness, the direction of the lambda update, the per-step bound of Adam, and the loss decreasing on a fixed rollout."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def model():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from safevla_amd.model import SafeDinoLLAMATxNavActorCriticSeparate
+
+    torch.manual_seed(0)
+    return SafeDinoLLAMATxNavActorCriticSeparate(device=DEV)
+
+
+def test_c2_chunked_accumulation_equals_unchunked_gradient(model):
+    from safevla_amd.engine import PPOLagConfig, PPOLagEngine
+    from safevla_amd.synth_env import SynthSpec, fill_synthetic_rollout
+
+    model.eval()                    # dropout masks are indexed by chunk-local rows: exactness is an eval-mode property
+    T, B = 128, 32
+    st, nxt, ep = fill_synthetic_rollout(model, SynthSpec(T=T, B=B, L=12, task="ObjectNav", seed=11), device=DEV)
+    st.compute_returns(nxt["next_value"], nxt["next_c_value"])
+    grads, sums = {}, {}
+    for chunk in (None, 8):
+        eng = PPOLagEngine(model, PPOLagConfig(env_chunk=chunk))
+        model.zero_grad()
+        eng._sums.zero_()
+        step = chunk or B
+        for c0 in range(0, B, step):
+            eng._accumulate(st.batch_slice(c0, c0 + step), T * B, 0.2, last=c0 + step >= B)
+        grads[chunk], sums[chunk] = model.arena.flat_g.clone(), eng._sums.clone()
+    a, b = grads[None].double(), grads[8].double()
+    assert torch.isfinite(a).all() and a.norm().item() > 0
+    assert ((a - b).norm() / a.norm()).item() < 5e-3          # bf16 re-rounding of per-chunk partial sums / atomics order only
+    assert torch.nn.functional.cosine_similarity(a, b, dim=0).item() > 0.99998
+    np.testing.assert_allclose(sums[None].cpu().numpy(), sums[8].cpu().numpy(), rtol=1e-4, atol=1e-6)
+    # every tower received a gradient
+    for lo, hi in model.arena.tower_ranges:
+        assert grads[None][lo:hi].abs().sum().item() > 0
+
+
+def test_c3_full_update_lambda_active(model):
+    """BASELINE configs[2]: PickUp, 64 envs x 256 steps, cost_limit 2.31964 (README.md:255), env-chunk 32, train mode (dropout on)."""
+    from safevla_amd.engine import PPOLagConfig, PPOLagEngine
+    from safevla_amd.synth_env import SynthSpec, fill_synthetic_rollout
+
+    model.train()
+    T, B = 256, 64
+    st, nxt, ep = fill_synthetic_rollout(model, SynthSpec(T=T, B=B, L=12, task="PickUp", seed=12), device=DEV)
+    cfg = PPOLagConfig(env_chunk=32, cost_limit=2.31964)
+    eng = PPOLagEngine(model, cfg)
+    p0 = model.arena.flat_p.clone()
+    jc = ep["episode_cost_sum"] / ep["n_episodes"]
+    assert jc > cfg.cost_limit                                  # Binomial(5, 0.05) per step x ~42-step episodes: the constraint is violated
+    info = eng.update(st, nxt["next_value"], nxt["next_c_value"], ep["episode_cost_sum"], ep["n_episodes"])
+    assert info["env_steps"] == T * B == 16384 and eng.opt_step == cfg.update_repeats and eng.tower_steps == [4, 4, 4]
+    assert all(np.isfinite(v) for v in info.values())
+    assert abs(info["Jc"] - jc) < 1e-9 and info["lagrangian_multiplier"] > cfg.lambda_init      # lambda moves toward the constraint
+    d = (model.arena.flat_p - p0).abs().max().item()
+    assert 0 < d <= cfg.update_repeats * cfg.lr * 1.01           # |Adam step| <= lr per optimiser step
+    assert torch.isfinite(model.arena.flat_p).all()
+    # bf16 mirrors in sync with the fp32 masters after the update
+    assert torch.equal(model.arena.flat_bf16, model.arena.flat_p.to(torch.bfloat16))
+    # more updates on the same rollout (eval mode: no dropout noise in the reported losses): lambda keeps rising (Jc fixed above the
+    # limit) and the critics' losses fall
+    model.eval()
+    infos = [eng.update(st, nxt["next_value"], nxt["next_c_value"], ep["episode_cost_sum"], ep["n_episodes"]) for _ in range(3)]
+    assert infos[2]["lagrangian_multiplier"] > infos[0]["lagrangian_multiplier"] > info["lagrangian_multiplier"]
+    assert infos[2]["value"] < infos[0]["value"] and infos[2]["c_value"] < infos[0]["c_value"]
+    model.arena.flat_p.copy_(p0)
+    model.sync_weights(frozen=False)
+
+
+def test_c5_shard_mixed_tasks_long_instructions(model):
+    """One GPU's shard of BASELINE configs[4]: mixed ObjectNav / PickUp / Fetch envs (env e -> task e mod 3), 64-token instructions
+    (S = 233 fusion tokens), reduced to 8 envs x 64 steps: one full update is finite and moves every tower."""
+    from safevla_amd.engine import PPOLagConfig, PPOLagEngine
+    from safevla_amd.synth_env import SynthSpec, fill_synthetic_rollout
+
+    model.train()
+    T, B = 64, 8
+    st, nxt, ep = fill_synthetic_rollout(model, SynthSpec(T=T, B=B, L=64, task="Mixed", seed=13, env_offset=32), device=DEV)
+    hand = st.observations["an_object_is_in_hand"][:, :, 0].float().mean(0)       # ObjectNav envs never hold an object
+    assert hand[[1, 4, 7]].sum().item() == 0                                      # (32 + b) % 3 == 0 -> ObjectNav
+    eng = PPOLagEngine(model, PPOLagConfig(update_repeats=1, env_chunk=4))
+    p0 = model.arena.flat_p.clone()
+    info = eng.update(st, nxt["next_value"], nxt["next_c_value"], ep["episode_cost_sum"], ep["n_episodes"])
+    assert all(np.isfinite(v) for v in info.values())
+    for lo, hi in model.arena.tower_ranges:
+        assert not torch.equal(model.arena.flat_p[lo:hi], p0[lo:hi])
+    model.arena.flat_p.copy_(p0)
+    model.sync_weights(frozen=False)

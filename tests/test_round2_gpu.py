@@ -1,0 +1,360 @@
+"""Round-2 additions on the GPU: HL-Gauss discrete critic (kernel vs the reference-generated golden G1, head + loss through the
+model API and the engine), clipped value loss, fp32 strided GEMM, the model's ``extras``, per-tower Adam bookkeeping, normalised
+advantages, the steppable synthetic vector env / acting-path rollout collection, Lightning checkpoints through ``build_agent``."""
+import math
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from safevla_amd import ops as o
+
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------------ HL-Gauss kernel
+def test_hlgauss_kernel_vs_reference_golden(ops):
+    """G1 was produced by the reference's own HLGaussLoss (tests/golden/make_golden.py): probs, loss and read-out value."""
+    g = dict(np.load(os.path.join(G, "g1_hlgauss.npz")))
+    logits, target = torch.from_numpy(g["logits"]).to(DEV), torch.from_numpy(g["target"]).to(DEV)
+    R, NB = logits.shape
+    values, dl, sums = ops.hlgauss_fwd_bwd(logits, target, None, -5.0, 15.0, 0.15, 1.0, 1.0 / R)
+    np.testing.assert_allclose(sums.item() / R, float(g["loss"]), rtol=2e-5)
+    # reference value read-out: transform_from_probs applied to its own target probabilities -- here: value of softmax(logits)
+    want_v = (torch.softmax(torch.from_numpy(g["logits"]).double(), -1) * ((torch.linspace(-5, 15, NB + 1)[:-1] + torch.linspace(-5, 15, NB + 1)[1:]) / 2).double()).sum(-1)
+    np.testing.assert_allclose(values.cpu().numpy(), want_v.numpy(), rtol=1e-5, atol=1e-5)
+    # gradient of the mean cross-entropy against the reference's probabilities: (softmax - q) / R
+    want_dl = (torch.softmax(torch.from_numpy(g["logits"]), -1) - torch.from_numpy(g["probs"])) / R
+    np.testing.assert_allclose(dl.cpu().numpy(), want_dl.numpy(), rtol=1e-4, atol=2e-7)
+    # the golden's "value" = transform_from_probs(probs): feed log(probs) as logits -> softmax == probs
+    lp = torch.log(torch.from_numpy(g["probs"]).clamp_min(1e-30)).to(DEV)
+    v2, _, _ = ops.hlgauss_fwd_bwd(lp, None, None, -5.0, 15.0, 0.15, want_grad=False)
+    np.testing.assert_allclose(v2.cpu().numpy(), g["value"], rtol=1e-5, atol=1e-5)
+
+
+def test_hlgauss_value_path_gradient_and_loss_object(ops):
+    from oracle import ref_loss
+    from safevla_amd.losses import HLGaussLoss
+
+    R, NB = 37, 101
+    logits, target, dval = rnd(R, NB, seed=1), rnd(R, seed=2, scale=3.0) + 4.0, rnd(R, seed=3)
+    sup = ref_loss.hl_support()
+    x = logits.clone().requires_grad_(True)
+    loss = 0.5 * 0.7 * ref_loss.hl_gauss_loss(x, target, sup) + (ref_loss.hl_gauss_value(torch.softmax(x, -1), sup) * dval).sum()
+    loss.backward()
+    _, dl, sums = ops.hlgauss_fwd_bwd(logits.to(DEV), target.to(DEV), dval.to(DEV), -5.0, 15.0, 0.15, 0.5 * 0.7, 1.0 / R)
+    np.testing.assert_allclose(dl.cpu().numpy(), x.grad.numpy(), rtol=2e-4, atol=1e-6)
+    # the loss object (reference API: loss_fn(logits, target), transform_from_probs) on device tensors == host closed form
+    hl = HLGaussLoss(-5.0, 15.0, 101, 0.15)
+    xg = logits.to(DEV).requires_grad_(True)
+    l = hl(xg, target.to(DEV))
+    l.backward()
+    want = ref_loss.hl_gauss_loss(logits, target, sup)
+    np.testing.assert_allclose(l.item(), want.item(), rtol=2e-5)
+    x2 = logits.clone().requires_grad_(True)
+    ref_loss.hl_gauss_loss(x2, target, sup).backward()
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), x2.grad.numpy(), rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(hl.value_from_logits(logits.to(DEV)).cpu().numpy(),
+                               ref_loss.hl_gauss_value(torch.softmax(logits, -1), sup).numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_value_mse_clipped_matches_reference_expression(ops):
+    """customized_loss.py:374-380 (the same expression upstream PPOValue uses)."""
+    R, clip = 1000, 0.1
+    v, r, ov = rnd(R, seed=1), rnd(R, seed=2), rnd(R, seed=3)
+    ov = v + 0.3 * ov                       # a mix of clipped and unclipped rows
+    vv = v.clone().requires_grad_(True)
+    vc = ov + (vv - ov).clamp(-clip, clip)
+    l = 0.5 * torch.max((vv - r).pow(2), (vc - r).pow(2)).mean()
+    l.backward()
+    sums, dv = ops.value_mse_fwd_bwd(v.to(DEV), r.to(DEV), 1.0, 1.0 / R, old_values=ov.to(DEV), clip=clip)
+    np.testing.assert_allclose(0.5 * sums.item() / R, l.item(), rtol=1e-5)
+    np.testing.assert_allclose(dv.cpu().numpy(), vv.grad.numpy(), rtol=1e-5, atol=1e-9)
+    from safevla_amd.api import SafeActorCriticOutput
+    from safevla_amd.losses import PPOValue
+
+    vg = v.to(DEV).view(R, 1, 1).requires_grad_(True)
+    aco = SafeActorCriticOutput(distributions=None, values=vg, c_values=None)
+    tot, info = PPOValue(clip_param=clip, use_clipped_value_loss=True).loss(0, {"values": ov.to(DEV).view(R, 1, 1), "returns": r.to(DEV).view(R, 1, 1)}, aco)
+    tot.backward()
+    np.testing.assert_allclose(info["value"], l.item(), rtol=1e-5)
+    np.testing.assert_allclose(vg.grad.reshape(R).cpu().numpy(), vv.grad.numpy(), rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("M,N,K", [(70, 101, 256), (513, 256, 512), (5, 1, 33)])
+def test_gemm_f32_all_layouts(ops, M, N, K):
+    A, B, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
+    want = F.relu(A @ B.t() + bias) + res
+    got = ops.gemm_f32(A.to(DEV), B.to(DEV), M, N, K, bias=bias.to(DEV), act=ops.ACT_RELU, residual=res.to(DEV))
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+    # NN: dX = dY . W  (B given as [K, N] row-major)
+    Bt = B.t().contiguous()
+    got = ops.gemm_f32(A.to(DEV), Bt.to(DEV), M, N, K, sb=(1, N))
+    np.testing.assert_allclose(got.cpu().numpy(), (A @ B.t()).numpy(), rtol=2e-5, atol=2e-5)
+    # TN with accumulate: dW[N, K] += dY[M, N]^T X[M, K]
+    dY, X = rnd(M, N, seed=5), rnd(M, K, seed=6)
+    acc = rnd(N, K, seed=7)
+    out = acc.clone().to(DEV)
+    ops.gemm_f32(dY.to(DEV), X.to(DEV), N, K, M, sa=(1, N), sb=(1, K), out=out, accumulate=True)
+    np.testing.assert_allclose(out.cpu().numpy(), (acc + dY.t() @ X).numpy(), rtol=3e-5, atol=3e-5)
+    # ReLU mask + colsum
+    mask = rnd(M, N, seed=8)
+    got = ops.gemm_f32(A.to(DEV), B.to(DEV), M, N, K, mask=mask.to(DEV))
+    np.testing.assert_allclose(got.cpu().numpy(), ((A @ B.t()) * (mask > 0)).numpy(), rtol=2e-5, atol=2e-5)
+    cs = torch.zeros(N, device=DEV)
+    ops.colsum_f32(dY.to(DEV), cs, M, N)
+    np.testing.assert_allclose(cs.cpu().numpy(), dY.sum(0).numpy(), rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ model: discrete critic, extras
+def _obs(T, B, seed=0, L=6):
+    rs = np.random.RandomState(seed)
+    ids = rs.randint(3, 32000, size=(B, L)); ids[:, -1] = 1
+    return {
+        "rgb_dinov2": torch.from_numpy(rs.standard_normal((T, B, 384, 7, 12)).astype(np.float32)).to(DEV),
+        "manipulation_rgb_dinov2": torch.from_numpy(rs.standard_normal((T, B, 384, 7, 12)).astype(np.float32)).to(DEV),
+        "goal_token_ids": torch.from_numpy(np.broadcast_to(ids, (T, B, L)).copy()).to(DEV),
+        "time_step": torch.arange(T)[:, None].expand(T, B).contiguous().to(DEV),
+        "traj_index": torch.zeros(T, B, dtype=torch.int64, device=DEV),
+        "an_object_is_in_hand": torch.zeros(T, B, 1, dtype=torch.int64, device=DEV),
+    }, torch.from_numpy(rs.randint(0, 20, size=(T, B))).to(DEV), torch.ones(T, B, 1, device=DEV)
+
+
+@pytest.mark.parametrize("critic_type", ["discrete", "mlp"])
+def test_critic_heads_forward_backward_vs_torch(ops, critic_type):
+    """DiscreteCriticHead / MLPCriticHead (allenact_dino_transformer.py:720-766): the head's forward and every parameter / input
+    gradient against a torch.autograd restatement on the same beliefs."""
+    from oracle import ref_loss
+    from safevla_amd.model import SafeDinoLLAMATxNavActorCriticSeparate
+
+    torch.manual_seed(0)
+    m = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV, critic_type=critic_type).eval()
+    tw = m.critic_tsfm
+    names = [k for k in m.state_dict() if k.startswith("critic_tsfm.critic.fc.")]
+    assert names == ([f"critic_tsfm.critic.fc.{i}.{p}" for i in (0, 2) for p in ("weight", "bias")] if critic_type == "discrete"
+                     else [f"critic_tsfm.critic.fc.{i}.{p}" for i in (0, 2, 4) for p in ("weight", "bias")])
+    T, B = 5, 3
+    obs, pa, mk = _obs(T, B)
+    m.zero_grad()
+    prep = m.prepare(obs, pa, mk)
+    _, values, c = tw.run_forward(prep, need_grad=True)
+    beliefs = c["beliefs"].clone()                                   # [R, 512] fp32, rows b*T + t
+    R = T * B
+    dval = rnd(T, B, 1, seed=5).to(DEV)
+    dfull = rnd(T, B, 101, seed=6, scale=0.1).to(DEV) if critic_type == "discrete" else None
+    full = tw._last_full_logits
+    tw.run_backward(prep, c, None, dval, dfull)
+    # torch restatement
+    fc = tw.critic.fc
+    ws = [(fc[i].weight.detach().clone().requires_grad_(True), fc[i].bias.detach().clone().requires_grad_(True)) for i in range(0, len(fc), 2)]
+    x = beliefs.clone().requires_grad_(True)
+    h = x
+    for j, (w, b) in enumerate(ws):
+        h = F.linear(h, w, b)
+        if j < len(ws) - 1:
+            h = F.relu(h)
+    out_tb = h.view(B, T, -1).transpose(0, 1)
+    if critic_type == "discrete":
+        sup = ref_loss.hl_support().to(DEV)
+        v_ref = ref_loss.hl_gauss_value(torch.softmax(out_tb, -1), sup).unsqueeze(-1)
+        np.testing.assert_allclose(full.cpu().numpy(), out_tb.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+        ((v_ref * dval).sum() + (out_tb * dfull).sum()).backward()
+    else:
+        v_ref = out_tb
+        (v_ref * dval).sum().backward()
+    np.testing.assert_allclose(values.cpu().numpy(), v_ref.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    for i, (w, b) in zip(range(0, len(fc), 2), ws):
+        np.testing.assert_allclose(tw.g(fc[i].weight).cpu().numpy(), w.grad.cpu().numpy(), rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(tw.g(fc[i].bias).cpu().numpy(), b.grad.cpu().numpy(), rtol=2e-4, atol=2e-6)
+    # the gradient reached the decoder: dW of the decoder output projection is non-zero and finite
+    gw = tw.g(tw.decoder.output.weight)
+    assert torch.isfinite(gw).all() and gw.abs().sum().item() > 0
+
+
+def test_discrete_critics_through_the_reference_api_and_engine(ops):
+    """SafePPOLogGrad(discrete_critics=True): value term = 0.5 * loss_func(extras["full_logits"], returns)
+    (customized_loss.py:364-370); the extras are the cost-critic tower's (separate_actor_critic.py:31-36).  API path
+    (``total.backward()``) and engine path must produce the same gradients, and both match the oracle formulas on the model's outputs."""
+    from oracle import ref_loss
+    from safevla_amd.engine import PPOLagConfig, PPOLagEngine
+    from safevla_amd.losses import SafePPOLogGrad
+    from safevla_amd.model import SafeDinoLLAMATxNavActorCriticSeparate
+
+    torch.manual_seed(0)
+    m = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV, critic_type="discrete").eval()
+    T, B = 4, 3
+    obs, pa, mk = _obs(T, B, seed=2)
+    rs = np.random.RandomState(3)
+    batch = {"actions": torch.from_numpy(rs.randint(0, 20, size=(T, B))).to(DEV), "old_action_log_probs": torch.full((T, B), -3.0, device=DEV),
+             "adv_targ": rnd(T, B, 1, seed=1).to(DEV), "c_adv_targ": rnd(T, B, 1, seed=2).to(DEV), "returns": (rnd(T, B, 1, seed=3) * 2 + 3).to(DEV),
+             "values": rnd(T, B, 1, seed=4).to(DEV), "c_returns": rnd(T, B, 1, seed=5).to(DEV)}
+    m.zero_grad()
+    aco, _ = m(obs, None, pa, mk)
+    assert {"full_logits", "loss_func", "stop_grad_logits", "total_norm", "weight_norm", "bias_norm", "weight_grad_norm"} <= set(aco.extras)
+    assert aco.extras["full_logits"].shape == (T, B, 101)
+    loss = SafePPOLogGrad(0.1, 0.5, 0.0, use_clipped_value_loss=False, discrete_critics=True, normalize_advantage=False)
+    total, info = loss.loss(0, batch, aco, lagrangian_multiplier=torch.tensor(0.37))
+    # oracle formulas on the model's own outputs
+    cb = {k: v.cpu() for k, v in batch.items()}
+    _, ri = ref_loss.safe_ppo_log_grad(aco.distributions.raw_logits.detach().cpu(), aco.values.detach().cpu(), cb, 0.37)
+    want_v = 0.5 * ref_loss.hl_gauss_loss(aco.extras["full_logits"].detach().cpu().view(-1, 101), cb["returns"].view(-1), ref_loss.hl_support())
+    np.testing.assert_allclose(info["value"], want_v.item(), rtol=1e-4)
+    np.testing.assert_allclose(info["action"], ri["action"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(info["ppo_total"], 0.5 * want_v.item() + ri["action"], rtol=1e-4, atol=1e-6)
+    total.backward()
+    g_api = m.arena.flat_g.clone()
+    a1, b1 = m.arena.tower_ranges[1]
+    assert g_api[a1:b1].abs().sum().item() == 0        # the reward-critic tower gets no gradient from this loss (reference data flow)
+    eng = PPOLagEngine(m, PPOLagConfig(stage_losses=("ppo_log_loss",)))
+    assert eng.active_towers() == (True, False, True)
+    m.zero_grad()
+    eng._sums.zero_()
+    eng._accumulate({**batch, "observations": obs, "prev_actions": pa, "masks": mk}, T * B, 0.37)
+    g_eng = m.arena.flat_g
+    err = (g_eng - g_api).norm() / g_api.norm()
+    assert err.item() < 2e-3, err.item()               # same kernels, atomics order only
+    np.testing.assert_allclose(0.5 * eng._sums[3].item() / (T * B), want_v.item(), rtol=1e-4)
+
+
+def test_extras_keys_of_the_default_model(ops):
+    from safevla_amd.model import SafeDinoLLAMATxNavActorCriticSeparate
+
+    m = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV).eval()
+    obs, pa, mk = _obs(3, 2)
+    aco, _ = m(obs, None, pa, mk)
+    ex = aco.extras
+    assert {"total_norm", "stop_grad_values", "weight_norm", "bias_norm", "weight_grad_norm"} <= set(ex)
+    assert torch.equal(ex["stop_grad_values"], aco.c_values.detach()) and not ex["stop_grad_values"].requires_grad
+    fc = m.c_critic_tsfm.critic.fc
+    np.testing.assert_allclose(ex["weight_norm"].item(), fc.weight.norm(2).item(), rtol=1e-6)
+    assert ex["total_norm"].item() == 0.0 and ex["weight_grad_norm"].item() == 0.0       # no backward yet
+    aco.c_values.sum().backward()
+    aco2, _ = m(obs, None, pa, mk)
+    a, b = m.arena.tower_ranges[2]
+    np.testing.assert_allclose(aco2.extras["total_norm"].item(), m.arena.flat_g[a:b].double().norm().item(), rtol=1e-5)
+    assert aco2.extras["weight_grad_norm"].item() > 0
+    # arena layout: every tower starts on a 256-element boundary (16-byte aligned bf16 weight views)
+    assert all(s % 256 == 0 for s, _ in m.arena.tower_ranges) and m.arena.tower_ranges[0][0] == 0
+    for t in m.towers:
+        for w in t._w.values():
+            assert w.data_ptr() % 16 == 0
+
+
+# ------------------------------------------------------------------------------------------------ engine bookkeeping
+def test_adam_skips_towers_without_a_loss_like_torch_optim(ops):
+    """torch.optim.Adam after zero_grad(set_to_none=True): parameters of a tower with no loss in the stage keep grad None -> skipped,
+    moments frozen, per-parameter step not advanced.  Stage 0 trains the two critics, stage 1+ the policy and the critic."""
+    from safevla_amd.engine import PPOLagConfig, PPOLagEngine
+    from safevla_amd.model import SafeDinoLLAMATxNavActorCriticSeparate
+    from safevla_amd.synth_env import SynthSpec, fill_synthetic_rollout
+
+    torch.manual_seed(0)
+    m = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV).eval()
+    st, nxt, ep = fill_synthetic_rollout(m, SynthSpec(T=6, B=2, L=5, task="PickUp", seed=3), device=DEV)
+    cfg = PPOLagConfig(update_repeats=1, stage_losses=("ppo_value_loss", "safe_ppo_value_loss"))
+    eng = PPOLagEngine(m, cfg)
+    ar = m.arena
+    p0 = ar.flat_p.clone()
+    eng.update(st, nxt["next_value"], nxt["next_c_value"], 3.0, 1.0)
+    (a0, b0), (a1, b1), (a2, b2) = ar.tower_ranges
+    assert eng.tower_steps == [0, 1, 1] and eng.active_towers() == (False, True, True)
+    assert torch.equal(ar.flat_p[a0:b0], p0[a0:b0]) and ar.flat_m[a0:b0].abs().sum().item() == 0
+    assert not torch.equal(ar.flat_p[a1:b1], p0[a1:b1]) and not torch.equal(ar.flat_p[a2:b2], p0[a2:b2])
+    cfg.stage_losses = ("ppo_log_loss",)                     # the shipped stage 1+: cost critic has no loss any more
+    m2, v2, p2 = ar.flat_m[a2:b2].clone(), ar.flat_v[a2:b2].clone(), ar.flat_p[a2:b2].clone()
+    eng.update(st, nxt["next_value"], nxt["next_c_value"], 3.0, 1.0)
+    assert eng.tower_steps == [1, 2, 1]
+    assert torch.equal(ar.flat_p[a2:b2], p2) and torch.equal(ar.flat_m[a2:b2], m2) and torch.equal(ar.flat_v[a2:b2], v2)
+    # first Adam step of the policy tower uses ITS step count (1): |delta| == lr wherever the gradient is non-zero
+    d = (ar.flat_p[a0:b0] - p0[a0:b0]).abs()
+    assert d.max().item() <= 2e-5 * 1.001 and d.max().item() > 2e-5 * 0.99
+
+
+def test_normalized_advantages(ops):
+    from safevla_amd.model import SafeDinoLLAMATxNavActorCriticSeparate
+    from safevla_amd.synth_env import SynthSpec, fill_synthetic_rollout
+
+    m = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV).eval()
+    st, nxt, _ = fill_synthetic_rollout(m, SynthSpec(T=9, B=3, L=5, seed=1), device=DEV)
+    st.compute_returns(nxt["next_value"], nxt["next_c_value"])
+    b = st.batch_slice(0, 3)
+    assert "norm_adv_targ" not in b                       # raw advantages are never passed off as normalised ones
+    bn = st.batch_slice(1, 3, normalized=True)
+    adv = st.adv_targ
+    want = (adv - adv.mean()) / (adv.std() + 1e-5)
+    np.testing.assert_allclose(bn["norm_adv_targ"].cpu().numpy(), want[:, 1:3].cpu().numpy(), rtol=1e-4, atol=1e-6)
+    cadv = st.c_adv_targ
+    np.testing.assert_allclose(bn["c_norm_adv_targ"].cpu().numpy(), ((cadv - cadv.mean()) / (cadv.std() + 1e-5))[:, 1:3].cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ rollout collection through the acting path
+def test_vector_env_and_acting_rollout_collection(ops):
+    """SynthVectorEnv.step -> SafeRLStepResult contract; collect_rollout fills the storage through the KV-cached single-step policy and
+    the stored log-probs / values equal a full-sequence (update-path) forward over the collected rollout (eval mode, equal-length goals)."""
+    from safevla_amd.api import SafeRLStepResult
+    from safevla_amd.model import SafeDinoLLAMATxNavActorCriticSeparate
+    from safevla_amd.storage import RolloutStorage
+    from safevla_amd.synth_env import SynthVectorEnv, collect_rollout, env_tasks
+
+    assert env_tasks("Mixed", 5, env_offset=2) == ["Fetch", "ObjectNav", "PickUp", "Fetch", "ObjectNav"]
+    torch.manual_seed(0)
+    m = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV).eval()
+    B, T = 3, 7
+    env = SynthVectorEnv(B, L=6, task="Mixed", seed=5, device=DEV)
+    obs, r, c, d, res = env.step(torch.tensor([0, 4, 1], device=DEV), want_results=True)
+    assert isinstance(res[0], SafeRLStepResult) and res[1].done is True and res[1].info["task_type"] == "PickUp"
+    assert 0 <= res[0].cost <= 5 and res[0].reward in (0.0, 10.0) and set(res[0].observation) == set(obs)
+    assert int(obs["time_step"][1]) == 0                       # env 1 ended: fresh episode
+    s_, n_ = env.pop_episode_costs()
+    assert n_ >= 1
+    st = RolloutStorage(T, device=DEV)
+    nxt = collect_rollout(m, env, st, T, obs0=env.reset())
+    assert st.step == T and nxt["next_value"].shape == (B, 1)
+    st.compute_returns(nxt["next_value"], nxt["next_c_value"])
+    batch = st.batch_slice(0, B)
+    with torch.no_grad():
+        out, _ = m(batch["observations"], None, batch["prev_actions"], batch["masks"])
+    lp = out.distributions.log_prob(batch["actions"])
+    # acting path (KV cache, episode window) == update path (block-causal over traj ids): bf16 kernels on different schedules
+    assert (lp - st.action_log_probs).abs().max().item() < 3e-2
+    assert (out.values[:T] - st.value_preds[:T]).abs().max().item() < 3e-2 * max(1.0, st.value_preds.abs().max().item())
+    st.after_updates()
+    assert st.step == 0
+
+
+def test_build_agent_loads_a_lightning_checkpoint(ops, tmp_path):
+    """the Lightning (IL) branch of build_agent used to index ["state_dict"] twice."""
+    from safevla_amd.agent import InferenceAgentVIDA
+    from safevla_amd.model import SafeDinoLLAMATxNavActorCriticSeparate
+
+    m = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV)
+    il = {"state_dict": {"model.actor.weight": torch.full((20, 512), 0.125), "model.actor.bias": torch.full((20,), -2.0),
+                         "model.decoder.norm.weight": torch.full((512,), 1.5),
+                         "model.visual_encoder.image_encoder.model.norm.weight": torch.full((384,), 2.0)}}
+    path = str(tmp_path / "il.ckpt")
+    torch.save(il, path)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        agent = InferenceAgentVIDA.build_agent(m, device=DEV, ckpt_path=path)
+    assert (m.actor.linear.weight == 0.125).all() and (m.actor.linear.bias == -2).all() and (m.decoder.norm.weight == 1.5).all()
+    assert (agent.nav_pre.vit.norm.weight == 2.0).all()                               # image-encoder keys fill the frozen ViT
+    msgs = " ".join(str(x.message) for x in w)
+    assert "word-hash goal tokenizer" in msgs and "random-init DINOv2" not in msgs    # ViT came from the checkpoint, tokenizer is a stand-in
+    assert not m.training
