@@ -71,7 +71,7 @@ int svla_small_linear_bwd_f32(const float* x, const float* W, const float* dout,
                               int accumulate_dx, float* dx, float* dW, float* db, void* stream);
 
 /* ---- normalisation ---------------------------------------------------------------------------------------- */
-/* LayerNorm (rms=0) / RMSNorm (rms=1) rows of width D (512; forward also 384).  Row maps (G,GS,OFF): logical row m is
+/* LayerNorm (rms=0) / RMSNorm (rms=1) rows of width D.  Forward widths 384 / 512 / 768 / 1024 (frozen ViT-S / policy / ViT-B + SigLIP-B / ViT-L), backward 512.  Row maps (G,GS,OFF): logical row m is
  * memory row (m/G)*GS + OFF + m%G (G = 0: identity).  Optional fused ReLU and per-group token add: the
  * "Linear -> LayerNorm -> ReLU (+ camera token)" adapters (allenact_dino_transformer.py:509-513,539-543,672-688);
  * nn.TransformerEncoderLayer norm1/norm2 (:545-552); llama RMSNorm (training/online/third_party_models/llama/model.py:28-71). */
@@ -191,6 +191,41 @@ int svla_adam_step_f32(float* p, const float* g, float* m, float* v, svla_bf16* 
                        float weight_decay, void* stream);
 int svla_cast_f32_bf16(const float* src, svla_bf16* dst, long n, void* stream);
 int svla_transpose_cast_f32_bf16(const float* src, int rows, int cols, svla_bf16* dst, void* stream);
+
+/* ---- fp32 verification mode --------------------------------------------------------------------------------------------------
+ * north_star asks for "matching losses/entropy within fp32 tolerance"; the reference computes everything in fp32 (no autocast anywhere,
+ * SURVEY 8).  The entry points below are fp32-activation twins of the bf16 ones above (same argument meaning, same cited reference
+ * layers: norms allenact_dino_transformer.py:509-552 + llama/model.py:28-71; attention allenact_dino_transformer.py:545-552,398-402 +
+ * llama/model.py:249-322; glue allenact_dino_transformer.py:353-385,663-692 + llama/model.py:359-360); with svla_gemm_f32 they run the
+ * SAME host schedule (model.precision = "fp32") so that logits / values / losses / lambda after an update can be checked against the
+ * reference-generated goldens at 1e-4 instead of the bf16 ladder.  Simple kernels, not tuned: a verification path, not the product path. */
+int svla_norm_fwd_f32(const float* x, int xG, int xGS, int xOFF, const float* gamma, const float* beta, float eps, int rows, int D,
+                      int rms, int relu, const float* tok, int tok_group, float* y, int yG, int yGS, int yOFF, float* mean, float* rstd,
+                      void* stream);
+int svla_norm_bwd_f32(const float* dy, int dyG, int dyGS, int dyOFF, const float* x, int xG, int xGS, int xOFF, const float* gamma,
+                      const float* beta, const float* mean, const float* rstd, int rows, int D, int rms, int relu, int tok_group,
+                      const float* dres, float* dx, int dxG, int dxGS, int dxOFF, float* dgamma, float* dbeta, float* dtok, float* dx_drop,
+                      const svla_dropout* drop, void* stream);
+int svla_attn_fwd_f32(const float* Q, const float* K, const float* V, long ld, float* O, long ldo, float* LSE, int rows, int S, int H,
+                      int head_dim, float scale, int mask_mode, const int* traj, const float* bias, const unsigned char* kvalid, int Sq,
+                      long ldq, int kv_rows, const svla_dropout* drop, void* stream);
+int svla_attn_bwd_f32(const float* Q, const float* K, const float* V, long ld, const float* O, long ldo, const float* LSE, const float* dO,
+                      long lddo, float* dQ, float* dK, float* dV, long ldd, int rows, int S, int H, int head_dim, float scale, int mask_mode,
+                      const int* traj, const unsigned char* kvalid, int Sq, long ldq, long lddq, const svla_dropout* drop, void* stream);
+int svla_feat_to_tokens_f32(const float* feat, int R, int C, int P, int cam, int ncam, float* out, void* stream);
+int svla_fusion_fill_f32(const float* fusion_token, const float* text, const int* gid, int R, int S, int L, int text_off, float* x0,
+                         void* stream);
+int svla_fusion_text_bwd_f32(const float* dx0, const int* gid, int T, int B, int S, int L, int text_off, float* dtext, void* stream);
+int svla_decoder_embed_fwd_f32(const float* xf, long xf_row_stride, const float* act_tab, const float* hand_tab, const float* div_term,
+                               const int64_t* prev_actions, const float* masks, const int64_t* hand, const int64_t* time_step, int T, int B,
+                               int n_actions, float* out, void* stream);
+int svla_decoder_embed_bwd_f32(const float* dout, const int64_t* prev_actions, const float* masks, const int64_t* hand, int T, int B,
+                               int n_actions, float* dxf, long dxf_row_stride, float* d_act_tab, float* d_hand_tab, void* stream);
+int svla_rows_add_f32(float* dst, long dst_ld, const float* src, long src_ld, int rows, int D, void* stream);
+int svla_swiglu_fwd_f32(const float* ab, long M, int Hd, float* g, void* stream);
+int svla_swiglu_bwd_f32(const float* ab, const float* dg, long M, int Hd, float* dab, void* stream);
+int svla_embed_gather_f32(const float* table, const int64_t* ids, long n, int D, float* out, void* stream);
+int svla_dropout_f32(float* x, long rows, int N, const svla_dropout* drop, void* stream);
 
 #ifdef __cplusplus
 }

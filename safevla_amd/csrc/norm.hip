@@ -41,12 +41,28 @@ __device__ __forceinline__ void store_row_bf16(bf16_t* p, const float (&v)[VPL])
     }
 }
 
+// fp32 activations (the fp32 verification mode): the same kernels instantiated on float rows
+template <int VPL>
+__device__ __forceinline__ void load_row(const bf16_t* p, float (&v)[VPL]) { load_row_bf16<VPL>(p, v); }
+template <int VPL>
+__device__ __forceinline__ void store_row(bf16_t* p, const float (&v)[VPL]) { store_row_bf16<VPL>(p, v); }
+template <int VPL>
+__device__ __forceinline__ void load_row(const float* p, float (&v)[VPL]) {
+#pragma unroll
+    for (int i = 0; i < VPL / 2; ++i) { const float2 w = *(const float2*)(p + 2 * i); v[2 * i] = w.x; v[2 * i + 1] = w.y; }
+}
+template <int VPL>
+__device__ __forceinline__ void store_row(float* p, const float (&v)[VPL]) {
+#pragma unroll
+    for (int i = 0; i < VPL / 2; ++i) *(float2*)(p + 2 * i) = float2{v[2 * i], v[2 * i + 1]};
+}
+
 // ---------------------------------------------------------------------------------------------- LayerNorm fwd
 // y = [relu](LN(x) * gamma + beta) [+ tok[(m % G) / tok_group]]        (rms != 0: RMS norm, beta ignored)
-template <int D>
-__global__ void norm_fwd_kernel(const bf16_t* __restrict__ x, RowMap xmap, const float* __restrict__ gamma,
+template <typename T, int D>
+__global__ void norm_fwd_kernel(const T* __restrict__ x, RowMap xmap, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float eps, int rows, int rms, int relu,
-                                const float* __restrict__ tok, int tok_group, bf16_t* __restrict__ y, RowMap ymap,
+                                const float* __restrict__ tok, int tok_group, T* __restrict__ y, RowMap ymap,
                                 float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     constexpr int VPL = D / 64;
     const int lane = threadIdx.x & 63;
@@ -56,7 +72,7 @@ __global__ void norm_fwd_kernel(const bf16_t* __restrict__ x, RowMap xmap, const
     for (int i = 0; i < VPL; ++i) { g[i] = gamma[lane * VPL + i]; b[i] = (beta && !rms) ? beta[lane * VPL + i] : 0.f; }
     for (int m = wave; m < rows; m += nw) {
         float v[VPL];
-        load_row_bf16<VPL>(x + map_row(xmap, m) * D + lane * VPL, v);
+        load_row<VPL>(x + map_row(xmap, m) * D + lane * VPL, v);
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) s += v[i];
@@ -74,20 +90,20 @@ __global__ void norm_fwd_kernel(const bf16_t* __restrict__ x, RowMap xmap, const
             if (tk) o += tk[i];
             v[i] = o;
         }
-        store_row_bf16<VPL>(y + map_row(ymap, m) * D + lane * VPL, v);
+        store_row<VPL>(y + map_row(ymap, m) * D + lane * VPL, v);
     }
 }
 
 // ---------------------------------------------------------------------------------------------- LayerNorm bwd
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma [* relu mask];   (rms: no mean(g) term)
 // dgamma += sum dy_masked * xhat; dbeta += sum dy_masked; dtok[k] += sum dy (rows of token group k)
-template <int D>
-__global__ void norm_bwd_kernel(const bf16_t* __restrict__ dy, RowMap dymap, const bf16_t* __restrict__ x, RowMap xmap,
+template <typename T, int D>
+__global__ void norm_bwd_kernel(const T* __restrict__ dy, RowMap dymap, const T* __restrict__ x, RowMap xmap,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                 const float* __restrict__ mean, const float* __restrict__ rstd_in, int rows, int rms,
-                                int relu, int tok_group, const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
+                                int relu, int tok_group, const T* __restrict__ dres, T* __restrict__ dx,
                                 RowMap dxmap, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                float* __restrict__ dtok, bf16_t* __restrict__ dx_drop, DropCfg drop) {
+                                float* __restrict__ dtok, T* __restrict__ dx_drop, DropCfg drop) {
     drop = drop_resolve(drop);
     constexpr int VPL = D / 64;
     __shared__ float red[4][4 * D];  // [wave][dgamma | dbeta | dtok0 | dtok1]
@@ -101,8 +117,8 @@ __global__ void norm_bwd_kernel(const bf16_t* __restrict__ dy, RowMap dymap, con
     }
     for (int m = wave; m < rows; m += nw) {
         float xv[VPL], dv[VPL];
-        load_row_bf16<VPL>(x + map_row(xmap, m) * D + lane * VPL, xv);
-        load_row_bf16<VPL>(dy + map_row(dymap, m) * D + lane * VPL, dv);
+        load_row<VPL>(x + map_row(xmap, m) * D + lane * VPL, xv);
+        load_row<VPL>(dy + map_row(dymap, m) * D + lane * VPL, dv);
         const float mu = rms ? 0.f : mean[m], rs = rstd_in[m];
         if (dtok) {
             const int k = (dymap.G > 0 ? (m % dymap.G) : m) / tok_group;
@@ -125,11 +141,11 @@ __global__ void norm_bwd_kernel(const bf16_t* __restrict__ dy, RowMap dymap, con
         for (int i = 0; i < VPL; ++i) xv[i] = rs * (gg[i] - s1 - xh[i] * s2);
         if (dres) {  // residual-branch gradient (pre-norm blocks: d h = d out + norm_bwd(...))
             float rv[VPL];
-            load_row_bf16<VPL>(dres + (size_t)m * D + lane * VPL, rv);
+            load_row<VPL>(dres + (size_t)m * D + lane * VPL, rv);
 #pragma unroll
             for (int i = 0; i < VPL; ++i) xv[i] += rv[i];
         }
-        store_row_bf16<VPL>(dx + map_row(dxmap, m) * D + lane * VPL, xv);
+        store_row<VPL>(dx + map_row(dxmap, m) * D + lane * VPL, xv);
         if (dx_drop) {
             // gradient through the dropout on the sub-layer output that was added to the residual stream before this norm
             // (x + dropout(sublayer(x))): the same keep-mask as the forward GEMM epilogue, regenerated from the element index
@@ -139,7 +155,7 @@ __global__ void norm_bwd_kernel(const bf16_t* __restrict__ dy, RowMap dymap, con
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xv[q4 * 4 + e] = ((keep >> e) & 1u) ? xv[q4 * 4 + e] * drop.scale : 0.f;
             }
-            store_row_bf16<VPL>(dx_drop + (size_t)m * D + lane * VPL, xv);
+            store_row<VPL>(dx_drop + (size_t)m * D + lane * VPL, xv);
         }
     }
 #pragma unroll
@@ -163,35 +179,62 @@ static inline int norm_grid(int rows) {
     return blocks > 2048 ? 2048 : (blocks < 1 ? 1 : blocks);
 }
 
-extern "C" int svla_norm_fwd_bf16(const bf16_t* x, int xG, int xGS, int xOFF, const float* gamma, const float* beta, float eps,
-                                  int rows, int D, int rms, int relu, const float* tok, int tok_group, bf16_t* y, int yG,
-                                  int yGS, int yOFF, float* mean, float* rstd, void* stream) {
+template <typename T>
+static int norm_fwd_launch(const T* x, int xG, int xGS, int xOFF, const float* gamma, const float* beta, float eps, int rows, int D, int rms,
+                           int relu, const float* tok, int tok_group, T* y, int yG, int yGS, int yOFF, float* mean, float* rstd, void* stream) {
     if (rows <= 0) return SVLA_EINVAL;
     if (tok && tok_group <= 0) return SVLA_EINVAL;
     RowMap xm{xG, xGS, xOFF}, ym{yG, yGS, yOFF};
     dim3 grid(norm_grid(rows)), block(256);
-    if (D == 512)
-        hipLaunchKernelGGL(norm_fwd_kernel<512>, grid, block, 0, (hipStream_t)stream, x, xm, gamma, beta, eps, rows, rms, relu,
-                           tok, tok_group, y, ym, mean, rstd);
-    else if (D == 384)
-        hipLaunchKernelGGL(norm_fwd_kernel<384>, grid, block, 0, (hipStream_t)stream, x, xm, gamma, beta, eps, rows, rms, relu,
-                           tok, tok_group, y, ym, mean, rstd);
-    else
-        return SVLA_EINVAL;
+#define NORM_FWD_CASE(DD) hipLaunchKernelGGL((norm_fwd_kernel<T, DD>), grid, block, 0, (hipStream_t)stream, x, xm, gamma, beta, eps, rows, rms, relu, tok, tok_group, y, ym, mean, rstd)
+    // widths on this path: 512 (policy, T5), 384 / 768 / 1024 (frozen ViT-S / ViT-B + SigLIP-B / ViT-L preprocessors)
+    if (D == 512) NORM_FWD_CASE(512);
+    else if (D == 384) NORM_FWD_CASE(384);
+    else if (D == 768) NORM_FWD_CASE(768);
+    else if (D == 1024) NORM_FWD_CASE(1024);
+    else return SVLA_EINVAL;
+#undef NORM_FWD_CASE
     return svla_launch_status();
 }
 
-extern "C" int svla_norm_bwd_bf16(const bf16_t* dy, int dyG, int dyGS, int dyOFF, const bf16_t* x, int xG, int xGS, int xOFF,
-                                  const float* gamma, const float* beta, const float* mean, const float* rstd, int rows,
-                                  int D, int rms, int relu, int tok_group, const bf16_t* dres, bf16_t* dx, int dxG, int dxGS,
-                                  int dxOFF, float* dgamma, float* dbeta, float* dtok, bf16_t* dx_drop, const svla_dropout* drop,
-                                  void* stream) {
+template <typename T>
+static int norm_bwd_launch(const T* dy, int dyG, int dyGS, int dyOFF, const T* x, int xG, int xGS, int xOFF, const float* gamma,
+                           const float* beta, const float* mean, const float* rstd, int rows, int D, int rms, int relu, int tok_group,
+                           const T* dres, T* dx, int dxG, int dxGS, int dxOFF, float* dgamma, float* dbeta, float* dtok, T* dx_drop,
+                           const svla_dropout* drop, void* stream) {
     if (rows <= 0 || D != 512) return SVLA_EINVAL;
     if (dtok && tok_group <= 0) return SVLA_EINVAL;
     RowMap dym{dyG, dyGS, dyOFF}, xm{xG, xGS, xOFF}, dxm{dxG, dxGS, dxOFF};
     int blocks = norm_grid(rows);
     if (blocks > 512) blocks = 512;  // fewer, fatter blocks: each ends with 4*D atomics
-    hipLaunchKernelGGL(norm_bwd_kernel<512>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, dym, x, xm, gamma, beta, mean,
+    hipLaunchKernelGGL((norm_bwd_kernel<T, 512>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, dym, x, xm, gamma, beta, mean,
                        rstd, rows, rms, relu, tok_group > 0 ? tok_group : 1, dres, dx, dxm, dgamma, dbeta, dtok, dx_drop, drop_cfg(drop));
     return svla_launch_status();
+}
+
+extern "C" int svla_norm_fwd_bf16(const bf16_t* x, int xG, int xGS, int xOFF, const float* gamma, const float* beta, float eps,
+                                  int rows, int D, int rms, int relu, const float* tok, int tok_group, bf16_t* y, int yG,
+                                  int yGS, int yOFF, float* mean, float* rstd, void* stream) {
+    return norm_fwd_launch<bf16_t>(x, xG, xGS, xOFF, gamma, beta, eps, rows, D, rms, relu, tok, tok_group, y, yG, yGS, yOFF, mean, rstd, stream);
+}
+extern "C" int svla_norm_fwd_f32(const float* x, int xG, int xGS, int xOFF, const float* gamma, const float* beta, float eps,
+                                 int rows, int D, int rms, int relu, const float* tok, int tok_group, float* y, int yG,
+                                 int yGS, int yOFF, float* mean, float* rstd, void* stream) {
+    return norm_fwd_launch<float>(x, xG, xGS, xOFF, gamma, beta, eps, rows, D, rms, relu, tok, tok_group, y, yG, yGS, yOFF, mean, rstd, stream);
+}
+extern "C" int svla_norm_bwd_bf16(const bf16_t* dy, int dyG, int dyGS, int dyOFF, const bf16_t* x, int xG, int xGS, int xOFF,
+                                  const float* gamma, const float* beta, const float* mean, const float* rstd, int rows,
+                                  int D, int rms, int relu, int tok_group, const bf16_t* dres, bf16_t* dx, int dxG, int dxGS,
+                                  int dxOFF, float* dgamma, float* dbeta, float* dtok, bf16_t* dx_drop, const svla_dropout* drop,
+                                  void* stream) {
+    return norm_bwd_launch<bf16_t>(dy, dyG, dyGS, dyOFF, x, xG, xGS, xOFF, gamma, beta, mean, rstd, rows, D, rms, relu, tok_group, dres, dx,
+                                   dxG, dxGS, dxOFF, dgamma, dbeta, dtok, dx_drop, drop, stream);
+}
+extern "C" int svla_norm_bwd_f32(const float* dy, int dyG, int dyGS, int dyOFF, const float* x, int xG, int xGS, int xOFF,
+                                 const float* gamma, const float* beta, const float* mean, const float* rstd, int rows,
+                                 int D, int rms, int relu, int tok_group, const float* dres, float* dx, int dxG, int dxGS,
+                                 int dxOFF, float* dgamma, float* dbeta, float* dtok, float* dx_drop, const svla_dropout* drop,
+                                 void* stream) {
+    return norm_bwd_launch<float>(dy, dyG, dyGS, dyOFF, x, xG, xGS, xOFF, gamma, beta, mean, rstd, rows, D, rms, relu, tok_group, dres, dx,
+                                  dxG, dxGS, dxOFF, dgamma, dbeta, dtok, dx_drop, drop, stream);
 }

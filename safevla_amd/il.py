@@ -134,7 +134,7 @@ class EarlyFusionCnnTransformer(Tower):
     # ---- reference forward API --------------------------------------------------------------------------------------------------
     def forward(self, batch: Dict) -> Dict[str, torch.Tensor]:
         prep = self.prepare(batch)
-        logits, _ = _TowerFn.apply(self._anchor, self, prep, True, False)      # [T, B, A] fp32
+        logits, _, _ = _TowerFn.apply(self._anchor, self, prep, True, False)      # [T, B, A] fp32
         out = dict(actions_logits=logits.transpose(0, 1))
         if "actions" in batch:
             tgt = batch["actions"].to(self.device_).transpose(0, 1).reshape(-1).to(torch.int64)

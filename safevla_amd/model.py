@@ -124,8 +124,14 @@ def _init_tensor(shape, init, g):
 class Tower(nn.Module):
     """``DinoLLAMATxNavActorCritic`` (full-sensor configuration of dinov2_vits_tsfm_base.py:234-270)."""
 
-    def __init__(self, arena: _Arena, device, n_fusion_layers=3, n_decoder_layers=3, max_steps=500, critic_type="linear"):
+    def __init__(self, arena: _Arena, device, n_fusion_layers=3, n_decoder_layers=3, max_steps=500, critic_type="linear",
+                 precision="bf16"):
         super().__init__()
+        if precision not in ("bf16", "fp32"):
+            raise ValueError(f"precision must be 'bf16' (MFMA product path) or 'fp32' (verification mode), got {precision!r}")
+        # activation / GEMM-operand dtype.  "fp32" = the verification mode: the same schedule on the fp32 twins of every kernel
+        # (include/svla.h, last section), for comparing with the reference's fp32 arithmetic at fp32 tolerance; not a fast path.
+        self.precision, self.adt = precision, (F32 if precision == "fp32" else BF16)
         if critic_type not in ("linear", "mlp", "discrete"):
             print(f"Unknown critic type: {critic_type}")
             raise NotImplementedError
@@ -231,9 +237,9 @@ class Tower(nn.Module):
         self._w, self._dw = {}, {}
         for key, ps, (n, k) in self._gemm_weights():
             off, _ = ar.offsets[id(ps[0])]
-            self._w[key] = ar.flat_bf16[off:off + n * k].view(n, k)
+            self._w[key] = (ar.flat_p if self.adt == F32 else ar.flat_bf16)[off:off + n * k].view(n, k)
             self._dw[key] = ar.flat_g[off:off + n * k].view(n, k)
-            self._wt[key] = torch.empty(k, n, device=self.device_, dtype=BF16)
+            self._wt[key] = torch.empty(k, n, device=self.device_, dtype=self.adt)
         ve = self.visual_encoder
         off, _ = ar.offsets[id(ve.visual_sensor_token_raw_navigation_camera)]
         self._camtok = ar.flat_p[off:off + 2 * D].view(2, D)
@@ -267,7 +273,7 @@ class Tower(nn.Module):
     # ---- acting path state (llama KV caches, llama/model.py:224-247; counter semantics allenact_dino_transformer.py:376-406)
     def _ensure_caches(self, B: int):
         if getattr(self, "_kv", None) is None or self._kv[0].shape[0] < B:
-            self._kv = [torch.zeros(B, self.max_steps, 2 * D, device=self.device_, dtype=BF16) for _ in self.decoder.layers]
+            self._kv = [torch.zeros(B, self.max_steps, 2 * D, device=self.device_, dtype=self.adt) for _ in self.decoder.layers]
 
     def cache_select(self, keep: list):
         if getattr(self, "_kv", None) is not None:
@@ -286,7 +292,7 @@ class Tower(nn.Module):
         c1 = ops.gemm_nt(tok, w["c1"], M2, D, DINO, bias=ve.visual_compressor[0].bias, act=ops.ACT_RELU)
         c2 = ops.gemm_nt(c1, w["c2"], M2, D, D, bias=ve.visual_compressor[2].bias, act=ops.ACT_RELU)
         a1 = ops.gemm_nt(c2, w["va"], M2, D, D, bias=ve.visual_adapter[0].bias)
-        x = torch.empty(R, S, D, device=self.device_, dtype=BF16)
+        x = torch.empty(R, S, D, device=self.device_, dtype=self.adt)
         _, va_mean, va_rstd = ops.norm_fwd(a1, ve.visual_adapter[1].weight, ve.visual_adapter[1].bias, 1e-5, M2, relu=True,
                                            tok=self._camtok, tok_group=NPATCH, y=x, ymap=(2 * NPATCH, S, 1))
         t5_seed = c["drop_seed"] if self.t5_dropout else None
@@ -294,7 +300,7 @@ class Tower(nn.Module):
         if t5_seed is None and key is not None and getattr(self, "_t5_cache", (None, None))[0] == key:
             t5 = self._t5_cache[1]     # eval mode: the frozen encoder is a pure function of the goal tokens (one episode = one goal)
         else:
-            t5 = ve.text_encoder.encode(prep.ids, prep.attn_mask, drop_seed=t5_seed, drop_p=self.dropout_p)   # [U*L, 512] bf16, frozen
+            t5 = ve.text_encoder.encode(prep.ids, prep.attn_mask, drop_seed=t5_seed, drop_p=self.dropout_p, dtype=self.adt)   # [U*L, 512], frozen
             self._t5_cache = (key, t5) if (t5_seed is None and key is not None) else (None, None)
         ta = ops.gemm_nt(t5, w["ta"], U * L, D, 512, bias=ve.text_adapter[0].bias)
         tf, ta_mean, ta_rstd = ops.norm_fwd(ta, ve.text_adapter[1].weight, ve.text_adapter[1].bias, 1e-5, U * L, relu=True)
@@ -327,7 +333,7 @@ class Tower(nn.Module):
             h1 = ops.gemm_nt(ao, w[f"f{i}.out"], M, D, D, bias=l.self_attn.out_proj.bias, residual=xf, drop=site(i, 1))
             x1, m1, r1 = ops.norm_fwd(h1, l.norm1.weight, l.norm1.bias, 1e-5, M, save_stats=need_grad)
             # the ReLU derivative is kept as 1 bit per element (M x 256 bytes): the input-gradient GEMM then reads 16x fewer mask bytes
-            f1b = torch.empty(ops.relu_bits_bytes(M, 2048), device=x1.device, dtype=torch.uint8) if need_grad else None
+            f1b = torch.empty(ops.relu_bits_bytes(M, 2048), device=x1.device, dtype=torch.uint8) if (need_grad and self.adt == BF16) else None
             f1 = ops.gemm_nt(x1, w[f"f{i}.l1"], M, 2048, D, bias=l.linear1.bias, act=ops.ACT_RELU, relu_bits_out=f1b, drop=site(i, 2))
             h2 = ops.gemm_nt(f1, w[f"f{i}.l2"], M, D, 2048, bias=l.linear2.bias, residual=x1, drop=site(i, 3))
             xo, m2, r2 = ops.norm_fwd(h2, l.norm2.weight, l.norm2.bias, 1e-5, M, save_stats=need_grad)
@@ -336,7 +342,7 @@ class Tower(nn.Module):
             xf = xo
         c["fusion"] = fl
         # decoder over the rollout time axis, rows (b*T + t)
-        j = torch.empty(R, D, device=self.device_, dtype=BF16)
+        j = torch.empty(R, D, device=self.device_, dtype=self.adt)
         ops.decoder_embed_fwd(xf, xf_stride, self.last_actions_embed.weight, self.object_in_hand_embed.weight,
                               self.time_encoder.div_term, prep.prev_actions, prep.masks, prep.hand, prep.time_step, T, B, j)
         xd = j
@@ -463,7 +469,7 @@ class Tower(nn.Module):
             first = False
         if first:
             return
-        dy = torch.empty(R, D, device=dev, dtype=BF16)
+        dy = torch.empty(R, D, device=dev, dtype=self.adt)
         ops.cast_bf16(dbel, dy)
         ops.gemm_tn_acc(dy, c["nf"], dw["dout"], R, D, D)
         dnf = ops.gemm_nt(dy, wt["dout"], R, D, D)
@@ -478,7 +484,7 @@ class Tower(nn.Module):
             dh = ops.norm_bwd(dn2, a["h"], l.ffn_norm.weight, None, None, a["r2"], R, g(l.ffn_norm.weight), None, rms=True, dres=dx)
             ops.gemm_tn_acc(dh, a["ao"], dw[f"d{i}.wo"], R, D, D)
             dao = ops.gemm_nt(dh, wt[f"d{i}.wo"], R, D, D)
-            dqkv = torch.empty(R, 3 * D, device=dev, dtype=BF16)
+            dqkv = torch.empty(R, 3 * D, device=dev, dtype=self.adt)
             q = a["qkv"]
             ops.attn_bwd(q, q[:, D:], q[:, 2 * D:], 3 * D, a["ao"], D, a["lse"], dao, D, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D,
                          B, T, 8, 0.125, mask_mode=ops.MASK_BLOCK_CAUSAL, traj=prep.traj_bt)
@@ -487,12 +493,12 @@ class Tower(nn.Module):
             dx = ops.norm_bwd(dn1, a["x"], l.attention_norm.weight, None, None, a["r1"], R, g(l.attention_norm.weight), None, rms=True, dres=dh)
         pruned = bool(c["fusion"]) and c["fusion"][-1]["pruned"]
         if pruned:
-            dxf = torch.empty(R, D, device=dev, dtype=BF16)        # gradient of the position-0 outputs only
+            dxf = torch.empty(R, D, device=dev, dtype=self.adt)        # gradient of the position-0 outputs only
             ops.decoder_embed_bwd(dx, prep.prev_actions, prep.masks, prep.hand, T, B, dxf, D, g(self.last_actions_embed.weight),
                                   g(self.object_in_hand_embed.weight))
             dyf = dxf
         else:
-            dxf = torch.zeros(R, S, D, device=dev, dtype=BF16)
+            dxf = torch.zeros(R, S, D, device=dev, dtype=self.adt)
             ops.decoder_embed_bwd(dx, prep.prev_actions, prep.masks, prep.hand, T, B, dxf, S * D, g(self.last_actions_embed.weight),
                                   g(self.object_in_hand_embed.weight))
             dyf = dxf.view(M, D)
@@ -519,8 +525,8 @@ class Tower(nn.Module):
                 da = dh1 if da is None else da
                 ops.gemm_tn_acc(da, a["ao"], dw[f"f{i}.out"], R, D, D, db=g(l.self_attn.out_proj.bias))
                 dao = ops.gemm_nt(da, wt[f"f{i}.out"], R, D, D)
-                dq0 = torch.empty(R, D, device=dev, dtype=BF16)
-                dkv = torch.empty(M, 2 * D, device=dev, dtype=BF16)
+                dq0 = torch.empty(R, D, device=dev, dtype=self.adt)
+                dkv = torch.empty(M, 2 * D, device=dev, dtype=self.adt)
                 kv = a["kv"]
                 ops.attn_bwd(a["q0"], kv, kv[:, D:], 2 * D, a["ao"], D, a["lse"], dao, D, dq0, dkv, dkv[:, D:], 2 * D, R, S, 8, 0.125,
                              Sq=1, ldq=D, lddq=D, drop=site(i, 0))
@@ -539,7 +545,10 @@ class Tower(nn.Module):
             df = dh2 if df is None else df               # grad of linear2's output (through dropout2); dh2 = residual-path grad
             ops.gemm_tn_acc(df, a["f1"], dw[f"f{i}.l2"], M, D, 2048, db=g(l.linear2.bias))
             # the sign bits were taken after ReLU and dropout: bit <=> (pre-activation > 0 and kept); alpha = the dropout scale
-            df1 = ops.gemm_nt(df, wt[f"f{i}.l2"], M, 2048, D, relu_bits=a["f1b"], alpha=drop_scale)
+            if a["f1b"] is not None:
+                df1 = ops.gemm_nt(df, wt[f"f{i}.l2"], M, 2048, D, relu_bits=a["f1b"], alpha=drop_scale)
+            else:       # fp32 verification mode: the stored activation itself is the mask
+                df1 = ops.gemm_nt(df, wt[f"f{i}.l2"], M, 2048, D, relu_mask=a["f1"], alpha=drop_scale)
             ops.gemm_tn_acc(df1, a["x1"], dw[f"f{i}.l1"], M, 2048, D, db=g(l.linear1.bias))
             dx1 = ops.gemm_nt(df1, wt[f"f{i}.l1"], M, D, 2048, residual=dh2)
             del df1, df
@@ -549,7 +558,7 @@ class Tower(nn.Module):
             da = dh1 if da is None else da
             ops.gemm_tn_acc(da, a["ao"], dw[f"f{i}.out"], M, D, D, db=g(l.self_attn.out_proj.bias))
             dao = ops.gemm_nt(da, wt[f"f{i}.out"], M, D, D)
-            dqkv = torch.empty(M, 3 * D, device=dev, dtype=BF16)
+            dqkv = torch.empty(M, 3 * D, device=dev, dtype=self.adt)
             q = a["qkv"]
             ops.attn_bwd(q, q[:, D:], q[:, 2 * D:], 3 * D, a["ao"], D, a["lse"], dao, D, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D,
                          R, S, 8, 0.125, drop=site(i, 0))
@@ -561,7 +570,7 @@ class Tower(nn.Module):
         # text adapter (trainable) -- the T5 encoder is frozen (no_grad in the reference)
         dtf = torch.zeros(U * L, D, device=dev, dtype=F32)
         ops.fusion_text_bwd(dx0, prep.gid, T, B, S, L, TEXT_OFF, dtf)
-        dtf_b = torch.empty(U * L, D, device=dev, dtype=BF16)
+        dtf_b = torch.empty(U * L, D, device=dev, dtype=self.adt)
         ops.cast_bf16(dtf, dtf_b)
         dta = ops.norm_bwd(dtf_b, c["ta"], ve.text_adapter[1].weight, ve.text_adapter[1].bias, c["ta_stats"][0], c["ta_stats"][1], U * L,
                            g(ve.text_adapter[1].weight), g(ve.text_adapter[1].bias), relu=True)
@@ -613,15 +622,15 @@ class T5Frozen(nn.Module):
         self._rt = None
         self._bias_cache: Dict[int, torch.Tensor] = {}
 
-    def sync(self):
-        """(re)build the bf16 runtime copies of the frozen weights."""
+    def sync(self, dtype=BF16):
+        """(re)build the runtime copies (bf16, or fp32 in the verification mode) of the frozen weights."""
         rt = []
         for b in self.encoder.block:
             sa, ff = b.layer[0].SelfAttention, b.layer[1].DenseReluDense
-            rt.append(dict(qkv=torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], 0).to(BF16).contiguous(),
-                           o=sa.o.weight.to(BF16).contiguous(), wi=ff.wi.weight.to(BF16).contiguous(),
-                           wo=ff.wo.weight.to(BF16).contiguous()))
-        self._rt = rt
+            rt.append(dict(qkv=torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], 0).to(dtype).contiguous(),
+                           o=sa.o.weight.to(dtype).contiguous(), wi=ff.wi.weight.to(dtype).contiguous(),
+                           wo=ff.wo.weight.to(dtype).contiguous()))
+        self._rt, self._rt_dtype = rt, dtype
         self._bias_cache.clear()
 
     def position_bias(self, L: int) -> torch.Tensor:
@@ -642,19 +651,19 @@ class T5Frozen(nn.Module):
     T5_STREAM = 64      # dropout stream ids of the text encoder: 62 embedding, 63 final, 64 + 4*block + {0 probs, 1 attn out, 2 ff act, 3 ff out}
 
     @torch.no_grad()
-    def encode(self, ids: torch.Tensor, attn_mask: torch.Tensor, drop_seed: Optional[int] = None, drop_p: float = 0.1) -> torch.Tensor:
+    def encode(self, ids: torch.Tensor, attn_mask: torch.Tensor, drop_seed: Optional[int] = None, drop_p: float = 0.1, dtype=BF16) -> torch.Tensor:
         """ids, attn_mask [U, L] int64 (device) -> last_hidden_state [U*L, 512] bf16.
 
         ``drop_seed``: the text encoder is frozen (no_grad) but NOT in eval mode in the reference -- the policy's ``self.train()``
         (allenact_dino_transformer.py:193) switches HF T5's dropout 0.1 on too -- so in train mode its six
         dropout sites per block / stack are applied here as well.  One realisation per unique goal and forward pass (the reference
         re-encodes the goal for every (t, b) row and so draws a fresh mask per row)."""
-        if self._rt is None:
-            self.sync()
+        if self._rt is None or getattr(self, "_rt_dtype", BF16) != dtype:
+            self.sync(dtype)
         U, L = ids.shape
         n = U * L
         site = (lambda k: ops.Dropout(drop_seed, k, drop_p)) if drop_seed is not None and drop_p > 0 else (lambda k: None)
-        x = ops.embed_gather(self.shared.weight, ids.reshape(-1).contiguous())
+        x = ops.embed_gather(self.shared.weight, ids.reshape(-1).contiguous(), dtype=dtype)
         ops.dropout_(x, site(62))
         bias = self.position_bias(L)
         kvalid = attn_mask.to(torch.uint8).contiguous()
@@ -707,18 +716,18 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
     def __init__(self, device="cuda", tokenizer: Optional[GoalTokenizer] = None, max_steps: int = 500,
                  goal_sensor_uuid="natural_language_spec", rgb_dino_preprocessor_uuid="rgb_dinov2",
                  manipulation_rgb_dino_preprocessor_uuid="manipulation_rgb_dinov2", an_object_is_in_hand_uuid="an_object_is_in_hand",
-                 time_step_uuid="time_step", traj_idx_uuid="traj_index", critic_type: str = "linear", **unused):
+                 time_step_uuid="time_step", traj_idx_uuid="traj_index", critic_type: str = "linear", precision: str = "bf16", **unused):
         if not torch.cuda.is_available():
             raise RuntimeError("safevla_amd needs an MI355X: there is no CPU or eager fallback for the policy kernels")
         ops.lib()  # fail loudly if the HIP extension is missing
         arena = _Arena()
         device = torch.device(device)
         arena.begin_tower()
-        super().__init__(arena, device, max_steps=max_steps, critic_type=critic_type)      # every tower is built from the same kwargs
+        super().__init__(arena, device, max_steps=max_steps, critic_type=critic_type, precision=precision)      # every tower is built from the same kwargs
         arena.begin_tower()
-        self.critic_tsfm = Tower(arena, device, max_steps=max_steps, critic_type=critic_type)
+        self.critic_tsfm = Tower(arena, device, max_steps=max_steps, critic_type=critic_type, precision=precision)
         arena.begin_tower()
-        self.c_critic_tsfm = Tower(arena, device, max_steps=max_steps, critic_type=critic_type)
+        self.c_critic_tsfm = Tower(arena, device, max_steps=max_steps, critic_type=critic_type, precision=precision)
         arena.build(device)
         self.towers = [self, self.critic_tsfm, self.c_critic_tsfm]
         for t in self.towers:
@@ -751,7 +760,7 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
         for t in self.towers:
             t.refresh_transposes()
             if frozen:
-                t.visual_encoder.text_encoder.sync()
+                t.visual_encoder.text_encoder.sync(t.adt)
                 t._t5_cache = (None, None)
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
@@ -772,9 +781,9 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
         p = Prep()
         p.T, p.B, p.R = T, B, R
         if "dino_tokens" in observations:       # storage-native layout [T,B,2,84,384] bf16
-            p.tokens = observations["dino_tokens"].reshape(R, 2, NPATCH, DINO).contiguous()
+            p.tokens = observations["dino_tokens"].reshape(R, 2, NPATCH, DINO).to(self.adt).contiguous()
         else:
-            p.tokens = torch.empty(R, 2, NPATCH, DINO, device=dev, dtype=BF16)
+            p.tokens = torch.empty(R, 2, NPATCH, DINO, device=dev, dtype=self.adt)
             ops.feat_to_tokens(observations[u["nav"]].reshape(R, DINO, NPATCH).contiguous(), p.tokens, 0)
             ops.feat_to_tokens(observations[u["manip"]].reshape(R, DINO, NPATCH).contiguous(), p.tokens, 1)
         p.prev_actions = prev_actions.reshape(R).contiguous()
@@ -834,7 +843,7 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
         if st is None:
             st = Prep()
             st.T, st.B, st.R, st.U, st.L, st.S = 1, B, B, B, L, TEXT_OFF + L
-            st.tokens = torch.zeros(B, 2, NPATCH, DINO, device=dev, dtype=BF16)
+            st.tokens = torch.zeros(B, 2, NPATCH, DINO, device=dev, dtype=self.adt)
             st.prev_actions = torch.zeros(B, device=dev, dtype=torch.int64)
             st.masks = torch.zeros(B, device=dev, dtype=F32)
             st.hand = torch.zeros(B, device=dev, dtype=torch.int64)

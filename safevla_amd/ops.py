@@ -127,12 +127,14 @@ def small_linear_bwd(x, W, dout, dx, dW, db, T=0, B=0, accumulate_dx=False):
 # ------------------------------------------------------------------------------------------------ norms
 def norm_fwd(x, gamma, beta, eps, rows, D=512, rms=False, relu=False, tok=None, tok_group=0, y=None,
              xmap=(0, 0, 0), ymap=(0, 0, 0), save_stats=True):
-    _chk(x, BF16, "x")
+    f32 = x.dtype == F32            # fp32 verification mode: the same kernel instantiated on float rows
+    if not f32:
+        _chk(x, BF16, "x")
     if y is None:
-        y = torch.empty(rows, D, device=x.device, dtype=BF16)
+        y = torch.empty(rows, D, device=x.device, dtype=x.dtype)
     mean = torch.empty(rows, device=x.device, dtype=F32) if (save_stats and not rms) else None
     rstd = torch.empty(rows, device=x.device, dtype=F32) if save_stats else None
-    lib().call("svla_norm_fwd_bf16", _p(x), *xmap, _p(gamma), _p(beta), float(eps), rows, D, int(rms), int(relu), _p(tok),
+    lib().call("svla_norm_fwd_f32" if f32 else "svla_norm_fwd_bf16", _p(x), *xmap, _p(gamma), _p(beta), float(eps), rows, D, int(rms), int(relu), _p(tok),
                int(tok_group), _p(y), *ymap, _p(mean), _p(rstd), _stream())
     return y, mean, rstd
 
@@ -141,10 +143,12 @@ def norm_bwd(dy, x, gamma, beta, mean, rstd, rows, dgamma, dbeta, D=512, rms=Fal
              dx=None, dymap=(0, 0, 0), xmap=(0, 0, 0), dxmap=(0, 0, 0), dres=None, dx_drop=None, drop=None):
     """``dx_drop`` (optional [rows, D] output) = dx with the keep-mask / scale of dropout site ``drop`` applied: the gradient of
     the sub-layer output that was dropped out before being added to the residual stream."""
-    _chk(dy, BF16, "dy")
+    f32 = dy.dtype == F32
+    if not f32:
+        _chk(dy, BF16, "dy")
     if dx is None:
-        dx = torch.empty(rows, D, device=x.device, dtype=BF16)
-    lib().call("svla_norm_bwd_bf16", _p(dy), *dymap, _p(x), *xmap, _p(gamma), _p(beta), _p(mean), _p(rstd), rows, D, int(rms),
+        dx = torch.empty(rows, D, device=x.device, dtype=dy.dtype)
+    lib().call("svla_norm_bwd_f32" if f32 else "svla_norm_bwd_bf16", _p(dy), *dymap, _p(x), *xmap, _p(gamma), _p(beta), _p(mean), _p(rstd), rows, D, int(rms),
                int(relu), int(tok_group), _p(dres), _p(dx), *dxmap, _p(dgamma), _p(dbeta), _p(dtok), _p(dx_drop), _d(drop), _stream())
     return dx
 
@@ -179,19 +183,30 @@ def dropout_(x, drop):
     """In-place dropout of a contiguous [rows, N] bf16 tensor (element index = flat index)."""
     if drop is None:
         return x
-    _chk(x, BF16, "x")
-    lib().call("svla_dropout_bf16", _p(x), x.numel() // x.shape[-1], x.shape[-1], _d(drop), _stream())
+    if x.dtype != F32:
+        _chk(x, BF16, "x")
+    lib().call("svla_dropout_f32" if x.dtype == F32 else "svla_dropout_bf16", _p(x), x.numel() // x.shape[-1], x.shape[-1], _d(drop), _stream())
     return x
 
 
 # ------------------------------------------------------------------------------------------------ GEMMs
 def gemm_nt(A, B, M, N, K, bias=None, residual=None, relu_mask=None, act=ACT_NONE, out=None, out_f32=False, alpha=1.0,
             lda=None, ldb=None, ldc=None, ldr=None, ldm=None, relu_bits_out=None, relu_bits=None, drop=None):
-    """out[M,N] = epi(alpha * A[M,K] @ B[N,K]^T).  A/B bf16; leading dims default to the last-dim stride of 2-D views."""
-    _chk(A, BF16, "A")
-    _chk(B, BF16, "B")
+    """out[M,N] = epi(alpha * A[M,K] @ B[N,K]^T).  A/B bf16; leading dims default to the last-dim stride of 2-D views.
+    fp32 operands (verification mode) run the fp32 strided GEMM with the same epilogue (ReLU masks as tensors, no bit masks)."""
     lda = lda if lda is not None else A.stride(-2)
     ldb = ldb if ldb is not None else B.stride(-2)
+    if A.dtype == F32:
+        if relu_bits is not None or relu_bits_out is not None:
+            raise ValueError("fp32 mode keeps the ReLU mask as a tensor (relu_mask=), not as bits")
+        if out is None:
+            out = torch.empty(M, N, device=A.device, dtype=F32)
+        return gemm_f32(A, B, M, N, K, sa=(lda, 1), sb=(ldb, 1), bias=bias, act=act, residual=residual, mask=relu_mask, out=out, alpha=alpha,
+                        drop=drop, ldc=ldc if ldc is not None else out.stride(-2),
+                        ldr=ldr if ldr is not None else (residual.stride(-2) if residual is not None else 0),
+                        ldm=ldm if ldm is not None else (relu_mask.stride(-2) if relu_mask is not None else 0))
+    _chk(A, BF16, "A")
+    _chk(B, BF16, "B")
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=F32 if out_f32 else BF16)
     ldc = ldc if ldc is not None else out.stride(-2)
@@ -213,6 +228,13 @@ def gemm_force_small_tile(on: bool):
 
 def gemm_tn_acc(dY, X, dW, M, N, K, ldy=None, ldx=None, ldw=None, db=None):
     """dW[N,K] (fp32) += dY[M,N]^T @ X[M,K];  optional fused bias gradient db[N] += dY.sum(0)."""
+    if dY.dtype == F32:
+        ldy = ldy if ldy is not None else dY.stride(-2)
+        ldx = ldx if ldx is not None else X.stride(-2)
+        gemm_f32(dY, X, N, K, M, sa=(1, ldy), sb=(1, ldx), out=dW, accumulate=True, ldc=ldw if ldw is not None else dW.stride(-2))
+        if db is not None:
+            colsum_f32(dY, db, M, N, ldx=ldy)
+        return
     _chk(dY, BF16, "dY")
     _chk(X, BF16, "X")
     _chk(dW, F32, "dW")
@@ -221,6 +243,8 @@ def gemm_tn_acc(dY, X, dW, M, N, K, ldy=None, ldx=None, ldw=None, db=None):
 
 
 def colsum_acc(dY, db, M, N, ldy=None, row_stride=1):
+    if dY.dtype == F32:
+        return colsum_f32(dY, db, M, N, row_stride=row_stride, ldx=ldy if ldy is not None else dY.stride(-2))
     lib().call("svla_colsum_bf16", _p(dY), ldy if ldy is not None else dY.stride(-2), M, N, row_stride, _p(db), _stream())
 
 
@@ -231,16 +255,20 @@ def attn_fwd(q, k, v, ld, rows, S, H, scale, out=None, ldo=None, mask_mode=MASK_
     every row (q then holds Sq rows per batch row with row stride ldq)."""
     nq = Sq if Sq > 0 else S
     if out is None:
-        out = torch.empty(rows * nq, H * 64, device=q.device, dtype=BF16)
+        out = torch.empty(rows * nq, H * 64, device=q.device, dtype=q.dtype)
     ldo = ldo if ldo is not None else out.stride(-2)
     lse = torch.empty(rows, H, nq, device=q.device, dtype=F32) if save_lse else None
-    lib().call("svla_attn_fwd_bf16", _p(q), _p(k), _p(v), ld, _p(out), ldo, _p(lse), rows, S, H, 64, float(scale), mask_mode,
+    lib().call("svla_attn_fwd_f32" if q.dtype == F32 else "svla_attn_fwd_bf16", _p(q), _p(k), _p(v), ld, _p(out), ldo, _p(lse), rows, S, H, 64, float(scale), mask_mode,
                _p(traj), _p(bias), _p(kvalid), int(Sq), int(ldq), int(kv_rows), _d(drop), _stream())
     return out, lse
 
 
 def attn_bwd(q, k, v, ld, o, ldo, lse, do, lddo, dq, dk, dv, ldd, rows, S, H, scale, mask_mode=MASK_NONE, traj=None,
              bias=None, kvalid=None, Sq=0, ldq=0, lddq=0, d_ws=None, drop=None):
+    if q.dtype == F32:
+        lib().call("svla_attn_bwd_f32", _p(q), _p(k), _p(v), ld, _p(o), ldo, _p(lse), _p(do), lddo, _p(dq), _p(dk), _p(dv), ldd, rows, S, H, 64,
+                   float(scale), mask_mode, _p(traj), _p(kvalid), int(Sq), int(ldq), int(lddq), _d(drop), _stream())
+        return
     if d_ws is None:   # [rows, H, Sq] fp32 workspace: rowsum(dO * O), handed from the dQ kernel to the dK/dV kernel
         d_ws = torch.empty(rows * H * (Sq or S), device=q.device, dtype=F32)
     lib().call("svla_attn_bwd_bf16", _p(q), _p(k), _p(v), ld, _p(o), ldo, _p(lse), _p(do), lddo, _p(dq), _p(dk), _p(dv), ldd,
@@ -253,43 +281,43 @@ def feat_to_tokens(feat, out, cam, ncam=2):
     _chk(feat, F32, "feat")
     R, C = feat.shape[:2]
     P = feat[0, 0].numel()
-    lib().call("svla_feat_to_tokens", _p(feat), R, C, P, cam, ncam, _p(out), _stream())
+    lib().call("svla_feat_to_tokens_f32" if out.dtype == F32 else "svla_feat_to_tokens", _p(feat), R, C, P, cam, ncam, _p(out), _stream())
 
 
 def fusion_fill(fusion_token, text, gid, x0, R, S, L, text_off):
-    lib().call("svla_fusion_fill", _p(fusion_token), _p(text), _p(gid), R, S, L, text_off, _p(x0), _stream())
+    lib().call("svla_fusion_fill_f32" if x0.dtype == F32 else "svla_fusion_fill", _p(fusion_token), _p(text), _p(gid), R, S, L, text_off, _p(x0), _stream())
 
 
 def fusion_text_bwd(dx0, gid, T, B, S, L, text_off, dtext):
-    lib().call("svla_fusion_text_bwd", _p(dx0), _p(gid), T, B, S, L, text_off, _p(dtext), _stream())
+    lib().call("svla_fusion_text_bwd_f32" if dx0.dtype == F32 else "svla_fusion_text_bwd", _p(dx0), _p(gid), T, B, S, L, text_off, _p(dtext), _stream())
 
 
 def decoder_embed_fwd(xf, xf_row_stride, act_tab, hand_tab, div_term, prev_actions, masks, hand, time_step, T, B, out,
                       n_actions=20):
-    lib().call("svla_decoder_embed_fwd", _p(xf), xf_row_stride, _p(act_tab), _p(hand_tab), _p(div_term), _p(prev_actions),
+    lib().call("svla_decoder_embed_fwd_f32" if out.dtype == F32 else "svla_decoder_embed_fwd", _p(xf), xf_row_stride, _p(act_tab), _p(hand_tab), _p(div_term), _p(prev_actions),
                _p(masks), _p(hand), _p(time_step), T, B, n_actions, _p(out), _stream())
 
 
 def decoder_embed_bwd(dout, prev_actions, masks, hand, T, B, dxf, dxf_row_stride, d_act_tab, d_hand_tab, n_actions=20):
-    lib().call("svla_decoder_embed_bwd", _p(dout), _p(prev_actions), _p(masks), _p(hand), T, B, n_actions, _p(dxf),
+    lib().call("svla_decoder_embed_bwd_f32" if dout.dtype == F32 else "svla_decoder_embed_bwd", _p(dout), _p(prev_actions), _p(masks), _p(hand), T, B, n_actions, _p(dxf),
                dxf_row_stride, _p(d_act_tab), _p(d_hand_tab), _stream())
 
 
 def rows_add(dst, dst_ld, src, src_ld, rows):
-    lib().call("svla_rows_add_bf16", _p(dst), dst_ld, _p(src), src_ld, rows, 512, _stream())
+    lib().call("svla_rows_add_f32" if dst.dtype == F32 else "svla_rows_add_bf16", _p(dst), dst_ld, _p(src), src_ld, rows, 512, _stream())
 
 
 def swiglu_fwd(ab, M, Hd, out=None):
     if out is None:
-        out = torch.empty(M, Hd, device=ab.device, dtype=BF16)
-    lib().call("svla_swiglu_fwd", _p(ab), M, Hd, _p(out), _stream())
+        out = torch.empty(M, Hd, device=ab.device, dtype=ab.dtype)
+    lib().call("svla_swiglu_fwd_f32" if ab.dtype == F32 else "svla_swiglu_fwd", _p(ab), M, Hd, _p(out), _stream())
     return out
 
 
 def swiglu_bwd(ab, dg, M, Hd, dab=None):
     if dab is None:
-        dab = torch.empty(M, 2 * Hd, device=ab.device, dtype=BF16)
-    lib().call("svla_swiglu_bwd", _p(ab), _p(dg), M, Hd, _p(dab), _stream())
+        dab = torch.empty(M, 2 * Hd, device=ab.device, dtype=ab.dtype)
+    lib().call("svla_swiglu_bwd_f32" if ab.dtype == F32 else "svla_swiglu_bwd", _p(ab), _p(dg), M, Hd, _p(dab), _stream())
     return dab
 
 
@@ -302,11 +330,11 @@ def row_hash(rows_u8):
     return out
 
 
-def embed_gather(table, ids, out=None):
+def embed_gather(table, ids, out=None, dtype=BF16):
     n, D = ids.numel(), table.shape[1]
     if out is None:
-        out = torch.empty(n, D, device=table.device, dtype=BF16)
-    lib().call("svla_embed_gather_f32_bf16", _p(table), _p(ids), n, D, _p(out), _stream())
+        out = torch.empty(n, D, device=table.device, dtype=dtype)
+    lib().call("svla_embed_gather_f32" if out.dtype == F32 else "svla_embed_gather_f32_bf16", _p(table), _p(ids), n, D, _p(out), _stream())
     return out
 
 
@@ -329,11 +357,17 @@ def ce_loss_fwd_bwd(logits, target, n_valid, dlogits, sums, ignore_index=-1):
 
 
 def cast_bf16(src, dst):
+    if dst.dtype == F32:          # fp32 verification mode: activations stay fp32
+        dst.copy_(src)
+        return
     lib().call("svla_cast_f32_bf16", _p(src), _p(dst), src.numel(), _stream())
 
 
 def transpose_cast_bf16(src, dst):
     rows, cols = src.shape
+    if dst.dtype == F32:          # fp32 verification mode
+        dst.copy_(src.t())
+        return
     lib().call("svla_transpose_cast_f32_bf16", _p(src), rows, cols, _p(dst), _stream())
 
 

@@ -37,17 +37,34 @@ def build_parser():
     ap.add_argument("--machine_id", type=int, default=0)
     ap.add_argument("--distributed_ip_and_port", default="127.0.0.1:0")
     ap.add_argument("--callbacks", default="")
+    ap.add_argument("--save_dir_fmt", default="flat", choices=["flat", "nested"])
+    ap.add_argument("--extra_tag", default="")
+    ap.add_argument("--deterministic_cudnn", default=False)
+    ap.add_argument("--deterministic_agents", default=False)
+    ap.add_argument("--disable_tensorboard", default=True)
+    ap.add_argument("--disable_config_saving", default=True)
+    ap.add_argument("--restart_pipeline", default=False)
     ap.add_argument("--cost_limit", type=float, default=None)
     ap.add_argument("--checkpoint", default=None)
     # synthetic-run controls (not in the reference)
     ap.add_argument("--num_steps", type=int, default=128, help="rollout length (reference: TrainingSettings(num_steps=128))")
     ap.add_argument("--total_steps", type=int, default=0, help="stop after this many env steps (0: run the full stage schedule)")
-    ap.add_argument("--task", default="ObjectNav", help="ObjectNav | PickUp | Fetch | Mixed (env e -> task e mod 3)")
+    ap.add_argument("--task", default=None, help="ObjectNav | PickUp | Fetch | Mixed (env e -> task e mod 3); default: inferred from --tag / --dataset_dir")
     ap.add_argument("--collect", default="acting", choices=["acting", "teacher"],
                     help="acting: step the synthetic vector env through the KV-cached single-step policy like the reference engine; "
                          "teacher: fill the storage with one full-sequence pass (benchmark mode)")
     ap.add_argument("--goal_tokens", type=int, default=12)
     return ap
+
+
+def infer_task(tag: str, dataset_dir: str) -> str:
+    """The reference picks its task sampler from the dataset directory (``.../ObjectNavType`` | ``PickupType`` | ``FetchType``,
+    scripts/train.sh:97-110; tag = the same string)."""
+    s = f"{tag} {dataset_dir}".lower()
+    for key, task in (("pickup", "PickUp"), ("fetch", "Fetch"), ("objectnav", "ObjectNav"), ("mixed", "Mixed")):
+        if key in s:
+            return task
+    return "ObjectNav"
 
 
 def stage_for(step: int):
@@ -59,6 +76,8 @@ def stage_for(step: int):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    if args.task is None:
+        args.task = infer_task(args.tag, args.dataset_dir)
     from . import parallel
     from .checkpoint import init_towers_from_il, load_checkpoint, save_checkpoint
     from .engine import PPOLagConfig, PPOLagEngine

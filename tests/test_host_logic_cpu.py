@@ -158,3 +158,24 @@ def test_bench_refuses_to_run_fewer_ranks_than_requested():
     env["WORLD_SIZE"] = "2"; env["RANK"] = "0"
     src = open(os.path.join(root, "bench.py")).read()
     assert "or world == 1" not in src
+
+
+def test_reference_entry_point_shim_parses_fire_style_command_lines():
+    import importlib.util
+    import os
+
+    from safevla_amd.train import build_parser, infer_task
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("entry", os.path.join(root, "training", "online", "dinov2_vits_tsfm_base.py"))
+    entry = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(entry)
+    with pytest.raises(SystemExit):
+        entry.main(["--num_train_processes", "4"])              # no command
+    with pytest.raises(SystemExit):
+        entry.main(["test", "--checkpoint", "x"])              # simulator-bound evaluation runner: refused with a pointer to the agent
+    a = build_parser().parse_args(["train", "--il_ckpt_path=il.ckpt", "--num_train_processes", "32", "--dataset_dir", "data/fifteen/FetchType",
+                                   "--tag", "FetchType", "--cost_limit", "2.31964", "--wandb_project", "p", "--wandb_entity", "e",
+                                   "--callbacks", "wandb_logging_callback", "--checkpoint", "c.pt"])
+    assert (a.il_ckpt_path, a.num_train_processes, a.cost_limit, a.checkpoint) == ("il.ckpt", 32, 2.31964, "c.pt")
+    assert infer_task(a.tag, a.dataset_dir) == "Fetch" and infer_task("ObjectNavType", "") == "ObjectNav" and infer_task("PickupType", "") == "PickUp"

@@ -37,16 +37,15 @@ def test_hlgauss_kernel_vs_reference_golden(ops):
     R, NB = logits.shape
     values, dl, sums = ops.hlgauss_fwd_bwd(logits, target, None, -5.0, 15.0, 0.15, 1.0, 1.0 / R)
     np.testing.assert_allclose(sums.item() / R, float(g["loss"]), rtol=2e-5)
-    # reference value read-out: transform_from_probs applied to its own target probabilities -- here: value of softmax(logits)
-    want_v = (torch.softmax(torch.from_numpy(g["logits"]).double(), -1) * ((torch.linspace(-5, 15, NB + 1)[:-1] + torch.linspace(-5, 15, NB + 1)[1:]) / 2).double()).sum(-1)
-    np.testing.assert_allclose(values.cpu().numpy(), want_v.numpy(), rtol=1e-5, atol=1e-5)
+    # the reference's read-out: transform_from_probs(softmax(logits)) (golden "value")
+    np.testing.assert_allclose(values.cpu().numpy(), g["value"], rtol=1e-5, atol=1e-5)
     # gradient of the mean cross-entropy against the reference's probabilities: (softmax - q) / R
     want_dl = (torch.softmax(torch.from_numpy(g["logits"]), -1) - torch.from_numpy(g["probs"])) / R
     np.testing.assert_allclose(dl.cpu().numpy(), want_dl.numpy(), rtol=1e-4, atol=2e-7)
-    # the golden's "value" = transform_from_probs(probs): feed log(probs) as logits -> softmax == probs
+    # transform_from_probs(transform_to_probs(t)) ~ t (bin width 0.2, sigma 0.15): feed log(probs) as logits -> softmax == probs
     lp = torch.log(torch.from_numpy(g["probs"]).clamp_min(1e-30)).to(DEV)
     v2, _, _ = ops.hlgauss_fwd_bwd(lp, None, None, -5.0, 15.0, 0.15, want_grad=False)
-    np.testing.assert_allclose(v2.cpu().numpy(), g["value"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(v2.cpu().numpy(), g["target"], atol=2e-2)
 
 
 def test_hlgauss_value_path_gradient_and_loss_object(ops):
@@ -103,21 +102,21 @@ def test_gemm_f32_all_layouts(ops, M, N, K):
     A, B, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
     want = F.relu(A @ B.t() + bias) + res
     got = ops.gemm_f32(A.to(DEV), B.to(DEV), M, N, K, bias=bias.to(DEV), act=ops.ACT_RELU, residual=res.to(DEV))
-    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)      # fp32 accumulation order (K up to 512)
     # NN: dX = dY . W  (B given as [K, N] row-major)
     Bt = B.t().contiguous()
     got = ops.gemm_f32(A.to(DEV), Bt.to(DEV), M, N, K, sb=(1, N))
-    np.testing.assert_allclose(got.cpu().numpy(), (A @ B.t()).numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(got.cpu().numpy(), (A @ B.t()).numpy(), rtol=1e-4, atol=1e-4)
     # TN with accumulate: dW[N, K] += dY[M, N]^T X[M, K]
     dY, X = rnd(M, N, seed=5), rnd(M, K, seed=6)
     acc = rnd(N, K, seed=7)
     out = acc.clone().to(DEV)
     ops.gemm_f32(dY.to(DEV), X.to(DEV), N, K, M, sa=(1, N), sb=(1, K), out=out, accumulate=True)
-    np.testing.assert_allclose(out.cpu().numpy(), (acc + dY.t() @ X).numpy(), rtol=3e-5, atol=3e-5)
+    np.testing.assert_allclose(out.cpu().numpy(), (acc + dY.t() @ X).numpy(), rtol=1e-4, atol=1e-4)
     # ReLU mask + colsum
     mask = rnd(M, N, seed=8)
     got = ops.gemm_f32(A.to(DEV), B.to(DEV), M, N, K, mask=mask.to(DEV))
-    np.testing.assert_allclose(got.cpu().numpy(), ((A @ B.t()) * (mask > 0)).numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(got.cpu().numpy(), ((A @ B.t()) * (mask > 0)).numpy(), rtol=1e-4, atol=1e-4)
     cs = torch.zeros(N, device=DEV)
     ops.colsum_f32(dY.to(DEV), cs, M, N)
     np.testing.assert_allclose(cs.cpu().numpy(), dY.sum(0).numpy(), rtol=1e-4, atol=1e-4)
@@ -358,3 +357,61 @@ def test_build_agent_loads_a_lightning_checkpoint(ops, tmp_path):
     msgs = " ".join(str(x.message) for x in w)
     assert "word-hash goal tokenizer" in msgs and "random-init DINOv2" not in msgs    # ViT came from the checkpoint, tokenizer is a stand-in
     assert not m.training
+
+
+def test_reference_path_entry_point_fire_style(ops, tmp_path):
+    """`python training/online/dinov2_vits_tsfm_base.py train --flag value --flag=value` (scripts/train.sh:116-136): same path, same flags;
+    collects rollouts through the acting path on the synthetic PickUp env, runs stage-0 updates, writes an AllenAct-style checkpoint."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "training", "online", "dinov2_vits_tsfm_base.py"), "--num_train_processes=2", "train",
+           "--output_dir", str(tmp_path), "--dataset_dir", "data/fifteen/PickupType", "--cost_limit", "2.31964", "--tag=PickupType",
+           "--num_steps", "8", "--total_steps", "32", "--save_interval", "32", "--seed", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 2 and lines[-1]["training_step"] == 32 and lines[0]["stage"] == ["ppo_value_loss", "safe_ppo_value_loss"]
+    assert all(np.isfinite(l["value"]) and np.isfinite(l["c_value"]) for l in lines)
+    ck = [f for f in os.listdir(tmp_path) if f.endswith(".pt")]
+    assert len(ck) == 1 and "PickupType" in ck[0]
+    sd = torch.load(os.path.join(tmp_path, ck[0]), map_location="cpu")
+    assert "model_state_dict" in sd and sd["optimizer_state"]["tower_steps"] == [0, 8, 8]      # 2 updates x 4 epochs, critics only
+
+
+def test_sentencepiece_goal_path_on_the_gpu(ops, tmp_path):
+    """byte-string goals -> sentencepiece ids (a model trained here; t5-small's own vocabulary is a network asset)
+    -> frozen T5 -> text adapter, de-duplicated per unique string: rows with the same instruction get identical outputs, different
+    instructions differ, and the ids that reach the encoder are the sentencepiece ids + EOS."""
+    import sentencepiece as spm
+
+    from safevla_amd.model import SafeDinoLLAMATxNavActorCriticSeparate
+    from safevla_amd.text import GoalTokenizer, str_to_bytes
+
+    corpus = tmp_path / "c.txt"
+    words = "find a mug pick up the bowl fetch red apple go to sofa navigate locate plate cup laptop".split()
+    corpus.write_text("\n".join(" ".join(np.random.RandomState(i).choice(words, 5)) for i in range(400)))
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(tmp_path / "sp"), vocab_size=40, model_type="unigram",
+                                   pad_id=0, eos_id=1, unk_id=2, bos_id=-1)
+    tok = GoalTokenizer(str(tmp_path / "sp.model"))
+    m = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV, tokenizer=tok).eval()
+    T, B = 3, 4
+    goals = ["find a mug", "pick up the bowl", "find a mug", "fetch red apple"]
+    obs, pa, mk = _obs(T, B)
+    del obs["goal_token_ids"]
+    obs["natural_language_spec"] = torch.from_numpy(np.stack([np.stack([str_to_bytes(g).reshape(-1) for g in goals])] * T)).to(DEV)
+    same = obs["rgb_dinov2"][:, 0].clone()
+    obs["rgb_dinov2"][:, 2] = same
+    obs["manipulation_rgb_dinov2"][:, 2] = obs["manipulation_rgb_dinov2"][:, 0]
+    pa[:, 2] = pa[:, 0]
+    prep = m.prepare(obs, pa, mk)
+    assert prep.U == 3 and prep.L == max(len(tok.encode(g)) for g in goals)
+    want = {tuple(tok.encode(g)) for g in goals}
+    got = {tuple(int(x) for x in row if x != 0) for row in prep.ids.cpu().tolist()}
+    assert got == want and all(row[-1] == 1 for row in want)
+    with torch.no_grad():
+        aco, _ = m(obs, None, pa, mk)
+    lg = aco.distributions.logits
+    assert torch.equal(lg[:, 0], lg[:, 2]) and not torch.equal(lg[:, 0], lg[:, 1])
