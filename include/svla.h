@@ -172,7 +172,8 @@ int svla_normalize_u8_f32(const unsigned char* x, long n, const float* mean3, co
  * (dino_preprocessors.py:27-35): u8 HWC frames -> bf16 rows [B, gh*gw, KP], k = c*P*P + ky*P + kx, zero padded to KP. */
 int svla_patchify_u8_bf16(const unsigned char* frames, int B, int H, int W, int crop_x, int P, int gh, int gw, int KP,
                           const float* mean3, const float* std3, svla_bf16* out, void* stream);
-/* cls token + position embedding (DINOv2 prepare_tokens [3P torch.hub facebookresearch/dinov2], dino_preprocessors.py:106). */
+/* cls token + position embedding (DINOv2 prepare_tokens [3P torch.hub facebookresearch/dinov2], dino_preprocessors.py:106);
+ * cls == NULL: no class token -- y[b, p] = patch[b, p] + pos[p] (timm SigLIP trunk [3P], architecture/allenact_preprocessors/siglip_preprocessors.py:86-88). */
 int svla_vit_tokens(const svla_bf16* patch, const float* cls, const float* pos, int B, int NP, int C, svla_bf16* y, void* stream);
 /* x_norm_patchtokens -> (B,C,16,27) -> AdaptiveAvgPool2d((7,12)) (dino_preprocessors.py:24,31-35); bf16 tokens and/or fp32 CHW. */
 int svla_adaptive_pool_tokens(const svla_bf16* x, int B, int skip, int gh, int gw, int C, int oh, int ow, int cam, int ncam,

@@ -452,22 +452,24 @@ extern "C" int svla_adaptive_pool_tokens(const bf16_t* x, int B, int skip, int g
 }
 
 // y[b, 0, :] = cls + pos[0]; y[b, 1 + p, :] = patch[b, p, :] + pos[1 + p]   (DINOv2 prepare_tokens: cls token + position embedding)
+// cls == NULL: no class token (SigLIP / timm ``class_token=False``, siglip_preprocessors.py:86-88): y[b, p, :] = patch[b, p, :] + pos[p].
 __global__ void vit_tokens_kernel(const bf16_t* __restrict__ patch, const float* __restrict__ cls, const float* __restrict__ pos,
                                   int B, int NP, int C, bf16_t* __restrict__ y) {
-    const long n = (long)B * (NP + 1) * (C / 2);
+    const int nc = cls ? 1 : 0, NT = NP + nc;
+    const long n = (long)B * NT * (C / 2);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % (C / 2)) * 2;
         const long t = i / (C / 2);
-        const int tok = (int)(t % (NP + 1));
-        const long b = t / (NP + 1);
+        const int tok = (int)(t % NT);
+        const long b = t / NT;
         float a0, a1;
-        if (tok == 0) { a0 = cls[c]; a1 = cls[c + 1]; }
-        else { const uint32_t w = *(const uint32_t*)(patch + ((size_t)b * NP + tok - 1) * C + c); a0 = bf_lo(w); a1 = bf_hi(w); }
+        if (tok < nc) { a0 = cls[c]; a1 = cls[c + 1]; }
+        else { const uint32_t w = *(const uint32_t*)(patch + ((size_t)b * NP + tok - nc) * C + c); a0 = bf_lo(w); a1 = bf_hi(w); }
         *(uint32_t*)(y + (size_t)t * C + c) = pack_bf2(a0 + pos[(size_t)tok * C + c], a1 + pos[(size_t)tok * C + c + 1]);
     }
 }
 extern "C" int svla_vit_tokens(const bf16_t* patch, const float* cls, const float* pos, int B, int NP, int C, bf16_t* y, void* stream) {
-    if (B <= 0 || (C % 2)) return SVLA_EINVAL;
+    if (B <= 0 || NP <= 0 || (C % 2)) return SVLA_EINVAL;
     long blocks = ((long)B * (NP + 1) * (C / 2) + 255) / 256; if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(vit_tokens_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, patch, cls, pos, B, NP, C, y);
     return svla_launch_status();

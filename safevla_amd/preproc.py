@@ -11,6 +11,9 @@ here): its published ViT-S/14 forward is restated (pre-LN blocks with qkv/proj b
 bicubic position-embedding interpolation) with the hub model's ``state_dict`` names, random-init geometry. PARITY UNPINNED
 against DINOv2 proper; pinned against the fp32 oracle restatement (oracle/ref_vit.py).
 
+Geometry-generic: DINOv2 ViT-S/B/L-14 (widths 384 / 768 / 1024, 433 tokens) and the SigLIP ViT-B/L-16 trunk
+(256 tokens, no class token) run on the same kernels -- ``SigLIPPreprocessor`` mirrors siglip_preprocessors.py:18-104.
+
 MI355X path: normalise + crop + im2col fused in one kernel, patch embedding and all block linears on the bf16 MFMA GEMM
 (LayerScale folded into the frozen weights at sync time), fused attention at S = 433, output written directly in the rollout
 storage's bf16 token layout [B, ncam, 84, 384] (and/or the reference's fp32 (B,384,7,12)).
@@ -50,17 +53,33 @@ class DataAugmentationPreprocessor:
         return ops.normalize_u8(x.contiguous(), self.mean if self.normalize else (0, 0, 0), self.stdev if self.normalize else (1, 1, 1))
 
 
-class DinoViT(nn.Module):
-    """DINOv2 ViT-S/14 geometry with the hub model's parameter names."""
+# geometry presets: (dim, depth, heads, patch, native_grid, class token, LayerScale)
+VIT_PRESETS = {
+    # DINOv2 (torch.hub facebookresearch/dinov2; dino_preprocessors.py:14-18,54-76): pos_embed is the 37 x 37 grid of 518 / 14
+    "dinov2_vits14": dict(dim=384, depth=12, heads=6, patch=14, native_grid=37, cls=True, layerscale=True),
+    "dinov2_vitb14": dict(dim=768, depth=12, heads=12, patch=14, native_grid=37, cls=True, layerscale=True),
+    "dinov2_vitl14": dict(dim=1024, depth=24, heads=16, patch=14, native_grid=37, cls=True, layerscale=True),
+    # timm trunk of hf-hub:timm/ViT-B-16-SigLIP-256 (siglip_preprocessors.py:15,86-88; image_encoders.py:75-112): 256 x 256 input,
+    # 16 x 16 patches -> 256 tokens, no class token, no LayerScale, learned [1, 256, 768] position embedding used as is
+    "ViT-B-16-SigLIP-256": dict(dim=768, depth=12, heads=12, patch=16, native_grid=16, cls=False, layerscale=False),
+    "ViT-L-16-SigLIP-256": dict(dim=1024, depth=24, heads=16, patch=16, native_grid=16, cls=False, layerscale=False),
+}
 
-    def __init__(self, device, dim=384, depth=12, heads=6, patch=14, native_grid=37):
+
+class DinoViT(nn.Module):
+    """Frozen ViT trunk with the hub / timm parameter names: DINOv2 ViT-S/B/L-14 and the SigLIP ViT-B/L-16 geometries."""
+
+    def __init__(self, device, dim=384, depth=12, heads=6, patch=14, native_grid=37, cls=True, layerscale=True):
         super().__init__()
+        assert dim % 64 == 0 and dim // heads == 64, "attention kernels: head_dim 64"
         self.dim, self.depth, self.heads, self.patch, self.native_grid = dim, depth, heads, patch, native_grid
+        self.has_cls, self.has_ls = cls, layerscale
         d = torch.device(device)
         P = lambda *s, sc=0.02: nn.Parameter((torch.randn(*s) * sc).to(d), requires_grad=False)
-        self.cls_token = P(1, 1, dim)
-        self.pos_embed = P(1, 1 + native_grid * native_grid, dim)
-        self.mask_token = P(1, dim)
+        if cls:
+            self.cls_token = P(1, 1, dim)
+            self.mask_token = P(1, dim)
+        self.pos_embed = P(1, (1 if cls else 0) + native_grid * native_grid, dim)
         self.patch_embed = _NS(); self.patch_embed.proj = _NS()
         self.patch_embed.proj.weight = P(dim, 3, patch, patch, sc=1.0 / math.sqrt(3 * patch * patch))
         self.patch_embed.proj.bias = P(dim)
@@ -71,25 +90,32 @@ class DinoViT(nn.Module):
             b.attn = _NS(); b.attn.qkv = _NS(); b.attn.proj = _NS()
             b.attn.qkv.weight = P(3 * dim, dim, sc=1.0 / math.sqrt(dim)); b.attn.qkv.bias = P(3 * dim)
             b.attn.proj.weight = P(dim, dim, sc=1.0 / math.sqrt(dim)); b.attn.proj.bias = P(dim)
-            b.ls1 = _NS(); b.ls1.gamma = nn.Parameter(torch.full((dim,), 1.0, device=d), requires_grad=False)
+            if layerscale:
+                b.ls1 = _NS(); b.ls1.gamma = nn.Parameter(torch.full((dim,), 1.0, device=d), requires_grad=False)
             b.norm2 = _NS(); b.norm2.weight = nn.Parameter(torch.ones(dim, device=d), requires_grad=False); b.norm2.bias = P(dim)
             b.mlp = _NS(); b.mlp.fc1 = _NS(); b.mlp.fc2 = _NS()
             b.mlp.fc1.weight = P(4 * dim, dim, sc=1.0 / math.sqrt(dim)); b.mlp.fc1.bias = P(4 * dim)
             b.mlp.fc2.weight = P(dim, 4 * dim, sc=1.0 / math.sqrt(4 * dim)); b.mlp.fc2.bias = P(dim)
-            b.ls2 = _NS(); b.ls2.gamma = nn.Parameter(torch.full((dim,), 1.0, device=d), requires_grad=False)
+            if layerscale:
+                b.ls2 = _NS(); b.ls2.gamma = nn.Parameter(torch.full((dim,), 1.0, device=d), requires_grad=False)
             self.blocks.append(b)
         self.norm = _NS(); self.norm.weight = nn.Parameter(torch.ones(dim, device=d), requires_grad=False); self.norm.bias = P(dim)
         self._rt = None
 
     def interpolated_pos(self, gh: int, gw: int) -> torch.Tensor:
-        """[1 + gh*gw, dim] fp32: class position + bicubic resize of the native_grid^2 patch positions (DINOv2 interpolate_pos_encoding)."""
+        """[(1 +) gh*gw, dim] fp32: class position + bicubic resize of the native_grid^2 patch positions (DINOv2 interpolate_pos_encoding);
+        the native grid is used as is (SigLIP at its own 16 x 16)."""
         pe = self.pos_embed[0].float()
-        g = self.native_grid
-        patch = pe[1:].reshape(1, g, g, self.dim).permute(0, 3, 1, 2)
+        g, nc = self.native_grid, (1 if self.has_cls else 0)
+        if (gh, gw) == (g, g):
+            return pe.contiguous()
+        patch = pe[nc:].reshape(1, g, g, self.dim).permute(0, 3, 1, 2)
         patch = F.interpolate(patch, size=(gh, gw), mode="bicubic", align_corners=False)
-        return torch.cat([pe[:1], patch.permute(0, 2, 3, 1).reshape(gh * gw, self.dim)], 0).contiguous()
+        return torch.cat([pe[:nc], patch.permute(0, 2, 3, 1).reshape(gh * gw, self.dim)], 0).contiguous()
 
-    def sync(self, gh=16, gw=27, KP=608):
+    def sync(self, gh=16, gw=27, KP=None):
+        K = 3 * self.patch * self.patch
+        KP = KP or ((K + 31) // 32) * 32          # im2col rows padded to the GEMM's K granule (588 -> 608; 768 stays)
         rt = dict(gh=gh, gw=gw, KP=KP)
         w = self.patch_embed.proj.weight.reshape(self.dim, -1).float()
         wp = torch.zeros(self.dim, KP, device=w.device)
@@ -97,10 +123,11 @@ class DinoViT(nn.Module):
         rt["pe_w"] = wp.to(BF16).contiguous()
         rt["pe_b"] = self.patch_embed.proj.bias.float().contiguous()
         rt["pos"] = self.interpolated_pos(gh, gw)
-        rt["cls"] = self.cls_token.reshape(-1).float().contiguous()
+        rt["cls"] = self.cls_token.reshape(-1).float().contiguous() if self.has_cls else None
         blocks = []
+        one = torch.ones(self.dim, device=w.device)
         for b in self.blocks:   # LayerScale folded into the frozen projections: gamma * (W x + b)
-            g1, g2 = b.ls1.gamma.float(), b.ls2.gamma.float()
+            g1, g2 = (b.ls1.gamma.float(), b.ls2.gamma.float()) if self.has_ls else (one, one)
             blocks.append(dict(qkv=b.attn.qkv.weight.to(BF16).contiguous(), qkv_b=b.attn.qkv.bias.float().contiguous(),
                                proj=(g1[:, None] * b.attn.proj.weight.float()).to(BF16).contiguous(), proj_b=(g1 * b.attn.proj.bias.float()).contiguous(),
                                fc1=b.mlp.fc1.weight.to(BF16).contiguous(), fc1_b=b.mlp.fc1.bias.float().contiguous(),
@@ -109,18 +136,20 @@ class DinoViT(nn.Module):
         self._rt = rt
 
     @torch.no_grad()
-    def patch_tokens(self, frames_u8: torch.Tensor, mean=DINO_RGB_MEANS, std=DINO_RGB_STDS) -> torch.Tensor:
-        """frames_u8 [B,224,384,3] uint8 -> x_norm tokens [B, 1+432, 384] bf16 (class token first)."""
-        if self._rt is None:
-            self.sync()
-        rt = self._rt
+    def patch_tokens(self, frames_u8: torch.Tensor, mean=DINO_RGB_MEANS, std=DINO_RGB_STDS, crop_x: int = 3) -> torch.Tensor:
+        """frames_u8 [B,H,W,3] uint8 -> normed tokens [B, (1 +) gh*gw, dim] bf16 (class token first when the geometry has one).
+        The patch grid is (H // patch) x ((W - 2 crop_x) // patch): 224 x 384 -> 16 x 27 (DINOv2), 256 x 256 -> 16 x 16 (SigLIP)."""
         B, H, W, _ = frames_u8.shape
-        assert (H, W) == (224, 384), f"Expected shape is 224x384; got {(H, W)}"
-        gh, gw, KP, C = rt["gh"], rt["gw"], rt["KP"], self.dim
-        NP, S = gh * gw, gh * gw + 1
+        gh, gw = H // self.patch, (W - 2 * crop_x) // self.patch
+        if self._rt is None or (self._rt["gh"], self._rt["gw"]) != (gh, gw):
+            self.sync(gh, gw)
+        rt = self._rt
+        KP, C = rt["KP"], self.dim
+        nc = 1 if self.has_cls else 0
+        NP, S = gh * gw, gh * gw + nc
         dev = frames_u8.device
         cols = torch.empty(B * NP, KP, device=dev, dtype=BF16)
-        ops.patchify_u8(frames_u8.contiguous(), mean, std, cols, crop_x=3, P=self.patch, gh=gh, gw=gw)
+        ops.patchify_u8(frames_u8.contiguous(), mean, std, cols, crop_x=crop_x, P=self.patch, gh=gh, gw=gw)
         pt = ops.gemm_nt(cols, rt["pe_w"], B * NP, C, KP, bias=rt["pe_b"])
         x = torch.empty(B * S, C, device=dev, dtype=BF16)
         ops.vit_tokens(pt, rt["cls"], rt["pos"], B, NP, C, x)
@@ -137,30 +166,61 @@ class DinoViT(nn.Module):
         return out.view(B, S, C)
 
 
-class DinoViTPreprocessor:
-    """Raw uint8 frames -> pooled DINOv2 features.  ``process`` returns the reference's fp32 (B,384,7,12); ``process_tokens``
-    writes the storage-native bf16 tokens [B, ncam, 84, 384]."""
+class _ViTPreprocessorBase:
+    """Raw uint8 frames -> frozen ViT -> AdaptiveAvgPool2d((7, 12)).  ``process`` returns the reference's fp32 (B, C, 7, 12);
+    ``process_tokens`` writes the storage-native bf16 tokens [B, ncam, 84, C]."""
+    MEAN, STD, CROP_X, HW = DINO_RGB_MEANS, DINO_RGB_STDS, 3, (224, 384)
 
-    def __init__(self, rgb_input_uuid: str, output_uuid: str, dino_model_type: str = "dinov2_vits14", device="cuda", **kw):
-        assert dino_model_type == "dinov2_vits14", "only the shipped ViT-S/14 geometry is built"
+    def _setup(self, rgb_input_uuid, output_uuid, model_type, device, flatten):
         self.input_uuids, self.uuid, self.device = [rgb_input_uuid], output_uuid, torch.device(device)
-        self.vit = DinoViT(self.device)
-        flatten = kw.get("flatten", True)
-        self.observation_space = Box(-float("inf"), float("inf"), (7 * 12, 384) if flatten else (7, 12, 384))   # dino_preprocessors.py:55-59,90-99
+        self.vit = DinoViT(self.device, **VIT_PRESETS[model_type])
+        C = self.vit.dim
+        self.observation_space = Box(-float("inf"), float("inf"), (7 * 12, C) if flatten else (7, 12, C))
 
     def to(self, device):
         return self
 
+    def _tokens(self, fr):
+        assert tuple(fr.shape[1:3]) == self.HW, f"Expected shape is {self.HW[0]}x{self.HW[1]}; got {tuple(fr.shape[1:3])}"
+        return self.vit.patch_tokens(fr, self.MEAN, self.STD, crop_x=self.CROP_X)
+
     @torch.no_grad()
     def process(self, obs: Dict[str, torch.Tensor], *a, **k) -> torch.Tensor:
         fr = obs[self.input_uuids[0]].to(self.device)
-        x = self.vit.patch_tokens(fr)
-        B = fr.shape[0]
-        out = torch.empty(B, self.vit.dim, 7, 12, device=self.device, dtype=torch.float32)
-        ops.adaptive_pool_tokens(x, B, 1, 16, 27, self.vit.dim, 7, 12, chw_out=out)
+        x = self._tokens(fr)
+        B, v = fr.shape[0], self.vit
+        gh, gw = self._rt_grid()
+        out = torch.empty(B, v.dim, 7, 12, device=self.device, dtype=torch.float32)
+        ops.adaptive_pool_tokens(x, B, 1 if v.has_cls else 0, gh, gw, v.dim, 7, 12, chw_out=out)
         return out
+
+    def _rt_grid(self):
+        return self.vit._rt["gh"], self.vit._rt["gw"]
 
     @torch.no_grad()
     def process_tokens(self, frames_u8: torch.Tensor, out_tokens: torch.Tensor, cam: int, ncam: int = 2):
-        x = self.vit.patch_tokens(frames_u8.to(self.device))
-        ops.adaptive_pool_tokens(x, frames_u8.shape[0], 1, 16, 27, self.vit.dim, 7, 12, cam=cam, ncam=ncam, tok_out=out_tokens)
+        x = self._tokens(frames_u8.to(self.device))
+        gh, gw = self._rt_grid()
+        ops.adaptive_pool_tokens(x, frames_u8.shape[0], 1 if self.vit.has_cls else 0, gh, gw, self.vit.dim, 7, 12, cam=cam, ncam=ncam, tok_out=out_tokens)
+
+
+class DinoViTPreprocessor(_ViTPreprocessorBase):
+    """dino_preprocessors.py:38-125: 224 x 384 frames, W crop [3:-3], DINOv2 ``x_norm_patchtokens`` -> (B, C, 16, 27) -> pool (7, 12)."""
+
+    def __init__(self, rgb_input_uuid: str, output_uuid: str, dino_model_type: str = "dinov2_vits14", device="cuda", flatten: bool = True, **kw):
+        if dino_model_type == "dinov2_vitg14":
+            raise NotImplementedError("dinov2_vitg14 (SwiGLU-fused MLP, 40 blocks) is not built; ViT-S/B/L-14 are")
+        assert dino_model_type in ("dinov2_vits14", "dinov2_vitb14", "dinov2_vitl14"), dino_model_type
+        self._setup(rgb_input_uuid, output_uuid, dino_model_type, device, flatten)
+
+
+class SigLIPPreprocessor(_ViTPreprocessorBase):
+    """siglip_preprocessors.py:18-104: 256 x 256 frames, mean = std = 0.5, timm trunk ``forward_features`` (B, 256, 768) ->
+    (B, 768, 16, 16) -> AdaptiveAvgPool2d((7, 12)).  Weights come from open_clip's hub download in the reference: random-init geometry
+    here (parity pinned against the fp32 restatement of the published timm forward, oracle/ref_vit.py)."""
+    SIGLIP_RGB_MEANS, SIGLIP_RGB_STDS = (0.5, 0.5, 0.5), (0.5, 0.5, 0.5)
+    MEAN, STD, CROP_X, HW = SIGLIP_RGB_MEANS, SIGLIP_RGB_STDS, 0, (256, 256)
+
+    def __init__(self, rgb_input_uuid: str, output_uuid: str, siglip_model_type: str = "ViT-B-16-SigLIP-256", device="cuda", flatten: bool = True, **kw):
+        assert siglip_model_type in ("ViT-B-16-SigLIP-256", "ViT-L-16-SigLIP-256"), siglip_model_type
+        self._setup(rgb_input_uuid, output_uuid, siglip_model_type, device, flatten)

@@ -1,5 +1,5 @@
 """Worker of tests/test_dp_gpu.py: one data-parallel rank (torchrun) computing its environment shard's gradients on the HIP kernels
-and SUM-all-reducing the flat gradient arena, exactly like PPOLagEngine.optimizer_step does before Adam."""
+and SUM-all-reducing it tower range by tower range, asynchronously, exactly like PPOLagEngine does before Adam."""
 import os
 import sys
 
@@ -38,8 +38,12 @@ def main():
     assert n_total == T * B
     m.zero_grad()
     eng._sums.zero_()
-    eng._accumulate(st.batch_slice(s, s + n), n_total, 0.25)
-    parallel.allreduce_sum_(m.arena.flat_g)
+    # the engine's own exchange: each tower's gradient range goes to an asynchronous all-reduce right after that tower's backward
+    eng._accumulate(st.batch_slice(s, s + n), n_total, 0.25, last=True)
+    assert len(eng._pending) == 3
+    for w in eng._pending:
+        w.wait()
+    eng._pending = []
     parallel.allreduce_sum_(eng._sums)
     if rank == 0:
         torch.save({"flat_g": m.arena.flat_g.cpu(), "sums": eng._sums.cpu()}, out)

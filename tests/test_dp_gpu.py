@@ -12,12 +12,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_equal_single_process_gradient(tmp_path):
+@pytest.mark.parametrize("backend", ["gloo", "rccl"])
+def test_two_ranks_equal_single_process_gradient(tmp_path, backend):
+    """backend "gloo": two ranks share the one GPU of the test box; "rccl": one rank per GPU over RCCL ("nccl" on ROCm) -- runs wherever
+    at least two GPUs are visible (the 8-GPU scaling node), skipped on 1-GPU boxes."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    if backend == "rccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank: fewer than 2 GPUs visible")
     T, B = 5, 4
     out = str(tmp_path / "dp.pt")
-    env = dict(os.environ, SVLA_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "gloo":
+        env["SVLA_DIST_BACKEND"] = "gloo"
+    else:
+        env.pop("SVLA_DIST_BACKEND", None)
     port = 29600 + (os.getpid() % 300)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "tests", "helpers", "dp_worker.py"), out, str(T), str(B)],

@@ -58,3 +58,59 @@ def test_state_dict_has_dinov2_names(pre):
     for k in ("cls_token", "pos_embed", "patch_embed.proj.weight", "blocks.0.attn.qkv.weight", "blocks.11.ls2.gamma", "blocks.5.mlp.fc1.bias", "norm.weight"):
         assert k in names, k
     assert pre.vit.state_dict()["pos_embed"].shape == (1, 1370, 384)
+
+
+# ---- geometry-generic ViT kernels: patch 14 / 16, width 384 / 768, 433 / 256 tokens ---------------------------------
+def _perturb(vit):
+    with torch.no_grad():
+        for b in vit.blocks:
+            if vit.has_ls:
+                b.ls1.gamma.copy_(0.5 + 0.5 * torch.rand(vit.dim, device=DEV))
+                b.ls2.gamma.copy_(0.5 + 0.5 * torch.rand(vit.dim, device=DEV))
+            b.norm1.weight.copy_(1 + 0.1 * torch.randn(vit.dim, device=DEV))
+        vit.pos_embed.mul_(10.0)
+    vit._rt = None
+
+
+def test_siglip_preprocessor_vs_oracle():
+    """SigLIPPreprocessor (siglip_preprocessors.py:18-104): 256 x 256, mean = std = 0.5, ViT-B/16 trunk without class token,
+    (B,256,768) -> (B,768,16,16) -> AdaptiveAvgPool2d((7,12))."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import ref_vit
+    from safevla_amd.preproc import SigLIPPreprocessor
+
+    torch.manual_seed(1)
+    p = SigLIPPreprocessor("rgb_raw", "rgb_siglip", device=DEV)
+    assert p.observation_space.shape == (84, 768) and "cls_token" not in p.vit.state_dict() and p.vit.state_dict()["pos_embed"].shape == (1, 256, 768)
+    _perturb(p.vit)
+    fr = torch.from_numpy(np.random.RandomState(2).randint(0, 256, (2, 256, 256, 3), dtype=np.uint8))
+    sd = {k: v.detach().float().cpu() for k, v in p.vit.state_dict().items()}
+    want_tok, want_pool = ref_vit.vit_features(sd, fr, heads=12, native_grid=16, patch=16, crop_x=0, mean=(0.5,) * 3, std=(0.5,) * 3)
+    got = p.process({"rgb_raw": fr}).cpu()
+    assert got.shape == (2, 768, 7, 12) and want_tok.shape == (2, 256, 768)
+    e = (got - want_pool).abs().max().item() / want_pool.abs().max().item()
+    assert e < 4e-2, e
+    with pytest.raises(AssertionError):
+        p.process({"rgb_raw": torch.zeros(1, 224, 384, 3, dtype=torch.uint8)})       # "Expected shape is 256x256"
+
+
+def test_dinov2_base_geometry_vs_oracle():
+    """dino_model_type='dinov2_vitb14' (dino_preprocessors.py:60-64): width 768, 12 heads, same 433-token grid."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import ref_vit
+    from safevla_amd.preproc import DinoViTPreprocessor
+
+    torch.manual_seed(2)
+    p = DinoViTPreprocessor("rgb_raw", "rgb_dinov2", dino_model_type="dinov2_vitb14", device=DEV)
+    assert p.observation_space.shape == (84, 768)
+    _perturb(p.vit)
+    fr = torch.from_numpy(np.random.RandomState(3).randint(0, 256, (1, 224, 384, 3), dtype=np.uint8))
+    sd = {k: v.detach().float().cpu() for k, v in p.vit.state_dict().items()}
+    _, want_pool = ref_vit.vit_features(sd, fr, heads=12)
+    got = p.process({"rgb_raw": fr}).cpu()
+    e = (got - want_pool).abs().max().item() / want_pool.abs().max().item()
+    assert got.shape == (1, 768, 7, 12) and e < 4e-2, e
+    with pytest.raises(NotImplementedError):
+        DinoViTPreprocessor("rgb_raw", "x", dino_model_type="dinov2_vitg14", device=DEV)
