@@ -76,3 +76,42 @@ def test_agent_steps_equal_full_sequence_forward(agent):
     agent.reset()
     a1, p1 = agent.get_action(fr[0], "navigate to the red chair and pick up the cup")
     assert np.abs(p1.float().cpu().numpy() - ref[0]).max() < 2e-2 * max(ref[0].max(), 1e-3)
+
+
+def test_agent_steps_vs_the_cpu_oracle_chain(agent):
+    """Not a self-comparison: the same episode through the fp32 CPU ORACLE chain -- oracle ViT (ref_vit.vit_features) on the raw frames ->
+    oracle 3-tower policy stepped with its own KV caches (ref_model, acting branch) -- with the agent's weights.  The agent's action
+    probabilities must follow it on the bf16 ladder (frames -> 12 ViT blocks -> 3 fusion + 3 decoder layers)."""
+    from oracle import ref_loss, ref_model, ref_vit
+    from safevla_amd.text import GoalTokenizer, str_to_bytes
+
+    m = agent.actor_critic
+    rs = np.random.RandomState(2)
+    T = 3
+    fr = _frames(rs, T)
+    goal = "find a mug"
+    agent.reset()
+    probs, acts = [], []
+    for t in range(T):
+        _, p = agent.get_action(fr[t], goal)
+        probs.append(p.float().cpu().numpy()); acts.append(int(agent.last_action_flat[0]))
+    ref = ref_model.RefSafeActorCritic(GoalTokenizer(), max_batch=1).eval()
+    ref.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    vsd = {k: v.detach().float().cpu() for k, v in agent.nav_pre.vit.state_dict().items()}
+    gb = torch.from_numpy(np.asarray(str_to_bytes(goal, 1000))).reshape(1, 1, -1)
+    want = []
+    with torch.no_grad():
+        for t in range(T):
+            _, nav = ref_vit.vit_features(vsd, torch.from_numpy(fr[t]["raw_navigation_camera"])[None])
+            _, man = ref_vit.vit_features(vsd, torch.from_numpy(fr[t]["raw_manipulation_camera"])[None])
+            obs = {"rgb_dinov2": nav[None], "manipulation_rgb_dinov2": man[None], "natural_language_spec": gb,
+                   "time_step": torch.tensor([[t]]), "traj_index": torch.tensor([[agent.traj_index]]),
+                   "an_object_is_in_hand": torch.tensor([[[int(t >= 3)]]])}
+            pa = torch.tensor([[acts[t - 1] if t else 0]])
+            mk = torch.tensor([[[1.0 if t else 0.0]]])
+            out, _ = ref(obs, None, pa, mk)
+            want.append(torch.softmax(out["logits"][0, 0], -1).numpy())
+    got, want = np.stack(probs), np.stack(want)
+    err = np.abs(got - want).max() / want.max()
+    assert err < 4e-2, err
+    agent.reset()

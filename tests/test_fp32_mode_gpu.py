@@ -301,3 +301,36 @@ def test_fp32_mode_full_update_matches_the_cpu_oracle(model32):
     assert moved > 1_000_000 and agree / moved > 0.999, (moved, agree)
     model.arena.flat_p.copy_(p0)
     model.sync_weights(frozen=False)
+
+
+def test_t5_encoder_unscaled_weights_fp32_mode_vs_oracle():
+    """the bf16 T5 test scales the query projection by 0.25 to keep the (un-scaled, T5-style) softmax away from
+    saturation.  In the fp32 mode the encoder is compared with the oracle (itself pinned against transformers.T5EncoderModel) on the
+    UN-scaled name-seeded weights, padding and relative-position bias included, at fp32 tolerance; the bf16 path on the same weights is
+    bounded in the mean (saturated softmaxes turn single bf16 roundings into arg-max flips, so its max error is not a kernel property)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle.detfill import fill_state_dict
+    from oracle.ref_t5 import RefT5Encoder
+    from safevla_amd.model import T5Frozen
+
+    t5 = T5Frozen(torch.device(DEV))
+    fill_state_dict(t5, seed=11)
+    ref = RefT5Encoder().eval()
+    ref.load_state_dict({k: v.detach().cpu() for k, v in t5.state_dict().items()})
+    rs = np.random.RandomState(0)
+    ids = torch.from_numpy(rs.randint(3, 32000, size=(5, 11)))
+    am = torch.ones(5, 11, dtype=torch.int64)
+    for i, n in enumerate([11, 4, 7, 1, 9]):
+        ids[i, n:] = 0
+        am[i, n:] = 0
+    want = ref(ids, am)
+    valid = am.bool()
+    got32 = t5.encode(ids.to(DEV), am.to(DEV), dtype=torch.float32).view(5, 11, 512).cpu()
+    assert got32.dtype == torch.float32
+    e32 = (got32 - want)[valid].abs().max().item() / want[valid].abs().max().item()
+    assert e32 < 1e-4, e32
+    got16 = t5.encode(ids.to(DEV), am.to(DEV)).float().view(5, 11, 512).cpu()
+    e16 = (got16 - want)[valid].abs().mean().item() / want[valid].abs().mean().item()
+    print(f"[fp32 t5 unscaled] fp32-mode max rel err {e32:.2e}; bf16 path mean rel err {e16:.2e}")
+    assert e16 < 6e-2, e16

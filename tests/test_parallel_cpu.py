@@ -53,7 +53,11 @@ def _worker(rank, world, port, q):
     loss = _loss_sum(net, x[:, s:s + n], {k: v[:, s:s + n] for k, v in batch.items()}, 0.37, n_total)
     loss.backward()
     flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
-    parallel.allreduce_sum_(flat)
+    # the engine's exchange pattern: contiguous ranges of one flat buffer reduced asynchronously, waited for before the optimiser step
+    cut = flat.numel() // 3
+    handles = [parallel.allreduce_sum_async(flat[a:b]) for a, b in ((0, cut), (cut, 2 * cut), (2 * cut, flat.numel()))]
+    for h in handles:
+        h.wait()
     jc, n_ep = parallel.mean_episode_cost(3.0 * (rank + 1), 2.0, "cpu")
     parallel.barrier()
     if rank == 0:
