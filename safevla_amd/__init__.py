@@ -8,5 +8,7 @@ Only the hot path named by BASELINE.json's ``north_star`` lives here (SURVEY.md 
   losses.py  SafePPOLogGrad / PPOValue / SafePPOValue / HLGaussLoss mirrors
   storage.py rollout storage with reward+cost GAE
   engine.py  the PPO-Lagrangian update loop (single- and multi-GPU)
+  parallel.py / synth_env.py / api.py / lagrange.py / checkpoint.py / preproc.py / agent.py / il.py: DP plumbing, the synthetic (steppable)
+  environment, the reference's output containers, lambda, checkpoint interchange, frozen ViT preprocessors, evaluation agent, IL workload
 """
-__version__ = "0.1.0"
+__version__ = "0.2.0"
