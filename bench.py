@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_TBPS = 8.0           # HBM3E peak (MI355X_MICROARCH.md)
 
 
 def flops_per_update(R, S, L, U, epochs):
@@ -96,10 +97,13 @@ def acting_bench(model, st, B, dev, n=24):
 
     step_in = lambda t: ({k: v[t:t + 1] for k, v in st.observations.items()}, None, st.prev_actions[t:t + 1], st.masks[t:t + 1])
 
-    def policy_rate(graph):
+    def policy_rate(mode):
         for t in model.towers:
             t.time_step_counter, t._kv = 0, None
-        model.enable_acting_graphs(graph)
+        if mode is None:
+            model.enable_acting_graphs(False)
+        else:
+            model.enable_acting_graphs(True, backend=mode)
         with torch.no_grad():
             for t in range(4):
                 model(*step_in(t))
@@ -114,7 +118,8 @@ def acting_bench(model, st, B, dev, n=24):
             t.time_step_counter, t._kv = 0, None
         return r
 
-    pol_eager, pol = policy_rate(False), policy_rate(True)
+    pol_eager, pol_plan, pol = policy_rate(None), policy_rate("plan"), policy_rate("hipgraph")
+    model.enable_acting_plans(True)         # back to the default acting path
     vit = DinoViTPreprocessor("rgb_raw", "rgb_dinov2", device=dev)
     fr = torch.randint(0, 256, (2 * B, 224, 384, 3), device=dev, dtype=torch.uint8)
     vit.process({"rgb_raw": fr})
@@ -124,8 +129,9 @@ def acting_bench(model, st, B, dev, n=24):
         vit.process({"rgb_raw": fr})
     torch.cuda.synchronize()
     fps = 3 * 2 * B / (time.perf_counter() - t0)
-    best = max(pol, pol_eager)
-    return {"policy_single_step_env_steps_per_s": round(pol_eager, 1), "policy_single_step_hipgraph_env_steps_per_s": round(pol, 1),
+    best = max(pol, pol_eager, pol_plan)
+    return {"policy_single_step_env_steps_per_s": round(pol_plan, 1), "policy_single_step_eager_env_steps_per_s": round(pol_eager, 1),
+            "policy_single_step_hipgraph_env_steps_per_s": round(pol, 1),
             "vit_frames_per_s": round(fps, 1),
             "acting_env_steps_per_s": round(1.0 / (1.0 / best + 2.0 / fps), 1), "envs": B,
             "note": "per env step: 2 frames (224x384) through DINOv2 ViT-S/14 + one KV-cached 3-tower step; eager = one Python-issued launch "
@@ -386,7 +392,11 @@ def main():
                                            "share_of_update": round(v["total_s"] / (ms * 1e-3), 3)} for k, v in allk.items() if k != "gemm_nt256"},
                 "executed_mfma_tflop_per_update": round(executed / 1e12, 1),
                 "executed_mfma_tflops_sustained": round(executed / (ms * 1e-3) / 1e12, 1),
-                "executed_mfma_frac_of_peak": round(executed / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+                "executed_mfma_frac_of_peak": round(executed / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                # the other roof: this GEMM family is d = 512 wide (<= 256 FLOP/B at N = K = 512, below the 312 FLOP/B ridge of 2.5 PF / 8 TB/s),
+                # so the HBM roof binds before the MFMA one; counter traffic per launch / live launch duration
+                "hbm_view": None if traffic is None else {"achieved_TBps": round(traffic / (g["avg_ms"] * 1e-3) / 1e12, 3), "peak_TBps": PEAK_HBM_TBPS,
+                                                          "frac": round(traffic / (g["avg_ms"] * 1e-3) / 1e12 / PEAK_HBM_TBPS, 4)}}
     cpu = None
     acting = None
     ns = None

@@ -18,11 +18,12 @@ NAV, MANIP = "raw_navigation_camera", "raw_manipulation_camera"
 
 
 class RefEarlyFusion(nn.Module):
-    def __init__(self, max_length=1000, max_batch=8):
+    def __init__(self, max_length=1000, max_batch=8, n_fusion_layers=3, n_decoder_layers=3, dino_dim=384):
+        """defaults = ``small_3``; (6, 6, 384) = ``small_6``; (3, 3, 768) = ``base_3`` (early_fusion_tsfm_models.py:221-240)."""
         super().__init__()
         d = 512
-        self.visual_encoder = RefGoalEncoder(tokenizer=None)
-        self.decoder = RefLlamaDecoder(d, 3, 8, 1e-5, max_batch, max_length)
+        self.visual_encoder = RefGoalEncoder(tokenizer=None, n_layers=n_fusion_layers, dino_dim=dino_dim)
+        self.decoder = RefLlamaDecoder(d, n_decoder_layers, 8, 1e-5, max_batch, max_length)
         self.actor = nn.Linear(d, N_ACTIONS)
         self.time_encoder = RefPositionalEncoder(d)
         self.last_actions_embed = nn.Embedding(N_ACTIONS + 2, d, padding_idx=N_ACTIONS + 1)

@@ -53,8 +53,13 @@ class _Lib:
             fn.restype = ctypes.c_int
             fn.argtypes = [ct for _, ct in args]
 
+    recorder = None      # optional list: every call is appended as (bound C function, args) -- launch-replay experiments (tools/replay_probe.py)
+
     def call(self, name: str, *args):
-        rc = getattr(self.cdll, name)(*args)
+        fn = getattr(self.cdll, name)
+        if self.recorder is not None:
+            self.recorder.append((fn, args))
+        rc = fn(*args)
         if rc != 0:
             raise SvlaError(f"{name} failed with status {rc}" + (" (invalid argument)" if rc == -1 else " (hipError_t)"))
 

@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
     bf16_t* Bs = As + NS64 * 256 * BK64;           // [NS64][256][64]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 2, wn = wid & 3;
-    const int ntn = p.N / 256, MT = (p.M + 255) / 256;
+    const int ntn = (p.N + 255) / 256, MT = (p.M + 255) / 256;     // N % 128 == 0: the last n-tile may be a half tile (ViT-S widths 384 / 1152)
     const int xcd = blockIdx.x & 7, lw = blockIdx.x >> 3, lstride = gridDim.x >> 3;
     const int n_local = ((MT - xcd + 7) / 8) * ntn;
     if (lw >= n_local) return;
@@ -321,8 +321,6 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
         n0 = (li % ntn) * 256;
     };
     uint32_t offB[4], offA[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) offB[j] = (uint32_t)((srow[j] * p.ldb + schunk[j]) * 2);
     const char* a_base = nullptr;
     const char* b_base = nullptr;
     auto set_dma_tile = [&](int ti) {
@@ -333,7 +331,10 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
         a_base = (const char*)p.A + (size_t)m0d * p.lda * 2;
         b_base = (const char*)p.B + (size_t)n0d * p.ldb * 2;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) offA[j] = (uint32_t)(((min(m0d + srow[j], p.M - 1) - m0d) * p.lda + schunk[j]) * 2);
+        for (int j = 0; j < 4; ++j) {
+            offA[j] = (uint32_t)(((min(m0d + srow[j], p.M - 1) - m0d) * p.lda + schunk[j]) * 2);
+            offB[j] = (uint32_t)(((min(n0d + srow[j], p.N - 1) - n0d) * p.ldb + schunk[j]) * 2);      // half last n-tile: clamp (never stored)
+        }
     };
     int d = 0, d_kt = 0, d_tile = 0;
     set_dma_tile(0);
@@ -403,8 +404,8 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
             }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (LDS_AUX && kt == nk - 1) load_aux(0, auxrm[0], m0, n0);
-            if (HAS_BITS && kt == nk - 1) load_bits(0, mbits[0], m0, n0);
+            if (LDS_AUX && kt == nk - 1 && n0 + wn * 64 < p.N) load_aux(0, auxrm[0], m0, n0);
+            if (HAS_BITS && kt == nk - 1 && n0 + wn * 64 < p.N) load_bits(0, mbits[0], m0, n0);
             issue_next();
             const int st = g % NS64;
             const bf16_t* Ab = As + st * 256 * BK64;
@@ -439,7 +440,8 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (p.dbg & 2) {
+        const bool wave_cols_valid = n0 + wn * 64 < p.N;      // wave-uniform: a wave's 64 output columns are all inside N or all outside
+        if ((p.dbg & 2) || !wave_cols_valid) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -528,7 +530,7 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        prev_full = m0 + 256 <= p.M;
+        prev_full = (m0 + 256 <= p.M) && wave_cols_valid;      // exactly 16 stores were issued behind this wave's in-flight DMA group
     }
 }
 
@@ -580,7 +582,9 @@ extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, lon
     if (act < ACT_NONE || act > ACT_GELU) return SVLA_EINVAL;
     if ((lda % 8) || (ldb % 8) || (ldc % (out_f32 ? 4 : 8)) || (residual && (ldr % 8)) || (relu_mask && (ldm % 8))) return SVLA_EINVAL;
     GemmNtArgs p{A, lda, B, ldb, bias, residual, ldr, relu_mask, ldm, C, ldc, M, N, K, act, out_f32, alpha, relu_bits_out, relu_bits, drop_cfg(drop), g_dbg};
-    if (!out_f32 && (N % 256) == 0 && (K % BK64) == 0 && K >= 2 * BK64 && (long)((M + 255) / 256) * (N / 256) >= 256 && !g_force_small_tile) {
+    // N % 256 == 128 with N >= 384 (the ViT-S widths 384 and 1152): the last n-tile is a half tile (75 % / 90 % of the MFMA work useful) --
+    // still well ahead of the 128-tile kernel
+    if (!out_f32 && ((N % 256) == 0 || ((N % 128) == 0 && N >= 384)) && (K % BK64) == 0 && K >= 2 * BK64 && (long)((M + 255) / 256) * ((N + 255) / 256) >= 256 && !g_force_small_tile) {
         static int n_cu = 0;
         if (!n_cu) {
             int dev = 0;
@@ -589,7 +593,7 @@ extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, lon
             n_cu = (n_cu / 8) * 8;
             if (n_cu < 8) n_cu = 8;
         }
-        const int ntiles = ((M + 255) / 256) * (N / 256);
+        const int ntiles = ((M + 255) / 256) * ((N + 255) / 256);
         int grid = n_cu;                       // persistent: one 512-thread workgroup (160 KiB LDS) per CU
         while (grid > 8 && (grid / 8) * 8 > ntiles) grid -= 8;
         return launch_nt256(p, grid, (hipStream_t)stream);

@@ -504,3 +504,23 @@ extern "C" int svla_dropout_bf16(bf16_t* x, long rows, int N, const svla_dropout
     return svla_launch_status();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// llama KV-cache append of the acting path (llama/model.py:279-293: cache[:bsz, start_pos] = xk / xv): cache[b, t, :] = src[b, :] with
+// the slot t read from DEVICE memory, so that a recorded / captured single-step launch sequence is step-independent.
+__global__ void kv_append_kernel(const bf16_t* __restrict__ src, long ld_src, bf16_t* __restrict__ cache, long cache_rows, int width,
+                                 const int64_t* __restrict__ t_dev, int B) {
+    const long t = *t_dev;
+    const int cpr = width / 8;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * cpr; i += gridDim.x * blockDim.x) {
+        const int b = i / cpr, c = (i % cpr) * 8;
+        *(u32x4*)(cache + ((size_t)b * cache_rows + t) * width + c) = *(const u32x4*)(src + (size_t)b * ld_src + c);
+    }
+}
+extern "C" int svla_kv_append_bf16(const bf16_t* src, long ld_src, bf16_t* cache, long cache_rows, int width, const int64_t* t_dev, int B,
+                                   void* stream) {
+    if (B <= 0 || width <= 0 || (width % 8) || (ld_src % 8) || !t_dev) return SVLA_EINVAL;
+    int blocks = (B * (width / 8) + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(kv_append_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, cache, cache_rows, width, t_dev, B);
+    return svla_launch_status();
+}

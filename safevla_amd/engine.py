@@ -97,28 +97,28 @@ class PPOLagEngine:
         names = set(cfg.stage_losses)
         sums = self._sums
         ret_ = f(batch["returns"])
-        if "ppo_log_loss" in names:
+        discrete = m.critic_type == "discrete"
+
+        def actor_block():
             # actor: clipped surrogate on the lambda-mixed advantage (+ entropy); critic: value_loss_coef * 0.5 * mse
             logits, _, c = m.run_forward(prep, need_grad=True)
-            ret = f(batch["returns"])
-            _, dl, _ = ops.ppo_lag_loss_fwd_bwd(logits.reshape(R, N_ACTIONS), ret, f(batch["actions"]), f(batch["old_action_log_probs"]),
-                                                f(batch["adv_targ"]), f(batch["c_adv_targ"]), ret, None, lam, cfg.clip_param, 0.0,
+            _, dl, _ = ops.ppo_lag_loss_fwd_bwd(logits.reshape(R, N_ACTIONS), ret_, f(batch["actions"]), f(batch["old_action_log_probs"]),
+                                                f(batch["adv_targ"]), f(batch["c_adv_targ"]), ret_, None, lam, cfg.clip_param, 0.0,
                                                 cfg.action_weight, cfg.entropy_coef, False, inv_n, sums=sums[0:3])
             m.run_backward(prep, c, dl.view(T, Bc, N_ACTIONS), None)
-            del c, logits, dl
             if last:
                 self._reduce_tower_async(0)
-        discrete = m.critic_type == "discrete"
-        if ("ppo_log_loss" in names and not discrete) or "ppo_value_loss" in names:
+
+        def critic_block():
             coef = cfg.value_loss_coef if "ppo_log_loss" in names else 1.0
             tw = m.critic_tsfm
             _, values, c = tw.run_forward(prep, need_grad=True)
-            _, dv = ops.value_mse_fwd_bwd(values.reshape(R), f(batch["returns"]), coef, inv_n, sums=sums[0:1])
+            _, dv = ops.value_mse_fwd_bwd(values.reshape(R), ret_, coef, inv_n, sums=sums[0:1])
             tw.run_backward(prep, c, None, dv.view(T, Bc, 1))
-            del c, values, dv
             if last:
                 self._reduce_tower_async(1)
-        if "safe_ppo_value_loss" in names or ("ppo_log_loss" in names and discrete):
+
+        def c_critic_block():
             tw = m.c_critic_tsfm
             _, c_values, c = tw.run_forward(prep, need_grad=True)
             dv = dfl = None
@@ -133,9 +133,20 @@ class PPOLagEngine:
                                                 want_values=False, sums=sums[3:4])
                 dfl = dfl.view(T, Bc, -1)
             tw.run_backward(prep, c, None, dv, dfl)
-            del c, c_values, dv, dfl
             if last:
                 self._reduce_tower_async(2)
+
+        blocks = [actor_block if "ppo_log_loss" in names else None,
+                  critic_block if (("ppo_log_loss" in names and not discrete) or "ppo_value_loss" in names) else None,
+                  c_critic_block if ("safe_ppo_value_loss" in names or ("ppo_log_loss" in names and discrete)) else None]
+        if m.concurrent_towers and R * prep.S <= m.concurrent_tower_tokens:
+            # small minibatches are bound by the dispatch of ~1000 small dependent kernels: the three towers (independent given the batch)
+            # run on three HIP streams (model.run_towers_concurrently); gradients land in disjoint arena ranges, loss sums are atomics
+            m.run_towers_concurrently(lambda k, t: blocks[k]() if blocks[k] is not None else None)
+        else:
+            for blk in blocks:      # update-sized shapes: one tower at a time (only one tower's activations resident)
+                if blk is not None:
+                    blk()
 
     def optimizer_step(self, reduced: bool = False):
         """Global-norm clip + Adam over the ranges of the towers that received a gradient.  ``reduced``: the per-tower asynchronous

@@ -43,14 +43,19 @@ class _CEFn(torch.autograd.Function):
 
 
 class EarlyFusionCnnTransformer(Tower):
+    # model_version -> (fusion layers, decoder layers, image-feature width); early_fusion_tsfm_models.py:221-240.  All at d = 512 with the
+    # llama decoder and the t5-small text encoder.  The 768-wide transformers (base_6, siglip_base_*_6 ...), the SigLIP text encoder variants,
+    # the nonTx encoders and clip_resnet_50_3 are not built.
+    VERSIONS = {"small": (3, 3, 384), "small_3": (3, 3, 384), "small_6": (6, 6, 384), "base_3": (3, 3, 768)}
+
     def __init__(self, device="cuda", max_length: int = 1000, input_sensors=(NAV, MANIP, "last_actions", "an_object_is_in_hand"),
-                 image_preprocessor=None):
+                 image_preprocessor=None, n_fusion_layers: int = 3, n_decoder_layers: int = 3, dino_dim: int = DINO):
         if not torch.cuda.is_available():
             raise RuntimeError("safevla_amd needs an MI355X: there is no CPU or eager fallback for the policy kernels")
         ops.lib()
         arena = _Arena()
         device = torch.device(device)
-        super().__init__(arena, device, max_steps=max_length)
+        super().__init__(arena, device, n_fusion_layers=n_fusion_layers, n_decoder_layers=n_decoder_layers, max_steps=max_length, dino_dim=dino_dim)
         arena.build(device)
         self.bind()
         self.towers = [self]
@@ -106,17 +111,17 @@ class EarlyFusionCnnTransformer(Tower):
         R = T * B
         p = Prep()
         p.T, p.B, p.R = T, B, R
-        p.tokens = torch.empty(R, 2, NPATCH, DINO, device=dev, dtype=BF16)
+        p.tokens = torch.empty(R, 2, NPATCH, self.dino_dim, device=dev, dtype=BF16)
         for cam, key in enumerate((NAV, MANIP)):
             x = batch[key].to(dev)
             if x.dtype == torch.uint8:                           # raw frames [B,T,H,W,3] -> frozen ViT
                 if self.image_preprocessor is None:
                     from .preproc import DinoViTPreprocessor
-                    self.image_preprocessor = DinoViTPreprocessor(key, key, device=dev)
+                    self.image_preprocessor = DinoViTPreprocessor(key, key, dino_model_type={384: "dinov2_vits14", 768: "dinov2_vitb14", 1024: "dinov2_vitl14"}[self.dino_dim], device=dev)
                 fr = x.transpose(0, 1).reshape(R, *x.shape[2:]).contiguous()
                 self.image_preprocessor.process_tokens(fr, p.tokens, cam)
             else:                                                # pre-encoded features [B,T,384,7,12]
-                ops.feat_to_tokens(x.transpose(0, 1).reshape(R, DINO, NPATCH).contiguous().float(), p.tokens, cam)
+                ops.feat_to_tokens(x.transpose(0, 1).reshape(R, self.dino_dim, NPATCH).contiguous().float(), p.tokens, cam)
         tb = lambda v: v.to(dev).transpose(0, 1).reshape(R).contiguous()     # [B,T] -> rows (t*B + b)
         la = tb(batch["last_actions"]).to(torch.int64)
         p.prev_actions = la
@@ -146,9 +151,11 @@ class EarlyFusionCnnTransformer(Tower):
     @classmethod
     def build_model(cls, model_version="small_3", input_sensors=(NAV, MANIP, "last_actions", "an_object_is_in_hand"), loss="action",
                     device="cuda", ckpt_pth: Optional[str] = None, ckpt_prefix: str = "model."):
-        if model_version not in ("small", "small_3"):
-            raise NotImplementedError("only the shipped DINOv2-S / t5-small / 3+3-layer geometry is built (early_fusion_tsfm_models.py:221-226)")
-        m = cls(device=device, input_sensors=input_sensors)
+        if model_version not in cls.VERSIONS:
+            raise NotImplementedError(f"model_version {model_version!r}: built are {sorted(cls.VERSIONS)} (DINOv2-S/B features, t5-small text, d = 512 "
+                                      "fusion + llama decoder; early_fusion_tsfm_models.py:221-240)")
+        nf, nd, dd = cls.VERSIONS[model_version]
+        m = cls(device=device, input_sensors=input_sensors, n_fusion_layers=nf, n_decoder_layers=nd, dino_dim=dd)
         if ckpt_pth is not None:    # Lightning checkpoint (training/offline/train_utils.py:6-68)
             sd = torch.load(ckpt_pth, map_location="cpu")["state_dict"]
             m.load_state_dict({k[len(ckpt_prefix):]: v for k, v in sd.items() if k.startswith(ckpt_prefix)}, strict=False)

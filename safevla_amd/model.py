@@ -125,8 +125,9 @@ class Tower(nn.Module):
     """``DinoLLAMATxNavActorCritic`` (full-sensor configuration of dinov2_vits_tsfm_base.py:234-270)."""
 
     def __init__(self, arena: _Arena, device, n_fusion_layers=3, n_decoder_layers=3, max_steps=500, critic_type="linear",
-                 precision="bf16"):
+                 precision="bf16", dino_dim=DINO):
         super().__init__()
+        self.dino_dim = dino_dim          # channel width of the frozen image features: 384 (ViT-S/14), 768 (ViT-B/14, SigLIP-B), 1024 (ViT-L)
         if precision not in ("bf16", "fp32"):
             raise ValueError(f"precision must be 'bf16' (MFMA product path) or 'fp32' (verification mode), got {precision!r}")
         # activation / GEMM-operand dtype.  "fp32" = the verification mode: the same schedule on the fp32 twins of every kernel
@@ -156,7 +157,7 @@ class Tower(nn.Module):
         dec(ve.text_adapter[0], "weight", (D, 512), "lin"); dec(ve.text_adapter[0], "bias", (D,), "zeros")
         dec(ve.text_adapter[1], "weight", (D,), "ones"); dec(ve.text_adapter[1], "bias", (D,), "zeros")
         ve.visual_compressor = _seq(4)
-        dec(ve.visual_compressor[0], "weight", (D, DINO, 1, 1), "lin"); dec(ve.visual_compressor[0], "bias", (D,), "zeros")
+        dec(ve.visual_compressor[0], "weight", (D, dino_dim, 1, 1), "lin"); dec(ve.visual_compressor[0], "bias", (D,), "zeros")
         dec(ve.visual_compressor[2], "weight", (D, D, 1, 1), "lin"); dec(ve.visual_compressor[2], "bias", (D,), "zeros")
         ve.visual_adapter = _seq(3)
         dec(ve.visual_adapter[0], "weight", (D, D), "lin"); dec(ve.visual_adapter[0], "bias", (D,), "zeros")
@@ -219,7 +220,7 @@ class Tower(nn.Module):
     def _gemm_weights(self):
         """(key, parameter(s), [N, K]) for every MFMA GEMM weight of the tower."""
         ve = self.visual_encoder
-        out = [("c1", [ve.visual_compressor[0].weight], (D, DINO)), ("c2", [ve.visual_compressor[2].weight], (D, D)),
+        out = [("c1", [ve.visual_compressor[0].weight], (D, self.dino_dim)), ("c2", [ve.visual_compressor[2].weight], (D, D)),
                ("va", [ve.visual_adapter[0].weight], (D, D)), ("ta", [ve.text_adapter[0].weight], (D, 512))]
         for i, l in enumerate(ve.fusion_xformer.layers):
             out += [(f"f{i}.in", [l.self_attn.in_proj_weight], (3 * D, D)), (f"f{i}.out", [l.self_attn.out_proj.weight], (D, D)),
@@ -273,12 +274,14 @@ class Tower(nn.Module):
     # ---- acting path state (llama KV caches, llama/model.py:224-247; counter semantics allenact_dino_transformer.py:376-406)
     def _ensure_caches(self, B: int):
         if getattr(self, "_kv", None) is None or self._kv[0].shape[0] < B:
+            self._kv_version = getattr(self, "_kv_version", 0) + 1        # recorded steps hold pointers into the caches: new caches, new plans
             self._kv = [torch.zeros(B, self.max_steps, 2 * D, device=self.device_, dtype=self.adt) for _ in self.decoder.layers]
 
     def cache_select(self, keep: list):
         if getattr(self, "_kv", None) is not None:
             idx = torch.as_tensor(keep, device=self.device_, dtype=torch.long)
             self._kv = [c[idx].contiguous() for c in self._kv]
+            self._kv_version = getattr(self, "_kv_version", 0) + 1
 
     def run_forward(self, prep: "Prep", need_grad: bool):
         T, B, R, S, L, U = prep.T, prep.B, prep.R, prep.S, prep.L, prep.U
@@ -288,8 +291,8 @@ class Tower(nn.Module):
         M2, M = R * 2 * NPATCH, R * S
         c = {}  # saved activations
         c["drop_seed"], site = self._drop_sites()
-        tok = prep.tokens.view(M2, DINO)
-        c1 = ops.gemm_nt(tok, w["c1"], M2, D, DINO, bias=ve.visual_compressor[0].bias, act=ops.ACT_RELU)
+        tok = prep.tokens.view(M2, self.dino_dim)
+        c1 = ops.gemm_nt(tok, w["c1"], M2, D, self.dino_dim, bias=ve.visual_compressor[0].bias, act=ops.ACT_RELU)
         c2 = ops.gemm_nt(c1, w["c2"], M2, D, D, bias=ve.visual_compressor[2].bias, act=ops.ACT_RELU)
         a1 = ops.gemm_nt(c2, w["va"], M2, D, D, bias=ve.visual_adapter[0].bias)
         x = torch.empty(R, S, D, device=self.device_, dtype=self.adt)
@@ -300,7 +303,8 @@ class Tower(nn.Module):
         if t5_seed is None and key is not None and getattr(self, "_t5_cache", (None, None))[0] == key:
             t5 = self._t5_cache[1]     # eval mode: the frozen encoder is a pure function of the goal tokens (one episode = one goal)
         else:
-            t5 = ve.text_encoder.encode(prep.ids, prep.attn_mask, drop_seed=t5_seed, drop_p=self.dropout_p, dtype=self.adt)   # [U*L, 512], frozen
+            t5 = ve.text_encoder.encode(prep.ids, getattr(prep, "attn_mask_u8", None) if getattr(prep, "attn_mask_u8", None) is not None else prep.attn_mask,
+                                        drop_seed=t5_seed, drop_p=self.dropout_p, dtype=self.adt)   # [U*L, 512], frozen
             self._t5_cache = (key, t5) if (t5_seed is None and key is not None) else (None, None)
         ta = ops.gemm_nt(t5, w["ta"], U * L, D, 512, bias=ve.text_adapter[0].bias)
         tf, ta_mean, ta_rstd = ops.norm_fwd(ta, ve.text_adapter[1].weight, ve.text_adapter[1].bias, 1e-5, U * L, relu=True)
@@ -358,10 +362,12 @@ class Tower(nn.Module):
                 kvalid = (torch.arange(t + 1, device=self.device_)[None, :] >= start[:, None]).to(torch.uint8).contiguous()
                 S_att = t + 1
             else:
-                # captured-graph form: the step counter lives in device memory, so every kernel argument is step-independent --
+                # captured / recorded form: the step counter lives in device memory, so every kernel argument is step-independent --
                 # attention runs over the whole cache window and the mask hides the slots beyond the counter
-                ar = self._ar_steps
-                kvalid = ((ar[None, :] <= t_dev) & (ar[None, :] >= torch.clamp(t_dev - prep.time_step, min=0)[:, None])).to(torch.uint8).contiguous()
+                kvalid = getattr(prep, "kvalid_static", None)        # shared by the three towers (a function of the step and time_step only)
+                if kvalid is None:
+                    ar = self._ar_steps
+                    kvalid = ((ar[None, :] <= t_dev) & (ar[None, :] >= torch.clamp(t_dev - prep.time_step, min=0)[:, None])).to(torch.uint8).contiguous()
                 S_att = self.max_steps
             for i, l in enumerate(self.decoder.layers):
                 n1, _, _ = ops.norm_fwd(xd, l.attention_norm.weight, None, 1e-5, B, rms=True, save_stats=False)
@@ -369,6 +375,8 @@ class Tower(nn.Module):
                 cache = self._kv[i]
                 if t_dev is None:
                     cache[:B, t].copy_(qkv[:, D:])
+                elif self.adt == BF16:
+                    ops.kv_append(qkv[:, D:], 3 * D, cache, t_dev, B, 2 * D)
                 else:
                     cache[:B].index_copy_(1, t_dev.view(1), qkv[:, D:].unsqueeze(1))
                 cv = cache.view(-1, 2 * D)
@@ -583,7 +591,7 @@ class Tower(nn.Module):
         dc2 = ops.gemm_nt(da1, wt["va"], M2, D, D, relu_mask=c["c2"])
         ops.gemm_tn_acc(dc2, c["c1"], dw["c2"], M2, D, D, db=g(ve.visual_compressor[2].bias))
         dc1 = ops.gemm_nt(dc2, wt["c2"], M2, D, D, relu_mask=c["c1"])
-        ops.gemm_tn_acc(dc1, prep.tokens.view(M2, DINO), dw["c1"], M2, D, DINO, db=g(ve.visual_compressor[0].bias))
+        ops.gemm_tn_acc(dc1, prep.tokens.view(M2, self.dino_dim), dw["c1"], M2, D, self.dino_dim, db=g(ve.visual_compressor[0].bias))
 
 
 # ================================================================================================ frozen T5
@@ -666,7 +674,7 @@ class T5Frozen(nn.Module):
         x = ops.embed_gather(self.shared.weight, ids.reshape(-1).contiguous(), dtype=dtype)
         ops.dropout_(x, site(62))
         bias = self.position_bias(L)
-        kvalid = attn_mask.to(torch.uint8).contiguous()
+        kvalid = attn_mask if attn_mask.dtype == torch.uint8 else attn_mask.to(torch.uint8).contiguous()   # uint8 given: no torch op (recorded steps)
         for i, (b, rt) in enumerate(zip(self.encoder.block, self._rt)):
             s0 = self.T5_STREAM + 4 * i
             nrm, _, _ = ops.norm_fwd(x, b.layer[0].layer_norm.weight, None, 1e-6, n, rms=True, save_stats=False)
@@ -736,6 +744,13 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
         self.uuids = dict(goal=goal_sensor_uuid, nav=rgb_dino_preprocessor_uuid, manip=manipulation_rgb_dino_preprocessor_uuid,
                           hand=an_object_is_in_hand_uuid, time=time_step_uuid, traj=traj_idx_uuid)
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
+        # small shapes (acting steps, small-batch updates): towers on concurrent streams; SVLA_SERIAL_TOWERS=1 turns it off
+        import os as _os
+        self.concurrent_towers = _os.environ.get("SVLA_SERIAL_TOWERS", "0") != "1"
+        self.concurrent_tower_tokens = 1 << 17          # rows x fusion tokens up to which the towers run concurrently
+        self._acting_graphs, self._acting_backend = None, "plan"
+        if self.concurrent_towers and precision == "bf16" and _os.environ.get("SVLA_NO_ACTING_PLANS", "0") != "1":
+            self.enable_acting_plans(True)              # recorded single-step launches are the default acting path
         self._goal_cache: Dict[int, List[int]] = {}
         self.sync_weights()
 
@@ -781,11 +796,11 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
         p = Prep()
         p.T, p.B, p.R = T, B, R
         if "dino_tokens" in observations:       # storage-native layout [T,B,2,84,384] bf16
-            p.tokens = observations["dino_tokens"].reshape(R, 2, NPATCH, DINO).to(self.adt).contiguous()
+            p.tokens = observations["dino_tokens"].reshape(R, 2, NPATCH, self.dino_dim).to(self.adt).contiguous()
         else:
-            p.tokens = torch.empty(R, 2, NPATCH, DINO, device=dev, dtype=self.adt)
-            ops.feat_to_tokens(observations[u["nav"]].reshape(R, DINO, NPATCH).contiguous(), p.tokens, 0)
-            ops.feat_to_tokens(observations[u["manip"]].reshape(R, DINO, NPATCH).contiguous(), p.tokens, 1)
+            p.tokens = torch.empty(R, 2, NPATCH, self.dino_dim, device=dev, dtype=self.adt)
+            ops.feat_to_tokens(observations[u["nav"]].reshape(R, self.dino_dim, NPATCH).contiguous(), p.tokens, 0)
+            ops.feat_to_tokens(observations[u["manip"]].reshape(R, self.dino_dim, NPATCH).contiguous(), p.tokens, 1)
         p.prev_actions = prev_actions.reshape(R).contiguous()
         p.masks = masks.reshape(R).to(F32).contiguous()
         p.hand = observations[u["hand"]].reshape(R).contiguous()
@@ -827,23 +842,63 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
         p.S = TEXT_OFF + p.L
         return p
 
+    # ---- small shapes: the three (independent) towers on three HIP streams ------------------------------------------------------
+    def run_towers_concurrently(self, fn):
+        """``[fn(k, tower) for k, tower in enumerate(towers)]`` with tower k issued on its own HIP stream.
+
+        Measured (tools/replay_probe.py): a single-step acting forward is 313 kernels in 4.3 ms whether it is issued eagerly from Python or
+        replayed from a pre-bound call list -- it is bound by the GPU-side dispatch of ~100 tiny DEPENDENT kernels per tower (~14 us each),
+        not by host issue.  The towers share no intermediate, so running them on three streams overlaps three dependency chains; at
+        update-sized shapes (every kernel fills the chip, activations of one tower are tens of GB) the towers stay sequential.
+        Inputs were produced on the current stream (side streams wait for it), outputs are handed back to it (it waits for the side
+        streams; returned tensors are ``record_stream``-ed so the caching allocator does not recycle them early)."""
+        main = torch.cuda.current_stream()
+        if getattr(self, "_tower_streams", None) is None:
+            self._tower_streams = [torch.cuda.Stream(device=self.device_) for _ in self.towers]
+        outs = []
+        for k, (t, s) in enumerate(zip(self.towers, self._tower_streams)):
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                outs.append(fn(k, t))
+        for s in self._tower_streams:
+            main.wait_stream(s)
+
+        def _rec(o):
+            if isinstance(o, torch.Tensor):
+                o.record_stream(main)
+            elif isinstance(o, (tuple, list)):
+                for x in o:
+                    _rec(x)
+        _rec(outs)
+        return outs
+
     # ---- captured acting step -------------------------------------------------------------------------------------------
-    def enable_acting_graphs(self, on: bool = True):
-        """Single-step (acting) forwards are bound by kernel-launch issue from Python (~190 launches, ~4 ms at 32 envs for ~1.5 ms of
-        GPU work).  With this switch the three-tower step is captured once per (envs, goal length) as a HIP graph and replayed:
-        the step counter, the KV-cache write slot and the dropout seeds live in device memory, the observation tensors are copied
-        into static buffers.  Same kernels, same arithmetic (attention runs over the whole cache window behind the mask)."""
+    def enable_acting_graphs(self, on: bool = True, backend: str = "hipgraph"):
+        """Single-step (acting) forwards are ~100 small dependent kernels per tower.  With this switch the three-tower step is made
+        step-independent -- step counter, KV-cache write slot and dropout seeds in device memory, observations copied into static buffers,
+        attention over the whole cache window behind the mask (same kernels, same arithmetic) -- and then either
+          backend="plan"     recorded once per (envs, goal length) as three ``ops.LaunchPlan``s (one per tower, each on its own HIP stream)
+                             and re-issued from a tight loop: the DEFAULT acting path (``enable_acting_plans``), or
+          backend="hipgraph" captured as a HIP graph and replayed: measured slower than eager issue on this ROCm stack, kept opt-in."""
+        assert backend in ("plan", "hipgraph")
         self._acting_graphs = {} if on else None
+        self._acting_backend = backend
+
+    def enable_acting_plans(self, on: bool = True):
+        self.enable_acting_graphs(on, backend="plan")
 
     def _acting_step_graph(self, prep: Prep):
         B, L = prep.B, prep.L
-        key = (B, L, self.training)
+        plan_mode = self._acting_backend == "plan"
+        for t in self.towers:
+            t._ensure_caches(B)
+        key = (B, L, self.training, self._acting_backend, tuple(getattr(t, "_kv_version", 0) for t in self.towers))
         st = self._acting_graphs.get(key)
         dev = self.device_
         if st is None:
             st = Prep()
             st.T, st.B, st.R, st.U, st.L, st.S = 1, B, B, B, L, TEXT_OFF + L
-            st.tokens = torch.zeros(B, 2, NPATCH, DINO, device=dev, dtype=self.adt)
+            st.tokens = torch.zeros(B, 2, NPATCH, self.dino_dim, device=dev, dtype=self.adt)
             st.prev_actions = torch.zeros(B, device=dev, dtype=torch.int64)
             st.masks = torch.zeros(B, device=dev, dtype=F32)
             st.hand = torch.zeros(B, device=dev, dtype=torch.int64)
@@ -853,7 +908,10 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
             st.attn_mask = torch.ones(B, L, device=dev, dtype=torch.int64)
             st.gid = torch.arange(B, device=dev, dtype=torch.int32)
             st.t_dev = torch.zeros((), device=dev, dtype=torch.int64)
-            st.graph = None
+            st.attn_mask_u8 = torch.ones(B, L, device=dev, dtype=torch.uint8)
+            st.kvalid_static = torch.zeros(B, self.max_steps, device=dev, dtype=torch.uint8) if plan_mode else None
+            st.ar_steps = torch.arange(self.max_steps, device=dev)
+            st.graph = st.plans = None
             for k, t in enumerate(self.towers):
                 t._ensure_caches(B)
                 t._ar_steps = torch.arange(t.max_steps, device=dev)
@@ -864,7 +922,43 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
         st.tokens.copy_(prep.tokens); st.prev_actions.copy_(prep.prev_actions); st.masks.copy_(prep.masks); st.hand.copy_(prep.hand)
         st.time_step.copy_(prep.time_step)
         st.ids.copy_(prep.ids[prep.gid.long()]); st.attn_mask.copy_(prep.attn_mask[prep.gid.long()])
+        st.attn_mask_u8.copy_(st.attn_mask)
         st.t_dev.fill_(self.time_step_counter)
+        if plan_mode:
+            # recorded step: every tower attends to cache slots [max(t - time_step_b, 0), t] (allenact_dino_transformer.py:388-397), computed once
+            tc, ar = self.time_step_counter, st.ar_steps
+            st.kvalid_static.copy_((ar[None, :] <= tc) & (ar[None, :] >= torch.clamp(tc - st.time_step, min=0)[:, None]))
+            if st.plans is None:
+                for t in self.towers:
+                    t._ensure_caches(B)
+                versions = tuple(getattr(t, "_kv_version", 0) for t in self.towers)
+
+                def rec(k, t):
+                    plan = ops.LaunchPlan()
+                    t._t_dev, t._seed_dev = st.t_dev, t._seed_dev_buf
+                    keep = t.time_step_counter
+                    with plan:
+                        lg, vl, _ = t.run_forward(st, need_grad=False)
+                    t.time_step_counter = keep
+                    t._t_dev, t._seed_dev = None, None
+                    return plan, lg, vl
+                for t in self.towers:
+                    t._seed_dev_buf.add_(0x3C6EF35)
+                res = self.run_towers_concurrently(rec)          # the recording pass is a real step
+                assert versions == tuple(getattr(t, "_kv_version", 0) for t in self.towers)
+                st.plans, st.outs = [r[0] for r in res], [(r[1], r[2]) for r in res]
+            else:
+                main = torch.cuda.current_stream()
+                for t in self.towers:
+                    t._seed_dev_buf.add_(0x3C6EF35)              # fresh dropout noise per step (device-resident seed, wraps in int32)
+                for plan, s_ in zip(st.plans, self._tower_streams):
+                    s_.wait_stream(main)
+                    plan.replay()
+                for s_ in self._tower_streams:
+                    main.wait_stream(s_)
+            for t in self.towers:
+                t.time_step_counter += 1
+            return st.outs[0][0].clone(), st.outs[1][1].clone(), st.outs[2][1].clone()
 
         def body():
             outs = []
@@ -901,6 +995,11 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
             return SafeActorCriticOutput(distributions=CategoricalDistr(logits), values=values, c_values=c_values, extras={}), memory
         if prep.T == 1 and torch.is_grad_enabled():
             raise RuntimeError("single-step (acting) forwards run under torch.no_grad(), as in the reference's rollout collection")
+        if not torch.is_grad_enabled() and self.concurrent_towers and prep.R * prep.S <= self.concurrent_tower_tokens:
+            (logits, _), (_, values), (_, c_values) = self.run_towers_concurrently(lambda k, t: t.run_forward(prep, need_grad=False)[:2])
+            c_full = self.c_critic_tsfm._last_full_logits
+            extras = self._extras(c_values, c_full) if prep.T > 1 else {}
+            return SafeActorCriticOutput(distributions=CategoricalDistr(logits), values=values, c_values=c_values, extras=extras), memory
         logits, _, _ = _TowerFn.apply(self._anchor, self, prep, True, False)
         _, values, _ = _TowerFn.apply(self._anchor, self.critic_tsfm, prep, False, True)
         _, c_values, c_full = _TowerFn.apply(self._anchor, self.c_critic_tsfm, prep, False, True)

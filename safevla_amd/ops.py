@@ -14,8 +14,45 @@ MASK_NONE, MASK_BLOCK_CAUSAL = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 
 
+class LaunchPlan:
+    """A recorded sequence of C-ABI calls (bound function + fully converted arguments, stream handle included) that can be re-issued from
+    one tight loop: no tensor allocation, no wrapper code, no argument conversion.  Everything a recorded call touched -- tensors, dropout
+    descriptors -- is kept alive by the plan, so the recorded device pointers stay valid; step-dependent state must live in device memory
+    (svla_dropout.seed_dev, the KV-cache slot of svla_kv_append_bf16).  Used for the single-step acting forward, which is ~100 small
+    dependent kernels per tower: issuing them through the Python wrappers costs ~14 us per launch, replaying them ~6.5 us
+    (tools/replay_probe.py).  HIP graphs, the textbook tool, replay slower than eager issue on this stack."""
+
+    def __init__(self):
+        self.calls, self.keep = [], []
+
+    def __enter__(self):
+        global _REC
+        assert _REC is None and lib().recorder is None, "launch recording is not re-entrant"
+        _REC = self
+        lib().recorder = self.calls
+        return self
+
+    def __exit__(self, *exc):
+        global _REC
+        _REC = None
+        lib().recorder = None
+
+    def replay(self):
+        for fn, a in self.calls:
+            rc = fn(*a)
+            if rc != 0:
+                raise RuntimeError(f"replayed {fn.__name__} failed with status {rc}")
+
+
+_REC: Optional["LaunchPlan"] = None
+
+
 def _p(t: Optional[torch.Tensor]):
-    return None if t is None else t.data_ptr()
+    if t is None:
+        return None
+    if _REC is not None:
+        _REC.keep.append(t)
+    return t.data_ptr()
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -176,7 +213,11 @@ class Dropout:
 
 
 def _d(drop):
-    return None if drop is None or drop.c.p <= 0 else ctypes.cast(ctypes.pointer(drop.c), ctypes.c_void_p)
+    if drop is None or drop.c.p <= 0:
+        return None
+    if _REC is not None:
+        _REC.keep.append(drop)
+    return ctypes.cast(ctypes.pointer(drop.c), ctypes.c_void_p)
 
 
 def dropout_(x, drop):
@@ -305,6 +346,12 @@ def decoder_embed_bwd(dout, prev_actions, masks, hand, T, B, dxf, dxf_row_stride
 
 def rows_add(dst, dst_ld, src, src_ld, rows):
     lib().call("svla_rows_add_f32" if dst.dtype == F32 else "svla_rows_add_bf16", _p(dst), dst_ld, _p(src), src_ld, rows, 512, _stream())
+
+
+def kv_append(src, ld_src, cache, t_dev, B, width):
+    """cache[b, *t_dev, :width] = src[b, :width] (cache: [rows, max_steps, width] bf16; t_dev: 0-d int64 device tensor)."""
+    _chk(cache, BF16, "cache")
+    lib().call("svla_kv_append_bf16", _p(src), int(ld_src), _p(cache), int(cache.shape[1]), int(width), _p(t_dev), int(B), _stream())
 
 
 def swiglu_fwd(ab, M, Hd, out=None):

@@ -415,3 +415,88 @@ def test_sentencepiece_goal_path_on_the_gpu(ops, tmp_path):
         aco, _ = m(obs, None, pa, mk)
     lg = aco.distributions.logits
     assert torch.equal(lg[:, 0], lg[:, 2]) and not torch.equal(lg[:, 0], lg[:, 1])
+
+
+@pytest.mark.parametrize("N,K,epi", [(384, 384, "res"), (1152, 384, "plain"), (384, 1536, "gelu_res")])
+def test_gemm_nt_256_tile_with_half_last_n_tile(ops, N, K, epi):
+    """ViT-S widths (384, 1152 = N % 256 == 128): the persistent 256-tile kernel with a half last n-tile == the 128-tile kernel == torch."""
+    M = 128 * 433 + 77
+    A = rnd(M, K, seed=1).to(torch.bfloat16)
+    W = (rnd(N, K, seed=2) / math.sqrt(K)).to(torch.bfloat16)
+    bias = rnd(N, seed=3)
+    res = rnd(M, N, seed=4).to(torch.bfloat16)
+    kw = dict(bias=bias.to(DEV))
+    if "res" in epi:
+        kw["residual"] = res.to(DEV)
+    if "gelu" in epi:
+        kw["act"] = ops.ACT_GELU
+    big = ops.gemm_nt(A.to(DEV), W.to(DEV), M, N, K, **kw)
+    ops.gemm_force_small_tile(True)
+    try:
+        small = ops.gemm_nt(A.to(DEV), W.to(DEV), M, N, K, **kw)
+    finally:
+        ops.gemm_force_small_tile(False)
+    y = A.float() @ W.float().t() + bias
+    if "gelu" in epi:
+        y = F.gelu(y)
+    if "res" in epi:
+        y = y + res.float()
+    err = (big.float().cpu() - y).abs().max().item() / y.abs().max().item()
+    assert err < 1e-2, err
+    assert (big.float() - small.float()).abs().max().item() <= 2e-2 * y.abs().max().item()
+
+
+def test_recorded_acting_step_equals_eager_acting(ops):
+    """The default acting path: the single-step 3-tower forward recorded once as three ops.LaunchPlans (one per tower / HIP stream; step
+    counter, KV slot and dropout seed in device memory, attention over the whole cache window behind the mask) must reproduce the eager
+    acting path step for step across an episode boundary, survive sampler_select (new caches => new plans) and draw fresh noise in train mode."""
+    from oracle.detfill import fill_state_dict
+    from safevla_amd.model import SafeDinoLLAMATxNavActorCriticSeparate
+
+    g = dict(np.load(os.path.join(G, "g5_samelen.npz"), allow_pickle=False))
+    obs = {k[4:]: torch.from_numpy(v).to(DEV) for k, v in g.items() if k.startswith("obs:")}
+    pa, mk = torch.from_numpy(g["prev_actions"]).to(DEV), torch.from_numpy(g["masks"]).to(DEV)
+    T = pa.shape[0]
+    m = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV)
+    assert m._acting_graphs is not None and m._acting_backend == "plan"          # on by default
+    fill_state_dict(m, seed=7)
+    m.sync_weights()
+    m.eval()
+
+    def run(plans):
+        for t in m.towers:
+            t.time_step_counter, t._kv = 0, None
+        m.enable_acting_plans(plans)
+        out = []
+        with torch.no_grad():
+            for t in range(T):
+                o, _ = m({k: v[t:t + 1] for k, v in obs.items()}, None, pa[t:t + 1], mk[t:t + 1])
+                out.append((o.distributions.logits.float().cpu(), o.values.cpu(), o.c_values.cpu()))
+        return out
+
+    eager, plan = run(False), run(True)
+    assert len(next(iter(m._acting_graphs.values())).plans) == 3
+    for t, (a, b) in enumerate(zip(eager, plan)):
+        for x, y in zip(a, b):
+            assert torch.allclose(x, y, rtol=0, atol=2e-2 * max(1.0, x.abs().max().item())), (t, (x - y).abs().max())
+    assert all(t.time_step_counter == T for t in m.towers)
+    # and against the reference's own step-by-step outputs
+    ga = dict(np.load(os.path.join(G, "g5_acting.npz"), allow_pickle=False))
+    relm = lambda a, b: np.abs(a - b).max() / (np.abs(b).max() + 1e-12)
+    assert relm(torch.cat([p[0] for p in plan]).numpy(), ga["logits"]) < 3e-2
+    assert relm(torch.cat([p[1] for p in plan]).numpy(), ga["values"]) < 3e-2 and relm(torch.cat([p[2] for p in plan]).numpy(), ga["c_values"]) < 3e-2
+    # sampler_select keeps rows -> new caches -> new plans; the step still runs
+    m.sampler_select([0, 2])
+    with torch.no_grad():
+        o, _ = m({k: v[0:1, [0, 2]] for k, v in obs.items()}, None, pa[0:1, [0, 2]], mk[0:1, [0, 2]])
+    assert o.values.shape == (1, 2, 1) and torch.isfinite(o.distributions.logits).all()
+    # train mode: device-resident seed advances per step -> same inputs, different outputs
+    m.train()
+    for t in m.towers:
+        t.time_step_counter, t._kv = 0, None
+    with torch.no_grad():
+        a, _ = m({k: v[0:1] for k, v in obs.items()}, None, pa[0:1], mk[0:1])
+        for t in m.towers:
+            t.time_step_counter = 0
+        b, _ = m({k: v[0:1] for k, v in obs.items()}, None, pa[0:1], mk[0:1])
+    assert (a.values - b.values).abs().max() > 1e-3 and torch.isfinite(b.values).all()
