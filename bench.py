@@ -153,7 +153,7 @@ def north_star_probe(model, dev, rows_T=32, rows_B=8, L=64):
 
     def once():
         model.zero_grad()
-        eng._accumulate(batch, R, 0.1)
+        eng._accumulate(batch, R, 0.1, cache_key="probe")     # like the epochs of one update: the first pass records, the others replay
 
     once()
     torch.cuda.synchronize()

@@ -155,6 +155,9 @@ int svla_decoder_embed_bwd(const svla_bf16* dout, const int64_t* prev_actions, c
 /* dst[r,:] += src[r,:] on 512-wide rows with independent row strides: adds the position-0 gradients of the last fusion layer
  * (allenact_dino_transformer.py:708 keeps only x[:, 0]) into the [R,S,512] input gradient. */
 int svla_rows_add_bf16(svla_bf16* dst, long dst_ld, const svla_bf16* src, long src_ld, int rows, int D, void* stream);
+/* Zero `bytes` bytes at p on the stream: the scratch the text-gradient scatter (allenact_dino_transformer.py:591-605 backward, svla_fusion_text_bwd)
+ * accumulates into -- part of the launch sequence rather than a framework-side fill. */
+int svla_zero_bytes(void* p, long bytes, void* stream);
 /* llama KV-cache append of the single-step (acting) path, training/online/third_party_models/llama/model.py:279-293
  * (cache_k[:bsz, start_pos] = xk): cache[b, *t_dev, 0:width] = src[b*ld_src + 0:width]; the slot is read from device memory so that a
  * recorded launch sequence of the step does not depend on the step counter. */

@@ -524,3 +524,11 @@ extern "C" int svla_kv_append_bf16(const bf16_t* src, long ld_src, bf16_t* cache
     hipLaunchKernelGGL(kv_append_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, cache, cache_rows, width, t_dev, B);
     return svla_launch_status();
 }
+
+// Zero a device buffer on the launch stream (gradient scratch that the text / embedding backward kernels accumulate into with atomics);
+// a C-ABI entry so that it is part of a recorded launch sequence instead of a framework-side fill.
+extern "C" int svla_zero_bytes(void* p, long bytes, void* stream) {
+    if (!p || bytes <= 0) return SVLA_EINVAL;
+    HIP_CHECK_RET(hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream));
+    return SVLA_OK;
+}

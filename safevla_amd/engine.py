@@ -52,6 +52,7 @@ class PPOLagConfig:
     lambda_optimizer: str = "Adam"
     lambda_upper_bound: Optional[float] = None
     env_chunk: Optional[int] = None       # envs per micro-batch (None: whole local minibatch)
+    record_small_updates: bool = True     # small minibatches: record each env-chunk's launch sequence in the first epoch, replay it in the others
     adam_betas: Tuple[float, float] = (0.9, 0.999)
     adam_eps: float = 1e-8
 
@@ -64,6 +65,7 @@ class PPOLagEngine:
         self.tower_steps = [0, 0, 0]          # torch.optim.Adam's per-parameter ``step`` (identical within a tower)
         self._pending = []                    # async all-reduce handles of the current minibatch
         self._count_cache = {}
+        self._chunk_cache = {}                # small minibatches: recorded launch sequences per env-chunk, valid within one update
         dev = model.device_
         self._gnorm_sq = torch.zeros(1, device=dev, dtype=torch.float64)
         self._sums = torch.zeros(5, device=dev, dtype=torch.float64)   # v_sq, action, -entropy, hl-gauss CE (discrete critic), c_v_sq
@@ -85,29 +87,53 @@ class PPOLagEngine:
             a, b = self.model.arena.tower_ranges[k]
             self._pending.append(parallel.allreduce_sum_async(self.model.arena.flat_g[a:b]))
 
-    def _accumulate(self, batch: Dict, n_total: int, lam: float, last: bool = False):
+    def _accumulate(self, batch: Dict, n_total: int, lam: float, last: bool = False, cache_key=None):
         """``last``: this is the final env-chunk of the minibatch -- each tower's gradient range is handed to the asynchronous
-        all-reduce right after that tower's backward has been issued."""
+        all-reduce right after that tower's backward has been issued.
+
+        ``cache_key`` (small minibatches only): the caller promises that this chunk -- same storage contents, lambda, stage -- comes
+        back under the same key (the epochs of one update).  The first call records each tower's launch sequence (forward, fused loss,
+        backward) as an ``ops.LaunchPlan`` while executing it; later calls re-issue the three lists on the three tower streams with
+        fresh device-resident dropout seeds.  ~1000 small dependent launches per 3-tower pass cost ~14 us each through the Python
+        wrappers and ~6.5 us replayed (tools/replay_probe.py)."""
         cfg, m = self.cfg, self.model
         T, Bc = batch["actions"].shape
         R = T * Bc
         inv_n = 1.0 / float(n_total)
+        names = set(cfg.stage_losses)
+        st = self._chunk_cache.get(cache_key) if cache_key is not None else None
+        if st is not None and st["sig"] == (R, n_total, lam, tuple(cfg.stage_losses), m.training):
+            main = torch.cuda.current_stream()
+            for k, plan in enumerate(st["plans"]):
+                if plan is None:
+                    continue
+                s_ = m._tower_streams[k]
+                m.towers[k]._seed_dev_buf.add_(0x3C6EF35)          # fresh dropout noise for this pass (forward and backward read the same seed)
+                s_.wait_stream(main)
+                plan.replay()
+                if last and parallel.is_dist():
+                    with torch.cuda.stream(s_):
+                        self._reduce_tower_async(k)
+            for s_ in m._tower_streams:
+                main.wait_stream(s_)
+            return
         prep = m.prepare(batch["observations"], batch["prev_actions"], batch["masks"])
         f = lambda t: t.reshape(R).contiguous()
-        names = set(cfg.stage_losses)
         sums = self._sums
         ret_ = f(batch["returns"])
         discrete = m.critic_type == "discrete"
+        small = m.concurrent_towers and R * prep.S <= m.concurrent_tower_tokens
+        record = (small and cache_key is not None and cfg.record_small_updates and m.adt == torch.bfloat16 and m.critic_type == "linear"
+                  and len(self._chunk_cache) < 4)        # a recorded chunk keeps its three towers' activations alive: bound the footprint
+        flat = {k: f(batch[k]) for k in ("actions", "old_action_log_probs", "adv_targ", "c_adv_targ", "c_returns")}     # contiguous once, outside the recorded region
 
         def actor_block():
             # actor: clipped surrogate on the lambda-mixed advantage (+ entropy); critic: value_loss_coef * 0.5 * mse
             logits, _, c = m.run_forward(prep, need_grad=True)
-            _, dl, _ = ops.ppo_lag_loss_fwd_bwd(logits.reshape(R, N_ACTIONS), ret_, f(batch["actions"]), f(batch["old_action_log_probs"]),
-                                                f(batch["adv_targ"]), f(batch["c_adv_targ"]), ret_, None, lam, cfg.clip_param, 0.0,
+            _, dl, _ = ops.ppo_lag_loss_fwd_bwd(logits.reshape(R, N_ACTIONS), ret_, flat["actions"], flat["old_action_log_probs"],
+                                                flat["adv_targ"], flat["c_adv_targ"], ret_, None, lam, cfg.clip_param, 0.0,
                                                 cfg.action_weight, cfg.entropy_coef, False, inv_n, sums=sums[0:3])
             m.run_backward(prep, c, dl.view(T, Bc, N_ACTIONS), None)
-            if last:
-                self._reduce_tower_async(0)
 
         def critic_block():
             coef = cfg.value_loss_coef if "ppo_log_loss" in names else 1.0
@@ -115,15 +141,13 @@ class PPOLagEngine:
             _, values, c = tw.run_forward(prep, need_grad=True)
             _, dv = ops.value_mse_fwd_bwd(values.reshape(R), ret_, coef, inv_n, sums=sums[0:1])
             tw.run_backward(prep, c, None, dv.view(T, Bc, 1))
-            if last:
-                self._reduce_tower_async(1)
 
         def c_critic_block():
             tw = m.c_critic_tsfm
             _, c_values, c = tw.run_forward(prep, need_grad=True)
             dv = dfl = None
             if "safe_ppo_value_loss" in names:
-                _, dv = ops.value_mse_fwd_bwd(c_values.reshape(R), f(batch["c_returns"]), 1.0, inv_n, sums=sums[4:5])
+                _, dv = ops.value_mse_fwd_bwd(c_values.reshape(R), flat["c_returns"], 1.0, inv_n, sums=sums[4:5])
                 dv = dv.view(T, Bc, 1)
             if "ppo_log_loss" in names and discrete:
                 # the reference's own data flow with critic_type="discrete": SafePPOLogGrad's value term is HL-Gauss(extras["full_logits"],
@@ -133,20 +157,40 @@ class PPOLagEngine:
                                                 want_values=False, sums=sums[3:4])
                 dfl = dfl.view(T, Bc, -1)
             tw.run_backward(prep, c, None, dv, dfl)
-            if last:
-                self._reduce_tower_async(2)
 
         blocks = [actor_block if "ppo_log_loss" in names else None,
                   critic_block if (("ppo_log_loss" in names and not discrete) or "ppo_value_loss" in names) else None,
                   c_critic_block if ("safe_ppo_value_loss" in names or ("ppo_log_loss" in names and discrete)) else None]
-        if m.concurrent_towers and R * prep.S <= m.concurrent_tower_tokens:
+        def run_block(k, t):
+            if blocks[k] is None:
+                return None
+            plan = None
+            if record:
+                if getattr(t, "_seed_dev_buf", None) is None:
+                    t._seed_dev_buf = torch.tensor([(t.drop_seed_base * 0x9E3779B1) & 0x7FFFFFFF], device=m.device_, dtype=torch.int32)
+                t._seed_dev_buf.add_(0x3C6EF35)
+                t._seed_dev = t._seed_dev_buf          # dropout descriptors of the recorded pass point at the device-resident seed
+                plan = ops.LaunchPlan()
+                try:
+                    with plan:
+                        blocks[k]()
+                finally:
+                    t._seed_dev = None
+            else:
+                blocks[k]()
+            if last:
+                self._reduce_tower_async(k)
+            return plan
+
+        if small:
             # small minibatches are bound by the dispatch of ~1000 small dependent kernels: the three towers (independent given the batch)
             # run on three HIP streams (model.run_towers_concurrently); gradients land in disjoint arena ranges, loss sums are atomics
-            m.run_towers_concurrently(lambda k, t: blocks[k]() if blocks[k] is not None else None)
+            plans = m.run_towers_concurrently(run_block)
+            if record:
+                self._chunk_cache[cache_key] = dict(sig=(R, n_total, lam, tuple(cfg.stage_losses), m.training), plans=plans, keep=(prep, flat, ret_))
         else:
-            for blk in blocks:      # update-sized shapes: one tower at a time (only one tower's activations resident)
-                if blk is not None:
-                    blk()
+            for k, t in enumerate(m.towers):      # update-sized shapes: one tower at a time (only one tower's activations resident)
+                run_block(k, t)
 
     def optimizer_step(self, reduced: bool = False):
         """Global-norm clip + Adam over the ranges of the towers that received a gradient.  ``reduced``: the per-tower asynchronous
@@ -190,6 +234,7 @@ class PPOLagEngine:
                episode_cost_sum: float, n_episodes: float, generator: Optional[torch.Generator] = None) -> Dict[str, float]:
         cfg, m = self.cfg, self.model
         dev = m.device_
+        self._chunk_cache.clear()             # a new rollout: recorded sequences of the previous update refer to other inputs
         storage.compute_returns(next_value, next_c_value, True, cfg.gamma, cfg.gae_lambda)
         Jc, n_ep = parallel.mean_episode_cost(episode_cost_sum, n_episodes, dev)
         lam = self.lagrange.update_lagrange_multiplier(Jc) if n_ep > 0 else self.lagrange.lagrangian_multiplier
@@ -206,7 +251,8 @@ class PPOLagEngine:
                 self._sums.zero_()
                 chunk = cfg.env_chunk or (b1 - b0)
                 for c0 in range(b0, b1, chunk):
-                    self._accumulate(storage.batch_slice(c0, min(b1, c0 + chunk)), n_total, lam, last=c0 + chunk >= b1)
+                    self._accumulate(storage.batch_slice(c0, min(b1, c0 + chunk)), n_total, lam, last=c0 + chunk >= b1,
+                                     cache_key=(c0, min(b1, c0 + chunk)))
                 self.optimizer_step(reduced=True)
                 parallel.allreduce_sum_(self._sums)
                 info_acc += self._sums / n_total

@@ -304,7 +304,8 @@ class Tower(nn.Module):
             t5 = self._t5_cache[1]     # eval mode: the frozen encoder is a pure function of the goal tokens (one episode = one goal)
         else:
             t5 = ve.text_encoder.encode(prep.ids, getattr(prep, "attn_mask_u8", None) if getattr(prep, "attn_mask_u8", None) is not None else prep.attn_mask,
-                                        drop_seed=t5_seed, drop_p=self.dropout_p, dtype=self.adt)   # [U*L, 512], frozen
+                                        drop_seed=t5_seed, drop_p=self.dropout_p, dtype=self.adt,
+                                        seed_dev=getattr(self, "_seed_dev", None))   # [U*L, 512], frozen
             self._t5_cache = (key, t5) if (t5_seed is None and key is not None) else (None, None)
         ta = ops.gemm_nt(t5, w["ta"], U * L, D, 512, bias=ve.text_adapter[0].bias)
         tf, ta_mean, ta_rstd = ops.norm_fwd(ta, ve.text_adapter[1].weight, ve.text_adapter[1].bias, 1e-5, U * L, relu=True)
@@ -506,7 +507,7 @@ class Tower(nn.Module):
                                   g(self.object_in_hand_embed.weight))
             dyf = dxf
         else:
-            dxf = torch.zeros(R, S, D, device=dev, dtype=self.adt)
+            dxf = ops.zeros(R, S, D, device=dev, dtype=self.adt)
             ops.decoder_embed_bwd(dx, prep.prev_actions, prep.masks, prep.hand, T, B, dxf, S * D, g(self.last_actions_embed.weight),
                                   g(self.object_in_hand_embed.weight))
             dyf = dxf.view(M, D)
@@ -576,7 +577,7 @@ class Tower(nn.Module):
         dx0 = dyf
         ops.colsum_acc(dx0, g(ve.fusion_token), R, D, row_stride=S)
         # text adapter (trainable) -- the T5 encoder is frozen (no_grad in the reference)
-        dtf = torch.zeros(U * L, D, device=dev, dtype=F32)
+        dtf = ops.zeros(U * L, D, device=dev, dtype=F32)
         ops.fusion_text_bwd(dx0, prep.gid, T, B, S, L, TEXT_OFF, dtf)
         dtf_b = torch.empty(U * L, D, device=dev, dtype=self.adt)
         ops.cast_bf16(dtf, dtf_b)
@@ -659,7 +660,8 @@ class T5Frozen(nn.Module):
     T5_STREAM = 64      # dropout stream ids of the text encoder: 62 embedding, 63 final, 64 + 4*block + {0 probs, 1 attn out, 2 ff act, 3 ff out}
 
     @torch.no_grad()
-    def encode(self, ids: torch.Tensor, attn_mask: torch.Tensor, drop_seed: Optional[int] = None, drop_p: float = 0.1, dtype=BF16) -> torch.Tensor:
+    def encode(self, ids: torch.Tensor, attn_mask: torch.Tensor, drop_seed: Optional[int] = None, drop_p: float = 0.1, dtype=BF16,
+               seed_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
         """ids, attn_mask [U, L] int64 (device) -> last_hidden_state [U*L, 512] bf16.
 
         ``drop_seed``: the text encoder is frozen (no_grad) but NOT in eval mode in the reference -- the policy's ``self.train()``
@@ -670,7 +672,8 @@ class T5Frozen(nn.Module):
             self.sync(dtype)
         U, L = ids.shape
         n = U * L
-        site = (lambda k: ops.Dropout(drop_seed, k, drop_p)) if drop_seed is not None and drop_p > 0 else (lambda k: None)
+        # seed_dev: recorded / captured passes read the pass seed from device memory (fresh noise per replay), like the fusion layers' sites
+        site = (lambda k: ops.Dropout(drop_seed, k, drop_p, seed_dev=seed_dev)) if drop_seed is not None and drop_p > 0 else (lambda k: None)
         x = ops.embed_gather(self.shared.weight, ids.reshape(-1).contiguous(), dtype=dtype)
         ops.dropout_(x, site(62))
         bias = self.position_bias(L)
@@ -807,7 +810,14 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
         p.time_step = observations[u["time"]].reshape(R).contiguous()
         p.traj_bt = observations[u["traj"]].reshape(T, B).t().contiguous().to(torch.int32)
         # goals: content-hash rows on the GPU, tokenise each unique string once on the host
-        if "goal_token_ids" in observations:
+        if "goal_token_ids" in observations and T == 1:
+            # single-step (acting) batches: every env is its own goal row -- no de-duplication, hence no host sync (torch.unique), so the
+            # host can run ahead of the GPU while it issues the recorded step
+            p.ids = observations["goal_token_ids"].reshape(R, -1).contiguous()
+            p.attn_mask = (p.ids != 0).to(torch.int64)
+            p.attn_mask[:, 0] = 1
+            inv = torch.arange(R, device=dev)
+        elif "goal_token_ids" in observations:
             ids_rows = observations["goal_token_ids"].reshape(R, -1).contiguous()
             hashes = ops.row_hash(ids_rows.view(torch.uint8).view(R, -1))
             uniq, inv = torch.unique(hashes, return_inverse=True)
@@ -838,6 +848,7 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
             p.ids, p.attn_mask = ids.to(dev), am.to(dev)
             p.ids_key = (tuple(tuple(e) for e in enc), L)      # host-side identity of the goal batch (eval-mode T5 cache)
         p.gid = inv.to(torch.int32).contiguous()
+        p.attn_mask_u8 = p.attn_mask.to(torch.uint8).contiguous()      # T5 key-padding mask in the kernels' format (once, not per tower)
         p.U, p.L = p.ids.shape
         p.S = TEXT_OFF + p.L
         return p

@@ -348,6 +348,13 @@ def rows_add(dst, dst_ld, src, src_ld, rows):
     lib().call("svla_rows_add_f32" if dst.dtype == F32 else "svla_rows_add_bf16", _p(dst), dst_ld, _p(src), src_ld, rows, 512, _stream())
 
 
+def zeros(*shape, device, dtype):
+    """torch.zeros through the C ABI (allocation by torch, the fill is a recorded launch)."""
+    t = torch.empty(*shape, device=device, dtype=dtype)
+    lib().call("svla_zero_bytes", _p(t), t.numel() * t.element_size(), _stream())
+    return t
+
+
 def kv_append(src, ld_src, cache, t_dev, B, width):
     """cache[b, *t_dev, :width] = src[b, :width] (cache: [rows, max_steps, width] bf16; t_dev: 0-d int64 device tensor)."""
     _chk(cache, BF16, "cache")

@@ -500,3 +500,44 @@ def test_recorded_acting_step_equals_eager_acting(ops):
             t.time_step_counter = 0
         b, _ = m({k: v[0:1] for k, v in obs.items()}, None, pa[0:1], mk[0:1])
     assert (a.values - b.values).abs().max() > 1e-3 and torch.isfinite(b.values).all()
+
+
+def test_recorded_small_update_equals_eager_update(ops):
+    """Small minibatches: the first epoch of an update records every env-chunk's launch sequence (three ops.LaunchPlans per chunk), the
+    other epochs replay them.  Same kernels on the same buffers => the update must equal the eagerly issued one (eval mode: no noise) up to
+    the order of the fp32 weight-gradient atomics; in train mode every replayed epoch draws fresh dropout noise (device-resident seed)."""
+    from safevla_amd.engine import PPOLagConfig, PPOLagEngine
+    from safevla_amd.model import SafeDinoLLAMATxNavActorCriticSeparate
+    from safevla_amd.synth_env import SynthSpec, fill_synthetic_rollout
+
+    torch.manual_seed(0)
+    m = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV).eval()
+    st, nxt, ep = fill_synthetic_rollout(m, SynthSpec(T=6, B=4, L=5, task="PickUp", seed=3), device=DEV)
+    ar = m.arena
+    p0 = ar.flat_p.clone()
+    res = {}
+    for rec in (False, True):
+        ar.flat_p.copy_(p0); ar.flat_m.zero_(); ar.flat_v.zero_()
+        m.sync_weights(frozen=False)
+        eng = PPOLagEngine(m, PPOLagConfig(update_repeats=3, env_chunk=2, record_small_updates=rec))
+        info = eng.update(st, nxt["next_value"], nxt["next_c_value"], 3.0, 1.0)
+        res[rec] = (info, ar.flat_p.clone(), len(eng._chunk_cache))
+    (ia, pa, na), (ib, pb, nb) = res[False], res[True]
+    assert na == 0 and nb == 2                                     # two env-chunks recorded
+    for k in ("value", "action", "entropy", "c_value"):
+        assert abs(ia[k] - ib[k]) <= 2e-3 * max(1.0, abs(ia[k])), (k, ia[k], ib[k])
+    moved = (pa - p0).norm().item()
+    assert moved > 0 and (pa - pb).norm().item() < 0.05 * moved, ((pa - pb).norm().item(), moved)
+    # train mode: replays run and each epoch sees different noise (the loss sums of two identical replays differ)
+    m.train()
+    eng = PPOLagEngine(m, PPOLagConfig(update_repeats=1, record_small_updates=True))
+    batch = st.batch_slice(0, 4)
+    outs = []
+    for _ in range(3):
+        m.zero_grad(); eng._sums.zero_()
+        eng._accumulate(batch, 24, 0.1, cache_key="k")
+        outs.append((eng._sums.clone(), ar.flat_g.norm().item()))
+    assert len(eng._chunk_cache) == 1 and all(np.isfinite(g) and g > 0 for _, g in outs)
+    assert not torch.equal(outs[1][0], outs[2][0])                 # both are replays: same launches, fresh seeds
+    ar.flat_p.copy_(p0)
+    m.sync_weights(frozen=False)
