@@ -137,13 +137,12 @@ class InferenceAgentVIDA(AbstractAgent):
         return list(ALL_STRETCH_ACTIONS)
 
     def get_action(self, frame: Dict[str, Any], goal_spec: str) -> Tuple[str, torch.Tensor]:
-        observations = {"rgb_raw": frame["raw_navigation_camera"], "natural_language_spec": str_to_bytes(goal_spec, 1000),
-                        "time_step": self.steps_taken_in_task, "traj_index": self.traj_index}
-        if "raw_manipulation_camera" in frame:
-            observations["manipulation_rgb_raw"] = frame["raw_manipulation_camera"]
-        if "an_object_is_in_hand" in frame:
-            observations["an_object_is_in_hand"] = frame["an_object_is_in_hand"]
-        return self.act(observations, goal_spec)
+        """frame: the evaluator's sensor dict (``raw_navigation_camera`` [, ``raw_manipulation_camera``, ``an_object_is_in_hand``])."""
+        optional = {"raw_manipulation_camera": "manipulation_rgb_raw", "an_object_is_in_hand": "an_object_is_in_hand"}
+        sensors = {dst: frame[src] for src, dst in optional.items() if src in frame}
+        sensors.update(rgb_raw=frame["raw_navigation_camera"], natural_language_spec=str_to_bytes(goal_spec, 1000),
+                       time_step=self.steps_taken_in_task, traj_index=self.traj_index)
+        return self.act(sensors, goal_spec)
 
     # ---- one acting step ----------------------------------------------------------------------------------------------------
     def _batch(self, observations: Dict[str, Any]) -> Dict[str, torch.Tensor]:
@@ -160,27 +159,30 @@ class InferenceAgentVIDA(AbstractAgent):
             u["hand"]: torch.tensor([int(np.asarray(observations.get("an_object_is_in_hand", 0)).reshape(-1)[0])], device=dev, dtype=torch.int64),
         }
 
+    def _remember(self, obs_batch: Dict[str, torch.Tensor]):
+        """Feed the step's observations to the rollout storage the way the update path's storage is fed: a task's first step
+        (re)initialises it, later steps append with the sampled previous action; value / reward / cost fields are unused placeholders."""
+        st = self.rollout_storage
+        if self.steps_taken_in_task > 0:
+            zero = torch.zeros((1, 1), device=self.device)
+            st.add(observations=obs_batch, memory=self.memory, actions=self.last_action_flat, action_log_probs=zero, value_preds=zero,
+                   rewards=zero, costs=zero, c_value_preds=zero, masks=torch.ones((1, 1), device=self.device))   # one task until reset(): never "done"
+            return
+        self.has_initialized = True
+        st.initialize(observations=obs_batch, num_samplers=1, recurrent_memory_specification=self.actor_critic.recurrent_memory_specification,
+                      action_space=None)
+        st.after_updates()
+
     @torch.no_grad()
     def act(self, observations: Dict[str, Any], goal_spec: str = "") -> Tuple[str, torch.Tensor]:
-        obs_batch = self._batch(observations)
+        self._remember(self._batch(observations))
         st = self.rollout_storage
-        if self.steps_taken_in_task == 0:
-            self.has_initialized = True
-            st.initialize(observations=obs_batch, num_samplers=1,
-                          recurrent_memory_specification=self.actor_critic.recurrent_memory_specification, action_space=None)
-            st.after_updates()
-        else:
-            dummy = torch.zeros((1, 1), device=self.device)
-            st.add(observations=obs_batch, memory=self.memory, actions=self.last_action_flat, action_log_probs=dummy,
-                   value_preds=dummy, rewards=dummy, costs=dummy, c_value_preds=dummy,
-                   masks=torch.ones((1, 1), device=self.device))   # always 1: a single task until ``reset``
-        aco, self.memory = self.actor_critic(**st.agent_input_for_next_step())
-        action = aco.distributions.sample(generator=self.generator)
-        action_greedy = aco.distributions.mode()
-        self.last_action_flat = action.reshape(1)                   # the stored previous action is always the stochastic one
+        out, self.memory = self.actor_critic(**st.agent_input_for_next_step())
+        dist = out.distributions
+        sampled, greedy = dist.sample(generator=self.generator), dist.mode()
+        self.last_action_flat = sampled.reshape(1)          # what the policy sees as "previous action" next step is the sampled action, also when acting greedily
         self.steps_taken_in_task += 1
-        if st.step == st.T:
+        if st.step == st.T:                                 # storage full: roll the last slot to the front
             st.after_updates()
-        names = self.get_action_list()
-        chosen = action_greedy if self.greedy_sampling else action
-        return names[int(chosen.reshape(-1)[0])], aco.distributions.probs[0][0]
+        idx = int((greedy if self.greedy_sampling else sampled).reshape(-1)[0])
+        return self.get_action_list()[idx], dist.probs[0][0]

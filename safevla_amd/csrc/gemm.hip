@@ -854,7 +854,7 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_tn256_bf16_kernel(GemmT
 extern "C" int svla_gemm_tn_f32acc(const bf16_t* dY, long ldy, const bf16_t* X, long ldx, float* dW, long ldw, float* db, int M,
                                    int N, int K, void* stream) {
     if (M <= 0 || (N % 128) || (K % 128) || (ldy % 8) || (ldx % 8)) return SVLA_EINVAL;
-    if ((N % 256) == 0 && (K % 256) == 0 && (M % TN256_ROWS) == 0 && M >= 65536 && !g_force_small_tile) {
+    if ((N % 256) == 0 && (K % 256) == 0 && (M % TN256_ROWS) == 0 && M >= 32768 && !g_force_small_tile) {   // (59.6 k-row minibatches: 256 rows x 233 tokens)
         const int ntile256 = (N / 256) * (K / 256);
         int chunks = 256 / ntile256;                                  // <= one workgroup per CU (no second dispatch wave)
         if (chunks < 1) chunks = 1;

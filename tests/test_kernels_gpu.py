@@ -235,7 +235,7 @@ def test_gemm_nt_epilogues(ops, M, N):
 
 @pytest.mark.parametrize("small", [False, True])
 @pytest.mark.parametrize("M,N,K", [(64, 128, 128), (1000, 128, 128), (5000, 512, 384), (3001, 1536, 512), (20000, 512, 2048),
-                                   (65536, 256, 256), (100000 // 32 * 32, 512, 512), (70016, 1536, 256)])
+                                   (65536, 256, 256), (100000 // 32 * 32, 512, 512), (70016, 1536, 256), (256 * 233, 512, 512), (256 * 233, 2048, 512)])
 def test_gemm_tn(ops, M, N, K, small):
     """128x128 register-staged kernel (forced / small shapes) and the 256x256 LDS-DMA kernel, with the fused bias gradient"""
     dY, X = bf(rnd(M, N, seed=1)), bf(rnd(M, K, seed=2))
