@@ -409,7 +409,7 @@ def main():
         ns = north_star_probe(model, dev)
         secondary = [secondary_config(model, dev, "C4-shard: one GPU's 32 envs of BASELINE configs[3] (Fetch, 256 envs over 8 GPUs)", "Fetch", 256, 32, 12, None, 2.31964),
                      secondary_config(model, dev, "C2: BASELINE configs[1] (ObjectNav, 32 envs x 128 steps)", "ObjectNav", 128, 32, 12, None, 2.31964),
-                     secondary_config(model, dev, "C5-shard: mixed ObjectNav+PickUp+Fetch sampler (env e -> task e mod 3), 64-token instructions, 32 envs/GPU", "Mixed", 256, 32, 64, 16, 2.31964)]
+                     secondary_config(model, dev, "C5-shard: mixed ObjectNav+PickUp+Fetch sampler (env e -> task e mod 3), 64-token instructions, 32 envs/GPU", "Mixed", 256, 32, 64, None, 2.31964)]
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(L=args.L, train_mode=not args.eval_mode)

@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_persist_kernel(AttnAr
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
                 a = mfma16(lds_row8i(Krow.lo, kt * 16), qcur[t][0], a);
                 a = mfma16(lds_row8i(Krow.hi, kt * 16), qcur[t][1], a);
-                if (kt == NKT - 1) {   // (NKT-1)*16 < S <= NKT*16 (launcher): only the last key tile is ragged
+                if (kt >= NKT - 2) {   // (NKT-2)*16 < S <= NKT*16 (launcher): only the last two key tiles can hold padded keys
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (kt * 16 + 4 * g + e >= S) a[e] = -INFINITY;
@@ -636,7 +636,7 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 1) attn_bwd_dkv_k
 // unrolled loops), the key / query pair loops are rolled, the softmax algebra is vector code (packed fp32), and
 // D = rowsum(dO * O) is computed once (dQ kernel) and handed to the dK/dV kernel through a workspace instead of re-reading O.
 template <int NKT>
-__global__ void __launch_bounds__(ATT_THREADS, 3) attn_bwd_dq_exact_kernel(AttnArgs p) {
+__global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_dq_exact_kernel(AttnArgs p) {
     p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16, MAXQT = (NKT + 3) / 4;
@@ -728,7 +728,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 3) attn_bwd_dq_exact_kernel(AttnA
 }
 
 template <int NKT>
-__global__ void __launch_bounds__(ATT_THREADS, 3) attn_bwd_dkv_exact_kernel(AttnArgs p) {
+__global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_dkv_exact_kernel(AttnArgs p) {
     p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16, MAXKT = (NKT + 3) / 4;
@@ -839,19 +839,20 @@ static int launch_fwd(const AttnArgs& p, int rows, hipStream_t st) {
         attr = true;
     }
     const bool generic = p.mask_mode != MASK_NONE || p.bias || p.kvalid;
-    if constexpr (NKT == 12) {
-        if (!generic && p.S > (NKT - 1) * 16) {
+    // persistent forward: S in (160, 192] (fusion encoder with short goals, S = 181) and S in (224, 256] (64-token instructions, S = 233)
+    if constexpr (NKT == 12 || NKT == 16) {
+        if (!generic && p.S > (NKT - 2) * 16) {
             const size_t ldsp = (size_t)2 * NKT * 16 * LDSROW * sizeof(bf16_t);
             static int slots = 0;
             if (!slots) {
                 int dev = 0, n_cu = 0;
                 HIP_CHECK_RET(hipGetDevice(&dev));
                 HIP_CHECK_RET(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-                HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_persist_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
-                slots = 2 * n_cu;              // 2 workgroups per CU (217 VGPRs)
+                HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_persist_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
+                slots = 2 * n_cu;              // 2 workgroups per CU
             }
             const int nitems = rows * p.H;
-            hipLaunchKernelGGL((attn_fwd_persist_kernel<12>), dim3(nitems < slots ? nitems : slots), dim3(ATT_THREADS), ldsp, st, p, nitems);
+            hipLaunchKernelGGL((attn_fwd_persist_kernel<NKT>), dim3(nitems < slots ? nitems : slots), dim3(ATT_THREADS), ldsp, st, p, nitems);
             return svla_launch_status();
         }
     }
@@ -872,7 +873,9 @@ static int launch_bwd(const AttnArgs& p, int rows, hipStream_t st) {
         attr = true;
     }
     const bool generic = p.mask_mode != MASK_NONE || p.bias || p.kvalid;
-    if constexpr (NKT <= 12) if (!generic && p.Dws && p.S > (NKT - 1) * 16) {
+    // exact-tile backward: correct for any S <= NKT*16 (padded keys have zero K / V rows, padded queries lse = +inf); used where at most
+    // three of the NKT key tiles are padding
+    if constexpr (NKT <= 16) if (!generic && p.Dws && p.S > (NKT - 3) * 16) {
         const size_t le_q = (size_t)2 * NKT * 16 * LDSROW * sizeof(bf16_t);
         const size_t le_kv = le_q + NKT * 16 * 2 * sizeof(float);
         static bool attr_e = false;

@@ -523,7 +523,7 @@ def _keep_np(seed, stream, p, idx):
     return torch.from_numpy(hash_keep(seed, stream, p, idx))
 
 
-@pytest.mark.parametrize("S,mask_mode", [(100, 0), (181, 0), (40, 1)])
+@pytest.mark.parametrize("S,mask_mode", [(100, 0), (181, 0), (40, 1), (233, 0), (250, 0)])
 def test_attn_dropout_fwd_bwd_vs_hash_reference(ops, S, mask_mode):
     """Dropout on the attention probabilities: generic kernels (S = 100, block-causal S = 40) and the persistent-forward /
     exact-tile backward kernels (S = 181) against torch with the SAME counter-based masks (include/svla.h: svla_dropout)."""
