@@ -46,6 +46,10 @@ class _Lib:
                 f"{LIB_PATH} not found: the HIP extension is required (no CPU / eager fallback). "
                 "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `python safevla_amd/build.py`."
             )
+        # torch first: the PyTorch-ROCm wheel carries its own HIP runtime; loading this library before it would bind a second runtime
+        # instance (launches on torch's streams then fail with hipErrorNoDevice) -- seen when build() and smoke() share one process
+        import torch  # noqa: F401
+
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.decls = parse_header()
         for name, args in self.decls.items():

@@ -541,3 +541,44 @@ def test_recorded_small_update_equals_eager_update(ops):
     assert not torch.equal(outs[1][0], outs[2][0])                 # both are replays: same launches, fresh seeds
     ar.flat_p.copy_(p0)
     m.sync_weights(frozen=False)
+
+
+def test_goal_row_hash_identity_and_separation(ops):
+    """svla_row_hash_u8 de-duplicates the 1000-byte goal rows (allenact_dino_transformer.py:591-603 tokenises every row): equal rows must
+    hash equal; rows that differ in one byte, in byte order, or only in where the text sits inside the zero padding must hash apart; no
+    collisions among 200 k random rows."""
+    from safevla_amd.text import str_to_bytes
+
+    base = np.stack([str_to_bytes(s).reshape(-1) for s in ("find a mug", "find a mug", "find a mua", "find a gum", " find a mug", "find a mug ")])
+    h = ops.row_hash(torch.from_numpy(base).to(DEV)).cpu().numpy()
+    assert h[0] == h[1] and len({int(x) for x in h[[0, 2, 3, 4, 5]]}) == 5 and (h >= 0).all()
+    rs = np.random.RandomState(0)
+    rows = rs.randint(0, 256, size=(200_000, 64), dtype=np.uint8)
+    rows[1] = rows[0]
+    hh = ops.row_hash(torch.from_numpy(rows).to(DEV)).cpu().numpy()
+    assert hh[0] == hh[1] and len(np.unique(hh)) == len(np.unique(rows, axis=0))
+    # int64 token-id rows (the synthetic path hashes the ids' bytes)
+    ids = torch.from_numpy(rs.randint(3, 32000, size=(512, 12))).to(DEV)
+    ids[7] = ids[3]
+    hi = ops.row_hash(ids.view(torch.uint8).view(512, -1)).cpu().numpy()
+    assert hi[7] == hi[3] and len(np.unique(hi)) == 511
+
+
+def test_attention_over_the_full_kv_window_behind_the_mask(ops):
+    """The recorded acting step attends over the WHOLE cache window (S = max_steps = 500, one query per env, kv_rows = 500) with the
+    episode-window key mask: must equal attention over just the valid slots -- including an env whose window is a single slot."""
+    rows, H, cap = 5, 8, 500
+    cache = rnd(rows * cap, 2 * H * 64, seed=1).to(torch.bfloat16)
+    q1 = rnd(rows, 3 * H * 64, seed=2).to(torch.bfloat16)
+    t_now = 137
+    start = torch.tensor([0, 100, 137, 50, 136])                      # per-env first valid slot (episode start), inclusive up to t_now
+    kvalid = ((torch.arange(cap)[None] <= t_now) & (torch.arange(cap)[None] >= start[:, None])).to(torch.uint8)
+    out, _ = ops.attn_fwd(q1.to(DEV), cache.to(DEV), cache.to(DEV)[:, H * 64:], 2 * H * 64, rows, cap, H, 0.125, kvalid=kvalid.to(DEV),
+                          save_lse=False, Sq=1, ldq=3 * H * 64, kv_rows=cap)
+    kk = cache.float().view(rows, cap, 2, H, 64)
+    s = torch.einsum("rhd,rkhd->rhk", q1.float()[:, :H * 64].view(rows, H, 64), kk[:, :, 0]) * 0.125
+    s = s.masked_fill(~kvalid.bool()[:, None, :], float("-inf"))
+    want = torch.einsum("rhk,rkhd->rhd", torch.softmax(s, -1), kk[:, :, 1])
+    err = (out.float().cpu().view(rows, H, 64) - want).abs().max().item() / want.abs().max().item()
+    assert err < 1e-2, err
+    assert torch.allclose(out.float().cpu().view(rows, H, 64)[2], kk[2, t_now, 1], atol=2e-2)      # single-slot window returns that V row
