@@ -13,6 +13,9 @@ from safevla_amd.storage import RolloutStorage
 dev = torch.device("cuda")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 m = SafeDinoLLAMATxNavActorCriticSeparate(device=dev)
+m.enable_acting_plans(False)          # measure the raw eager path and a raw replay of its launches (the model's own recorded path is the default otherwise)
+if len(sys.argv) > 2 and sys.argv[2] == "serial":
+    m.concurrent_towers = False       # towers one after the other on one stream (profiles/r02_replay_probe_sequential_towers.txt)
 env = SynthVectorEnv(B, L=12, task="PickUp", seed=0, device=dev)
 st = RolloutStorage(64, device=dev)
 st.initialize(env.reset(), num_samplers=B)
