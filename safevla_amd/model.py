@@ -751,6 +751,10 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
         import os as _os
         self.concurrent_towers = _os.environ.get("SVLA_SERIAL_TOWERS", "0") != "1"
         self.concurrent_tower_tokens = 1 << 17          # rows x fusion tokens up to which the towers run concurrently
+        # Train-mode dropout inside the frozen T5 encoder: by default one realisation per UNIQUE goal per forward (the encoder runs once per
+        # unique goal); the reference draws one per (t, b) row (it encodes every row).  True = the reference's statistics, at the price of
+        # encoding R rows instead of U unique goals (+13 % FLOPs at L = 12).  Token-id goals only; eval mode is unaffected.
+        self.t5_dropout_per_row = False
         self._acting_graphs, self._acting_backend = None, "plan"
         if self.concurrent_towers and precision == "bf16" and _os.environ.get("SVLA_NO_ACTING_PLANS", "0") != "1":
             self.enable_acting_plans(True)              # recorded single-step launches are the default acting path
@@ -810,9 +814,11 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
         p.time_step = observations[u["time"]].reshape(R).contiguous()
         p.traj_bt = observations[u["traj"]].reshape(T, B).t().contiguous().to(torch.int32)
         # goals: content-hash rows on the GPU, tokenise each unique string once on the host
-        if "goal_token_ids" in observations and T == 1:
+        per_row = self.t5_dropout_per_row and self.training and "goal_token_ids" in observations
+        if "goal_token_ids" in observations and (T == 1 or per_row):
             # single-step (acting) batches: every env is its own goal row -- no de-duplication, hence no host sync (torch.unique), so the
-            # host can run ahead of the GPU while it issues the recorded step
+            # host can run ahead of the GPU while it issues the recorded step.  ``t5_dropout_per_row``: the reference's exact train-mode
+            # statistics -- it re-encodes the goal of every (t, b) row, so every row sees its own dropout realisation of the frozen T5
             p.ids = observations["goal_token_ids"].reshape(R, -1).contiguous()
             p.attn_mask = (p.ids != 0).to(torch.int64)
             p.attn_mask[:, 0] = 1

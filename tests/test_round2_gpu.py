@@ -582,3 +582,29 @@ def test_attention_over_the_full_kv_window_behind_the_mask(ops):
     err = (out.float().cpu().view(rows, H, 64) - want).abs().max().item() / want.abs().max().item()
     assert err < 1e-2, err
     assert torch.allclose(out.float().cpu().view(rows, H, 64)[2], kk[2, t_now, 1], atol=2e-2)      # single-slot window returns that V row
+
+
+def test_t5_dropout_per_row_switch(ops):
+    """Train-mode T5 dropout: one realisation per unique goal by default (rows of one episode share their text features), one per (t, b)
+    row with ``t5_dropout_per_row`` (what the reference does by re-encoding every row); eval mode: identical either way."""
+    from safevla_amd.model import SafeDinoLLAMATxNavActorCriticSeparate
+
+    m = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV)
+    T, B = 4, 2
+    obs, pa, mk = _obs(T, B, seed=5)                     # every step of an env carries the same goal ids
+
+    def text_feats(per_row, train):
+        m.train(train)
+        m.t5_dropout_per_row = per_row
+        prep = m.prepare(obs, pa, mk)
+        feats = m.visual_encoder.text_encoder.encode(prep.ids, prep.attn_mask_u8, drop_seed=123 if train else None).view(prep.U, prep.L, 512)
+        return prep, feats[prep.gid.long()].float()      # per (t*B + b) row
+
+    p0, f0 = text_feats(False, True)
+    assert p0.U == B and torch.equal(f0[0], f0[B])       # same env, steps 0 and 1: shared realisation
+    p1, f1 = text_feats(True, True)
+    assert p1.U == T * B and not torch.equal(f1[0], f1[B])
+    _, e0 = text_feats(False, False)
+    _, e1 = text_feats(True, False)                      # eval: the switch is inert (de-duplicated) and features agree
+    assert torch.equal(e0, e1)
+    m.t5_dropout_per_row = False
