@@ -247,6 +247,59 @@ def stock_rocm_baseline(dev, L=12, train_mode=True, T=64, B=8):
     return out
 
 
+def parity_gate(dev, T=8, B=4):
+    """the parity gate of the same run.  One seeded (T x B)-row minibatch through the CPU oracle (the checker) and through
+    the HIP path with the same weights, eval mode: the fp32 verification mode must agree at fp32 tolerance (1e-4), the bf16 product path
+    on its documented ladder (3e-2).  Reports relative-to-max errors of logits / values / c_values and the SafePPOLogGrad scalars."""
+    import numpy as np
+
+    from oracle import ref_loss, ref_model
+    from safevla_amd.losses import SafePPOLogGrad
+    from safevla_amd.model import SafeDinoLLAMATxNavActorCriticSeparate
+    from safevla_amd.text import GoalTokenizer, str_to_bytes
+
+    rs = np.random.RandomState(7)
+    goals = ["find a mug", "pick up the bowl", "fetch a red apple", "find a mug"]
+    obs = {"rgb_dinov2": torch.from_numpy(rs.standard_normal((T, B, 384, 7, 12)).astype(np.float32)),
+           "manipulation_rgb_dinov2": torch.from_numpy(rs.standard_normal((T, B, 384, 7, 12)).astype(np.float32)),
+           "natural_language_spec": torch.from_numpy(np.stack([np.stack([str_to_bytes(goals[b]).reshape(-1) for b in range(B)]) for _ in range(T)])),
+           "time_step": torch.arange(T)[:, None].expand(T, B).contiguous(), "traj_index": torch.from_numpy((np.arange(T)[:, None] >= 5).astype(np.int64) + np.zeros((T, B), np.int64)),
+           "an_object_is_in_hand": torch.from_numpy(rs.randint(0, 2, (T, B, 1)))}
+    obs["time_step"] = torch.where(obs["traj_index"] > 0, obs["time_step"] - 5, obs["time_step"])          # an episode boundary at step 5
+    pa, mk = torch.from_numpy(rs.randint(0, 20, (T, B))), torch.ones(T, B, 1)
+    mk[5] = 0
+    batch = {"actions": torch.from_numpy(rs.randint(0, 20, (T, B))), "old_action_log_probs": torch.full((T, B), -3.0), "adv_targ": torch.randn(T, B, 1),
+             "c_adv_targ": torch.randn(T, B, 1), "returns": torch.randn(T, B, 1), "values": torch.randn(T, B, 1)}
+    d = lambda x: {k: v.to(dev) for k, v in x.items()}
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    out = {"sample": f"T={T} x B={B} rows, 3 distinct goals, one episode boundary, eval mode, lambda 0.37; relative-to-max errors vs the fp32 CPU oracle"}
+    ref = None
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(11)
+        m = SafeDinoLLAMATxNavActorCriticSeparate(device=dev, precision=prec).eval()
+        if ref is None:
+            ref = ref_model.RefSafeActorCritic(GoalTokenizer(), max_batch=B).eval()
+            ref.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+            with torch.no_grad():
+                ro, _ = ref(obs, None, pa, mk)
+            _, ri = ref_loss.safe_ppo_log_grad(ro["logits"], ro["values"], batch, 0.37)
+            sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        else:
+            m.load_state_dict(sd)
+        with torch.no_grad():
+            aco, _ = m(d(obs), None, pa.to(dev), mk.to(dev))
+        _, info = SafePPOLogGrad(0.1, 0.5, 0.0, use_clipped_value_loss=False, normalize_advantage=False).loss(0, d(batch), aco, lagrangian_multiplier=torch.tensor(0.37))
+        e = {"logits": rel(aco.distributions.logits.float().cpu(), ref_loss.categorical(ro["logits"])), "values": rel(aco.values.cpu(), ro["values"]),
+             "c_values": rel(aco.c_values.cpu(), ro["c_values"]),
+             "loss_scalars": max(abs(info[k] - ri[k]) / max(1.0, abs(ri[k])) for k in ("ppo_total", "value", "action", "entropy"))}
+        tol = 1e-4 if prec == "fp32" else 3e-2
+        out[prec] = {k: float(f"{v:.3g}") for k, v in e.items()}
+        out[prec].update(tolerance=tol, passed=bool(max(e.values()) < tol))
+        del m, aco
+        torch.cuda.empty_cache()
+    return out
+
+
 def _self_spawn(args):
     """`python bench.py --gpus N` outside torchrun: re-exec under torch.distributed.run, one rank per GPU (RCCL).  Never
     falls back to fewer ranks: a box with < N GPUs is an error."""
@@ -420,6 +473,10 @@ def main():
             cpu["stock_pytorch_rocm"] = stock_rocm_baseline(dev, L=args.L, train_mode=not args.eval_mode)
         except Exception as e:          # the intermediate baseline must never take the bench line down
             cpu["stock_pytorch_rocm"] = {"error": repr(e)[:200]}
+        try:
+            cpu["parity_gate"] = parity_gate(dev)
+        except Exception as e:
+            cpu["parity_gate"] = {"error": repr(e)[:200]}
     if rank == 0:
         out = {"metric": "env-steps/sec through PPO-Lagrangian update", "value": round(env_steps / (ms * 1e-3), 1), "unit": "env-steps/s",
                "n_gpus": world, "rccl_ranks": (torch.distributed.get_world_size() if world > 1 else 1),
