@@ -33,6 +33,16 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     m, eng, st = build(dev, T, B)               # every rank builds the same GLOBAL rollout, then works on its env shard only
+    if rank == 1:                               # make rank 1 differ (arena AND frozen T5), then let rank 0's replica win
+        m.arena.flat_p.mul_(1.5)
+        m.visual_encoder.text_encoder.shared.weight.mul_(0.5)
+    before = (m.arena.flat_p.double().sum().item(), m.visual_encoder.text_encoder.shared.weight.double().sum().item())
+    parallel.broadcast_model_(m)
+    after = torch.tensor([m.arena.flat_p.double().sum().item(), m.visual_encoder.text_encoder.shared.weight.double().sum().item()], dtype=torch.float64, device=dev)
+    chk = after.clone()
+    torch.distributed.all_reduce(chk, op=torch.distributed.ReduceOp.MAX)
+    assert torch.equal(chk, after), "replicas differ after broadcast_model_"
+    assert rank == 0 or before != tuple(after.tolist())
     s, n = parallel.shard_envs(B, world, rank)
     n_total = parallel.global_count(T * n, dev)
     assert n_total == T * B
