@@ -456,14 +456,22 @@ def main():
     ns = None
     secondary = None
     if rank == 0 and world == 1 and not args.no_secondary:
+        # secondary measurements must never take the headline line down: each one is guarded on its own
+        def guarded(fn, *a):
+            try:
+                return fn(*a)
+            except Exception as e:
+                torch.cuda.empty_cache()
+                return {"error": repr(e)[:300]}
+
         del eng, step
-        acting = acting_bench(model, st, B, dev)
+        acting = guarded(acting_bench, model, st, B, dev)
         del st, nxt
         torch.cuda.empty_cache()
-        ns = north_star_probe(model, dev)
-        secondary = [secondary_config(model, dev, "C4-shard: one GPU's 32 envs of BASELINE configs[3] (Fetch, 256 envs over 8 GPUs)", "Fetch", 256, 32, 12, None, 2.31964),
-                     secondary_config(model, dev, "C2: BASELINE configs[1] (ObjectNav, 32 envs x 128 steps)", "ObjectNav", 128, 32, 12, None, 2.31964),
-                     secondary_config(model, dev, "C5-shard: mixed ObjectNav+PickUp+Fetch sampler (env e -> task e mod 3), 64-token instructions, 32 envs/GPU", "Mixed", 256, 32, 64, None, 2.31964)]
+        ns = guarded(north_star_probe, model, dev)
+        secondary = [guarded(secondary_config, model, dev, "C4-shard: one GPU's 32 envs of BASELINE configs[3] (Fetch, 256 envs over 8 GPUs)", "Fetch", 256, 32, 12, None, 2.31964),
+                     guarded(secondary_config, model, dev, "C2: BASELINE configs[1] (ObjectNav, 32 envs x 128 steps)", "ObjectNav", 128, 32, 12, None, 2.31964),
+                     guarded(secondary_config, model, dev, "C5-shard: mixed ObjectNav+PickUp+Fetch sampler (env e -> task e mod 3), 64-token instructions, 32 envs/GPU", "Mixed", 256, 32, 64, None, 2.31964)]
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(L=args.L, train_mode=not args.eval_mode)
