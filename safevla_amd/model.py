@@ -292,8 +292,13 @@ class Tower(nn.Module):
         c = {}  # saved activations
         c["drop_seed"], site = self._drop_sites()
         tok = prep.tokens.view(M2, self.dino_dim)
-        c1 = ops.gemm_nt(tok, w["c1"], M2, D, self.dino_dim, bias=ve.visual_compressor[0].bias, act=ops.ACT_RELU)
-        c2 = ops.gemm_nt(c1, w["c2"], M2, D, D, bias=ve.visual_compressor[2].bias, act=ops.ACT_RELU)
+        # ReLU derivatives of the two compressor convs as 1 bit per element (like the feed-forward's): the input-gradient GEMMs then read
+        # M2 x 64 mask bytes instead of re-reading a whole M2 x 512 bf16 activation
+        bits = need_grad and self.adt == BF16
+        c1b = torch.empty(ops.relu_bits_bytes(M2, D), device=self.device_, dtype=torch.uint8) if bits else None
+        c2b = torch.empty(ops.relu_bits_bytes(M2, D), device=self.device_, dtype=torch.uint8) if bits else None
+        c1 = ops.gemm_nt(tok, w["c1"], M2, D, self.dino_dim, bias=ve.visual_compressor[0].bias, act=ops.ACT_RELU, relu_bits_out=c1b)
+        c2 = ops.gemm_nt(c1, w["c2"], M2, D, D, bias=ve.visual_compressor[2].bias, act=ops.ACT_RELU, relu_bits_out=c2b)
         a1 = ops.gemm_nt(c2, w["va"], M2, D, D, bias=ve.visual_adapter[0].bias)
         x = torch.empty(R, S, D, device=self.device_, dtype=self.adt)
         _, va_mean, va_rstd = ops.norm_fwd(a1, ve.visual_adapter[1].weight, ve.visual_adapter[1].bias, 1e-5, M2, relu=True,
@@ -310,7 +315,7 @@ class Tower(nn.Module):
         ta = ops.gemm_nt(t5, w["ta"], U * L, D, 512, bias=ve.text_adapter[0].bias)
         tf, ta_mean, ta_rstd = ops.norm_fwd(ta, ve.text_adapter[1].weight, ve.text_adapter[1].bias, 1e-5, U * L, relu=True)
         ops.fusion_fill(ve.fusion_token, tf, prep.gid, x, R, S, L, TEXT_OFF)
-        c.update(c1=c1, c2=c2, a1=a1, va=(va_mean, va_rstd), t5=t5, ta=ta, ta_stats=(ta_mean, ta_rstd))
+        c.update(c1=c1, c2=c2, c1b=c1b, c2b=c2b, a1=a1, va=(va_mean, va_rstd), t5=t5, ta=ta, ta_stats=(ta_mean, ta_rstd))
         xf = x.view(M, D)
         fl = []
         nfl = len(ve.fusion_xformer.layers)
@@ -589,9 +594,9 @@ class Tower(nn.Module):
                            g(ve.visual_adapter[1].weight), g(ve.visual_adapter[1].bias), relu=True, dtok=self._dcamtok,
                            tok_group=NPATCH, dymap=(2 * NPATCH, S, 1))
         ops.gemm_tn_acc(da1, c["c2"], dw["va"], M2, D, D, db=g(ve.visual_adapter[0].bias))
-        dc2 = ops.gemm_nt(da1, wt["va"], M2, D, D, relu_mask=c["c2"])
+        dc2 = ops.gemm_nt(da1, wt["va"], M2, D, D, relu_bits=c["c2b"]) if c.get("c2b") is not None else ops.gemm_nt(da1, wt["va"], M2, D, D, relu_mask=c["c2"])
         ops.gemm_tn_acc(dc2, c["c1"], dw["c2"], M2, D, D, db=g(ve.visual_compressor[2].bias))
-        dc1 = ops.gemm_nt(dc2, wt["c2"], M2, D, D, relu_mask=c["c1"])
+        dc1 = ops.gemm_nt(dc2, wt["c2"], M2, D, D, relu_bits=c["c1b"]) if c.get("c1b") is not None else ops.gemm_nt(dc2, wt["c2"], M2, D, D, relu_mask=c["c1"])
         ops.gemm_tn_acc(dc1, prep.tokens.view(M2, self.dino_dim), dw["c1"], M2, D, self.dino_dim, db=g(ve.visual_compressor[0].bias))
 
 
