@@ -36,6 +36,8 @@ DINO = 384
 NPATCH = 84          # 7 x 12 grid per camera
 TEXT_OFF = 1 + 2 * NPATCH
 BF16, F32 = torch.bfloat16, torch.float32
+import os as _os0
+_NO_COMPRESSOR_BITS = _os0.environ.get("SVLA_NO_COMPRESSOR_BITS", "0") == "1"     # A/B switch of the 1-bit compressor ReLU masks
 
 
 class _NS(nn.Module):
@@ -294,7 +296,7 @@ class Tower(nn.Module):
         tok = prep.tokens.view(M2, self.dino_dim)
         # ReLU derivatives of the two compressor convs as 1 bit per element (like the feed-forward's): the input-gradient GEMMs then read
         # M2 x 64 mask bytes instead of re-reading a whole M2 x 512 bf16 activation
-        bits = need_grad and self.adt == BF16
+        bits = need_grad and self.adt == BF16 and not _NO_COMPRESSOR_BITS
         c1b = torch.empty(ops.relu_bits_bytes(M2, D), device=self.device_, dtype=torch.uint8) if bits else None
         c2b = torch.empty(ops.relu_bits_bytes(M2, D), device=self.device_, dtype=torch.uint8) if bits else None
         c1 = ops.gemm_nt(tok, w["c1"], M2, D, self.dino_dim, bias=ve.visual_compressor[0].bias, act=ops.ACT_RELU, relu_bits_out=c1b)
