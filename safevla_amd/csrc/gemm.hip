@@ -56,6 +56,10 @@ struct GemmNtArgs {
 // group) are one 8-byte word and a 32-row x 64-column slab (one wave's epilogue unit in the 256-tile kernel) is 256 contiguous bytes
 __device__ __forceinline__ size_t relu_bits_word(int m, int n, int N) { return ((size_t)(m >> 5) * (N >> 6) + (n >> 6)) * 256 + (size_t)(m & 31) * 8; }
 
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) {
+    typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
 __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p) {
@@ -289,6 +293,157 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p)
 #define NS64 2
 __device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
+// Epilogue of the 256x256 kernels (shared by the persistent 2-buffer kernel and the 8-phase kernel): bias / activation / dropout /
+// mask / residual in fp32 on the accumulator layout acc[i][j][reg] (row = wm*128 + i*32 + (lane&31), col = wn*64 + j*32 + (reg&3) +
+// 8*(reg>>2) + 4*(lane>>5)), one bf16 rounding, then each 32 x 64 slab is transposed through the wave-private 4 KiB LDS buffer so
+// that every global store instruction writes 8 full 128-byte lines.
+template <int ACT, int AUX, int HI_OFF, bool LDS_BIAS>
+struct Nt256Epi {
+    static constexpr bool HAS_RES = (AUX & 1) != 0, HAS_MASK = (AUX & 2) != 0, HAS_BITS = AUX == 4, LDS_AUX = HAS_RES || HAS_MASK;
+    const GemmNtArgs& p;
+    const int wm, wn, lane, fr, fh;
+    const bf16_t* aux;
+    long ldaux;
+    // wave-private staging of one 32 x 64 bf16 slab (128-byte rows): write (row fr, 8-byte piece), read (row lane>>3 [+8 it], 16-byte
+    // chunk lane&7).  Rows 0-15 start at Es, rows 16-31 at Es + hi_off (2048: one contiguous 4-KiB buffer; 16384: two 2-KiB stripes
+    // of neighbouring ring slots, see gemm_nt8p)
+    char* Es;
+    static constexpr int hi_off = HI_OFF;
+    int e_wr, e_sw, e_rd;
+    const float* bias_lds;    // LDS-resident copy of bias[0..N) (8-phase kernel: no vector-memory load in the bias path), or nullptr
+    // the residual / mask slab is fetched row-major (8 full 128-byte lines per instruction), one slab ahead, and turned into the
+    // accumulator layout through the wave's LDS buffer (the inverse of the output transposition)
+    u32x4 auxrm[2][4];
+    // AUX == 4: the ReLU mask as 1 bit per element ([M, N/8] bytes): the 64 bits of this lane's slab row are ONE 8-byte load in
+    // the accumulator layout -- no LDS round trip, 16x fewer mask bytes than a bf16 activation tensor
+    u32x2 mbits[2];
+    __device__ __forceinline__ Nt256Epi(const GemmNtArgs& p_, char* es_wave, const float* bias_lds_, int wid, int lane_)
+        : p(p_), wm(wid >> 2), wn(wid & 3), lane(lane_), fr(lane_ & 31), fh(lane_ >> 5) {
+        aux = HAS_RES ? p.residual : (HAS_MASK ? p.relu_mask : nullptr);
+        ldaux = HAS_RES ? p.ldr : p.ldm;
+        Es = es_wave;
+        bias_lds = bias_lds_;
+        e_wr = (fr & 15) * 128 + (fr >> 4) * hi_off + fh * 8;
+        e_sw = fr & 7;
+        e_rd = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);
+    }
+    __device__ __forceinline__ int it_off(int it) const { return (it & 1) * 1024 + (it >> 1) * hi_off; }     // rows it*8 .. it*8+7
+    __device__ __forceinline__ void load_aux(int i, u32x4 (&buf)[4], int tm0, int tn0) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int mr = min(tm0 + wm * 128 + i * 32 + it * 8 + (lane >> 3), p.M - 1);
+            buf[it] = *(const u32x4*)(aux + (size_t)mr * ldaux + tn0 + wn * 64 + (lane & 7) * 8);
+        }
+    }
+    __device__ __forceinline__ void load_bits(int i, u32x2& dst, int tm0, int tn0) {
+        const int mc = min(tm0 + wm * 128 + i * 32 + fr, p.M - 1);
+        dst = *(const u32x2*)(p.bits_in + relu_bits_word(mc, tn0 + wn * 64, p.N));
+    }
+    // slab 0's operands: issued while the last K-tile is still being computed
+    __device__ __forceinline__ void prefetch0(int m0, int n0) {
+        if (LDS_AUX && n0 + wn * 64 < p.N) load_aux(0, auxrm[0], m0, n0);
+        if (HAS_BITS && n0 + wn * 64 < p.N) load_bits(0, mbits[0], m0, n0);
+    }
+    // returns whether this wave issued exactly 16 (+4 sign-bit) stores (full tile, columns inside N)
+    __device__ __forceinline__ bool run(f32x16 (&acc)[4][2], int m0, int n0) {
+        bf16_t* C = (bf16_t*)p.C;
+        const bool wave_cols_valid = n0 + wn * 64 < p.N;      // wave-uniform: a wave's 64 output columns are all inside N or all outside
+        if ((p.dbg & 2) || !wave_cols_valid) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+        } else {
+            f32x4 bias4[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    bias4[j][rg] = LDS_BIAS ? *(const f32x4*)(bias_lds + n0 + wn * 64 + j * 32 + 8 * rg + 4 * fh)
+                                            : (p.bias ? *(const f32x4*)(p.bias + n0 + wn * 64 + j * 32 + 8 * rg + 4 * fh) : f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wm * 128 + i * 32 + fr;
+                const int mc = min(m, p.M - 1);
+                if (LDS_AUX && i + 1 < 4) load_aux(i + 1, auxrm[(i + 1) & 1], m0, n0);
+                if (HAS_BITS && i + 1 < 4) load_bits(i + 1, mbits[(i + 1) & 1], m0, n0);
+                if (LDS_AUX) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) *(u32x4*)(Es + it_off(it) + e_rd) = auxrm[i & 1][it];
+                    __builtin_amdgcn_wave_barrier();
+                }
+                unsigned obw[2] = {0u, 0u};       // sign bits of this lane's 2 x 16 outputs, at their column positions
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int nb = n0 + wn * 64 + j * 32;
+                    u32x2 pk[4];
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int n = nb + 8 * rg + 4 * fh;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[i][j][rg * 4 + e] * p.alpha + bias4[j][rg][e];
+                            if (ACT == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                            else if (ACT == ACT_GELU) v[e] = gelu_f(v[e]);
+                        }
+                        if (p.drop.thr) {      // wave-uniform
+                            const unsigned keep = drop_keep4(p.drop, (unsigned long long)m * p.drop.row_mult * p.N + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = ((keep >> e) & 1u) ? v[e] * p.drop.scale : 0.f;
+                        }
+                        if (HAS_MASK) {
+                            const u32x2 mk = HAS_RES ? *(const u32x2*)(p.relu_mask + (size_t)mc * p.ldm + n) : *(const u32x2*)(Es + e_wr + (((j * 4 + rg) ^ e_sw) << 4));
+                            if (!(bf_lo(mk[0]) > 0.f)) v[0] = 0.f;
+                            if (!(bf_hi(mk[0]) > 0.f)) v[1] = 0.f;
+                            if (!(bf_lo(mk[1]) > 0.f)) v[2] = 0.f;
+                            if (!(bf_hi(mk[1]) > 0.f)) v[3] = 0.f;
+                        }
+                        if (HAS_BITS) {
+                            const unsigned nib = mbits[i & 1][j] >> (8 * rg + 4 * fh);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (!((nib >> e) & 1u)) v[e] = 0.f;
+                        }
+                        if (HAS_RES) {
+                            const u32x2 rs = *(const u32x2*)(Es + e_wr + (((j * 4 + rg) ^ e_sw) << 4));
+                            v[0] += bf_lo(rs[0]); v[1] += bf_hi(rs[0]); v[2] += bf_lo(rs[1]); v[3] += bf_hi(rs[1]);
+                        }
+                        pk[rg][0] = pack_bf2(v[0], v[1]);
+                        pk[rg][1] = pack_bf2(v[2], v[3]);
+                        *(u32x2*)(Es + e_wr + (((j * 4 + rg) ^ e_sw) << 4)) = pk[rg];
+                        if (ACT == ACT_RELU && AUX == 0) {   // outputs are >= 0: "positive" == non-zero magnitude bits of the rounded value
+                            // per 16-bit half: min(magnitude, 1) (v_pk_min_u16), then fold bit 16 down to bit 1
+                            const unsigned t0 = pk_min_u16(pk[rg][0] & 0x7fff7fffu, 0x00010001u), t1 = pk_min_u16(pk[rg][1] & 0x7fff7fffu, 0x00010001u);
+                            const unsigned nib = ((t0 | (t0 >> 15)) & 3u) | (((t1 | (t1 >> 15)) & 3u) << 2);
+                            obw[j] |= nib << (8 * rg + 4 * fh);
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const u32x4 w = *(const u32x4*)(Es + it_off(it) + e_rd);
+                    const int mr = m0 + wm * 128 + i * 32 + it * 8 + (lane >> 3);
+                    if (p.dbg & 1) { asm volatile("" ::"v"(w)); }
+                    else if (mr < p.M) *(u32x4*)(C + (size_t)mr * p.ldc + n0 + wn * 64 + (lane & 7) * 8) = w;
+                }
+                if (ACT == ACT_RELU && AUX == 0 && p.bits_out) {
+                    // lanes fr and fr+32 hold the two interleaved nibble sets of row fr: merge, then ONE 8-byte store per row (store
+                    // instructions, not bytes, are what the CU's store path charges for)
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(obw[0], obw[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(obw[1], obw[1], false, false);
+                    const u32x2 ob = {obw[0] | s0[1], obw[1] | s1[1]};
+                    if (fh == 0 && m < p.M) *(u32x2*)(p.bits_out + relu_bits_word(m, n0 + wn * 64, p.N)) = ob;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return (m0 + 256 <= p.M) && wave_cols_valid && !(p.dbg & 3);
+    }
+};
+
+
 // ACT / AUX (bit 0: +residual, bit 1: ReLU mask) are compile-time: a runtime-selected epilogue unrolled over the 32 accumulator
 // pieces is ~100 KiB of code (128 inlined erff bodies ...) that evicts the main loop from the instruction cache once per tile.
 template <int ACT, int AUX>
@@ -358,31 +513,7 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
 
     f32x16 acc[4][2];
     const int fr = lane & 31, fh = lane >> 5;
-    bf16_t* C = (bf16_t*)p.C;
-    constexpr bool HAS_RES = (AUX & 1) != 0, HAS_MASK = (AUX & 2) != 0, HAS_BITS = AUX == 4, LDS_AUX = HAS_RES || HAS_MASK;
-    const bf16_t* aux = HAS_RES ? p.residual : (HAS_MASK ? p.relu_mask : nullptr);
-    const long ldaux = HAS_RES ? p.ldr : p.ldm;
-    // the residual / mask slab is fetched row-major (8 full 128-byte lines per instruction), one slab ahead, and turned into the
-    // accumulator layout through the wave's LDS buffer (the inverse of the output transposition)
-    u32x4 auxrm[2][4];
-    auto load_aux = [&](int i, u32x4 (&buf)[4], int tm0, int tn0) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int mr = min(tm0 + wm * 128 + i * 32 + it * 8 + (lane >> 3), p.M - 1);
-            buf[it] = *(const u32x4*)(aux + (size_t)mr * ldaux + tn0 + wn * 64 + (lane & 7) * 8);
-        }
-    };
-    // AUX == 4: the ReLU mask as 1 bit per element ([M, N/8] bytes): the 64 bits of this lane's slab row are ONE 8-byte load in
-    // the accumulator layout -- no LDS round trip, 16x fewer mask bytes than a bf16 activation tensor
-    u32x2 mbits[2];
-    auto load_bits = [&](int i, u32x2& dst, int tm0, int tn0) {
-        const int mc = min(tm0 + wm * 128 + i * 32 + fr, p.M - 1);
-        dst = *(const u32x2*)(p.bits_in + relu_bits_word(mc, tn0 + wn * 64, p.N));
-    };
-    // epilogue staging (wave-private 4 KiB): write (row fr, 8-byte piece), read (row lane>>3 [+8 it], 16-byte chunk lane&7)
-    char* Es = smem + (size_t)NS64 * 512 * BK64 * 2 + (size_t)__builtin_amdgcn_readfirstlane(wid) * 4096;
-    const int e_wr = fr * 128 + fh * 8, e_sw = fr & 7;
-    const int e_rd = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);
+    Nt256Epi<ACT, AUX, 2048, false> epi(p, smem + (size_t)NS64 * 512 * BK64 * 2 + (size_t)__builtin_amdgcn_readfirstlane(wid) * 4096, nullptr, wid, lane);
     for (int s = 0; s < NS64 - 1; ++s) issue_next();
     int g = 0;
     bool prev_full = true;
@@ -404,8 +535,7 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
             }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (LDS_AUX && kt == nk - 1 && n0 + wn * 64 < p.N) load_aux(0, auxrm[0], m0, n0);
-            if (HAS_BITS && kt == nk - 1 && n0 + wn * 64 < p.N) load_bits(0, mbits[0], m0, n0);
+            if (kt == nk - 1) epi.prefetch0(m0, n0);
             issue_next();
             const int st = g % NS64;
             const bf16_t* Ab = As + st * 256 * BK64;
@@ -440,98 +570,208 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        const bool wave_cols_valid = n0 + wn * 64 < p.N;      // wave-uniform: a wave's 64 output columns are all inside N or all outside
-        if ((p.dbg & 2) || !wave_cols_valid) {
+        prev_full = epi.run(acc, m0, n0);      // exactly 16 stores were issued behind this wave's in-flight DMA group
+    }
+}
+
+// =================================================================================================
+// 8-phase ("ping-pong") 256x256x64 NT kernel.  Same tile, wave layout (2(M) x 4(N) waves, 128 x 64 per wave) and epilogue as
+// gemm_nt256k64; what changes is the operand pipeline.
+//   * LDS ring of EIGHT 16-KiB half-tiles instead of two 64-KiB stages.  A K-tile is four half-tiles, in DMA order
+//       B0 = cols {wn*64 + 0..31}  (j = 0)      B1 = cols {wn*64 + 32..63}  (j = 1)
+//       A0 = rows {wm*128 + 0..63} (i = 0,1)    A1 = rows {wm*128 + 64..127} (i = 2,3)
+//     each [128 rows][64 k] bf16, 128-byte rows (full-line LDS-DMA), XOR-swizzled like the stages of the 2-buffer kernel.
+//   * A K-tile is computed as four phases, phase i = the wave's accumulator row block i (32 rows x 64 columns, 8 MFMAs).  Both B
+//     half-tiles are read whole (all 64 k) into registers in phase 0 and kept for the K-tile, A row block i is read in phase i: every
+//     LDS byte is read once per wave, and a half-tile's ring slot is free again two phases after its last read -- the ring holds
+//     almost only data in flight.  The DMA stream runs P8_L = 6 half-tiles (96 KiB) ahead of the reads, one half-tile (2 DMA
+//     instructions per wave) issued per phase, continuously across K-tiles and output tiles, waited for with a counted vmcnt
+//     (never 0 in steady state).
+//   * Two wave groups (wm = 0 / 1: one wave of each on every SIMD) run one barrier apart: while one group issues its MFMAs, the
+//     other issues its fragment reads and DMA.  Each phase = [reads + DMA issue] barrier [8 MFMAs] barrier.
+// Synchronisation (ticks = intervals between workgroup barriers; group 0: load(P) in tick 2P, compute(P) in tick 2P+1; group 1 one
+// tick later; half-tile q = 4*ktile + type).  RAW: every wave waits for ITS pieces of the half-tiles first read in phase P+1 at the
+// end of load(P), i.e. before a barrier that precedes any read of them: at P = 3 (mod 4) the next K-tile's B0, B1, A0 (q <= P+3 of
+// the q <= P+6 issued: 3 half-tiles = 6 instructions may stay in flight), at P = 1 (mod 4) A1 (q <= P+2: 8 instructions).  WAR:
+// half-tile q+8 is issued in load(q+2), two full phases after the last read of q (which is in phase <= q; the reads of a phase are
+// retired by the lgkmcnt wait in front of its MFMAs, one barrier before the next phase of the same group).
+#define P8_RING_BYTES 131072
+template <int ACT, int AUX>
+__global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt8p_bf16_kernel(GemmNtArgs p) {
+    p.drop = drop_resolve(p.drop);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3;
+    const int ntn = (p.N + 255) / 256, MT = (p.M + 255) / 256;
+    const int xcd = blockIdx.x & 7, lw = blockIdx.x >> 3, lstride = gridDim.x >> 3;
+    const int n_local = ((MT - xcd + 7) / 8) * ntn;
+    if (lw >= n_local) return;
+    const int my_tiles = (n_local - lw + lstride - 1) / lstride;
+    const int nk = p.K / BK64;
+    auto tile_origin = [&](int ti, int& m0, int& n0) {
+        const int li = lw + ti * lstride;
+        m0 = ((li / ntn) * 8 + xcd) * 256;
+        n0 = (li % ntn) * 256;
+    };
+
+    // ---- DMA side.  One wave instruction = 8 half-tile rows x 128 B; wave w fills half-tile rows w*16 + j*8 + (lane>>3), j = 0,1.
+    uint32_t offB[2][2], offA[2][2];          // [half][j]: byte offset of this lane's 16-byte chunk from the tile's operand base
+    const char* a_base = nullptr;
+    const char* b_base = nullptr;
+    auto set_dma_tile = [&](int ti) {
+        int m0d, n0d;
+        tile_origin(ti, m0d, n0d);
+        m0d = __builtin_amdgcn_readfirstlane(m0d);
+        n0d = __builtin_amdgcn_readfirstlane(n0d);
+        a_base = (const char*)p.A + (size_t)m0d * p.lda * 2;
+        b_base = (const char*)p.B + (size_t)n0d * p.ldb * 2;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 2; ++j) {
+            const int rho = wid * 16 + (lane >> 3) + 8 * j;
+            const int csw = ((lane & 7) ^ ((rho >> 1) & 7)) * 8;       // swizzle on the SOURCE address (the DMA writes lane-linear)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
-        } else {
-            f32x4 bias4[2][4];
+            for (int h = 0; h < 2; ++h) {
+                const int arow = (rho >> 6) * 128 + h * 64 + (rho & 63);
+                const int bcol = (rho >> 5) * 64 + h * 32 + (rho & 31);
+                offA[h][j] = (uint32_t)(((min(m0d + arow, p.M - 1) - m0d) * p.lda + csw) * 2);      // M tail: clamp (never stored)
+                offB[h][j] = (uint32_t)(((min(n0d + bcol, p.N - 1) - n0d) * p.ldb + csw) * 2);      // half last n-tile: clamp
+            }
+        }
+    };
+    int d_tile = 0, d_kt = 0, d_par = 0;
+    bool d_live = true;
+    const int wrow_off = __builtin_amdgcn_readfirstlane(wid * 2048);
+    set_dma_tile(0);
+    // ty: 0 = B0, 1 = B1, 2 = A0, 3 = A1 (compile-time at every call site); ring slot = 4 * (K-tile parity) + ty
+    auto issue = [&](const int ty) {
+        if (d_live) {
+            const char* base = ty >= 2 ? a_base : b_base;
+            const uint32_t kb = (uint32_t)(d_kt * BK64 * 2);
+            char* dst = smem + (d_par * 4 + ty) * 16384 + wrow_off;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t off = (ty == 0 ? offB[0][j] : ty == 1 ? offB[1][j] : ty == 2 ? offA[0][j] : offA[1][j]) + kb;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
+                                                 (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+            }
+        }
+        if (ty == 3) {          // the K-tile's last half-tile: advance the DMA cursor
+            d_par ^= 1;
+            if (++d_kt == nk) {
+                d_kt = 0;
+                if (++d_tile < my_tiles) set_dma_tile(d_tile);
+                else d_live = false;
+            }
+        }
+    };
+
+    // ---- fragment read addresses: A row (wm*64 + i'*32 + fr), B row (wn*32 + fr) of a half-tile, logical chunk kk*2 + fh
+    uint32_t ra[4], rb[4];
+    {
+        const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int ko = ((kk * 2 + fh) ^ ((fr >> 1) & 7)) * 16;
+            ra[kk] = (uint32_t)(32768 + (wm * 64 + fr) * 128 + ko);
+            rb[kk] = (uint32_t)((wn * 32 + fr) * 128 + ko);
+        }
+    }
+    f32x16 acc[4][2];
+    bf16x8 fa[4], fb0[4], fb1[4];
+    // Epilogue staging lives in the ring: when a wave enters the epilogue, the DMA stream has issued the next tile's half-tiles
+    // 0..5, so the two slots of types A0 / A1 of the K-tile after next (parity c_par ^ 1) hold no live data; wave w uses ITS OWN
+    // 2-KiB stripes of them (rows w*16 .. w*16+15 -- the rows only wave w ever fills by DMA, so no other wave touches them, and its
+    // own next DMA into them is issued after its last staging access has retired).  The 32 KiB behind the ring hold bias[0..N).
+    float* bias_lds = (float*)(smem + P8_RING_BYTES);
+    for (int i = tid; i < p.N; i += NT256_THREADS) bias_lds[i] = p.bias ? p.bias[i] : 0.f;
+    Nt256Epi<ACT, AUX, 16384, true> epi(p, smem, bias_lds, wid, lane);
+
+    // prologue: half-tiles 0..5 in flight, 0..2 (the first K-tile's B0, B1, A0) landed and published
+    issue(0); issue(1); issue(2); issue(3); issue(0); issue(1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind
+    int c_par = 0;
+    int relax = 0;
+    bool eb = false;       // the previous tile's epilogue left exactly 16 stores behind the DMA that was already in flight
+#define P8_LDS(off) (*(const bf16x8*)(smem + (off)))
+    // The MFMAs are pure register operations: nothing but data dependences keeps them between the two barriers of their phase.  Both
+    // barriers are therefore inline asm that "modifies" the phase's accumulators (and clobbers memory, which pins the LDS reads and
+    // the DMA issue on their side of it).
+#define P8_COMPUTE(i_)                                                                                                   \
+    asm volatile("s_barrier\n\ts_setprio 1" : "+v"(acc[i_][0]), "+v"(acc[i_][1])::"memory");                             \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                                   \
+        acc[i_][0] = mfma32(fb0[kk], fa[kk], acc[i_][0]);                                                                \
+        acc[i_][1] = mfma32(fb1[kk], fa[kk], acc[i_][1]);                                                                \
+    }                                                                                                                    \
+    asm volatile("s_setprio 0\n\ts_barrier" : "+v"(acc[i_][0]), "+v"(acc[i_][1])::"memory");
+
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        int m0, n0;
+        tile_origin(ti, m0, n0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg)
-                    bias4[j][rg] = p.bias ? *(const f32x4*)(p.bias + n0 + wn * 64 + j * 32 + 8 * rg + 4 * fh) : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma clang loop unroll(disable)
+        for (int kt = 0; kt < nk; ++kt) {
+            const uint32_t kbase = (uint32_t)c_par * 65536u;
+            c_par ^= 1;
+            // ---- phase 0: both B half-tiles + A row block 0
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + wm * 128 + i * 32 + fr;
-                const int mc = min(m, p.M - 1);
-                if (LDS_AUX && i + 1 < 4) load_aux(i + 1, auxrm[(i + 1) & 1], m0, n0);
-                if (HAS_BITS && i + 1 < 4) load_bits(i + 1, mbits[(i + 1) & 1], m0, n0);
-                if (LDS_AUX) {
+            for (int kk = 0; kk < 4; ++kk) fb0[kk] = P8_LDS(kbase + rb[kk]);
 #pragma unroll
-                    for (int it = 0; it < 4; ++it) *(u32x4*)(Es + it * 1024 + e_rd) = auxrm[i & 1][it];
-                    __builtin_amdgcn_wave_barrier();
-                }
-                unsigned obw[2] = {0u, 0u};       // sign bits of this lane's 2 x 16 outputs, at their column positions
+            for (int kk = 0; kk < 4; ++kk) fb1[kk] = P8_LDS(kbase + 16384 + rb[kk]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int nb = n0 + wn * 64 + j * 32;
-                    u32x2 pk[4];
+            for (int kk = 0; kk < 4; ++kk) fa[kk] = P8_LDS(kbase + ra[kk]);
+            issue(2);
+            P8_COMPUTE(0)
+            // ---- phase 1
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const int n = nb + 8 * rg + 4 * fh;
-                        float v[4];
+            for (int kk = 0; kk < 4; ++kk) fa[kk] = P8_LDS(kbase + 4096 + ra[kk]);
+            issue(3);
+            if (!d_live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tail of this workgroup's stream: nothing is issued any more
+            else if (eb || relax > 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");      // 8 + the epilogue's 16 stores (VM ops retire in order)
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            eb = false;
+            P8_COMPUTE(1)
+            // ---- phase 2
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = acc[i][j][rg * 4 + e] * p.alpha + bias4[j][rg][e];
-                            if (ACT == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
-                            else if (ACT == ACT_GELU) v[e] = gelu_f(v[e]);
-                        }
-                        if (p.drop.thr) {      // wave-uniform
-                            const unsigned keep = drop_keep4(p.drop, (unsigned long long)m * p.drop.row_mult * p.N + n);
+            for (int kk = 0; kk < 4; ++kk) fa[kk] = P8_LDS(kbase + 16384 + ra[kk]);
+            issue(0);
+            P8_COMPUTE(2)
+            // ---- phase 3
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = ((keep >> e) & 1u) ? v[e] * p.drop.scale : 0.f;
-                        }
-                        if (HAS_MASK) {
-                            const u32x2 mk = HAS_RES ? *(const u32x2*)(p.relu_mask + (size_t)mc * p.ldm + n) : *(const u32x2*)(Es + e_wr + (((j * 4 + rg) ^ e_sw) << 4));
-                            if (!(bf_lo(mk[0]) > 0.f)) v[0] = 0.f;
-                            if (!(bf_hi(mk[0]) > 0.f)) v[1] = 0.f;
-                            if (!(bf_lo(mk[1]) > 0.f)) v[2] = 0.f;
-                            if (!(bf_hi(mk[1]) > 0.f)) v[3] = 0.f;
-                        }
-                        if (HAS_BITS) {
-                            const unsigned nib = mbits[i & 1][j] >> (8 * rg + 4 * fh);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (!((nib >> e) & 1u)) v[e] = 0.f;
-                        }
-                        if (HAS_RES) {
-                            const u32x2 rs = *(const u32x2*)(Es + e_wr + (((j * 4 + rg) ^ e_sw) << 4));
-                            v[0] += bf_lo(rs[0]); v[1] += bf_hi(rs[0]); v[2] += bf_lo(rs[1]); v[3] += bf_hi(rs[1]);
-                        }
-                        pk[rg][0] = pack_bf2(v[0], v[1]);
-                        pk[rg][1] = pack_bf2(v[2], v[3]);
-                        *(u32x2*)(Es + e_wr + (((j * 4 + rg) ^ e_sw) << 4)) = pk[rg];
-                        if (ACT == ACT_RELU && AUX == 0) {   // outputs are >= 0: "positive" == non-zero magnitude bits of the rounded value
-                            const unsigned nib = ((pk[rg][0] & 0x7fffu) ? 1u : 0u) | ((pk[rg][0] & 0x7fff0000u) ? 2u : 0u) |
-                                                 ((pk[rg][1] & 0x7fffu) ? 4u : 0u) | ((pk[rg][1] & 0x7fff0000u) ? 8u : 0u);
-                            obw[j] |= nib << (8 * rg + 4 * fh);
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const u32x4 w = *(const u32x4*)(Es + it * 1024 + e_rd);
-                    const int mr = m0 + wm * 128 + i * 32 + it * 8 + (lane >> 3);
-                    if (p.dbg & 1) { asm volatile("" ::"v"(w)); }
-                    else if (mr < p.M) *(u32x4*)(C + (size_t)mr * p.ldc + n0 + wn * 64 + (lane & 7) * 8) = w;
-                }
-                if (ACT == ACT_RELU && AUX == 0 && p.bits_out) {
-                    // lanes fr and fr+32 hold the two interleaved nibble sets of row fr: merge, then ONE 8-byte store per row (store
-                    // instructions, not bytes, are what the CU's store path charges for)
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(obw[0], obw[0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(obw[1], obw[1], false, false);
-                    const u32x2 ob = {obw[0] | s0[1], obw[1] | s1[1]};
-                    if (fh == 0 && m < p.M) *(u32x2*)(p.bits_out + relu_bits_word(m, n0 + wn * 64, p.N)) = ob;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
+            for (int kk = 0; kk < 4; ++kk) fa[kk] = P8_LDS(kbase + 16384 + 4096 + ra[kk]);
+            if (kt == nk - 1) epi.prefetch0(m0, n0);
+            issue(1);
+            if (!d_live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (relax > 0) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");      // TIMING-ONLY experiment (dbg & 4): pretend the epilogue's stores need not complete
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            --relax;
+            P8_COMPUTE(3)
         }
-        prev_full = (m0 + 256 <= p.M) && wave_cols_valid;      // exactly 16 stores were issued behind this wave's in-flight DMA group
+        if (ti == my_tiles - 1 && wm == 0) __builtin_amdgcn_s_barrier();      // pairs with group 1's last barrier
+        epi.Es = smem + ((c_par ^ 1) * 4 + 2) * 16384 + wrow_off;
+        eb = epi.run(acc, m0, n0);
+        relax = (p.dbg & 4) ? ((p.dbg & 8) ? 4 : 2) : 0;
     }
+#undef P8_LDS
+#undef P8_COMPUTE
+}
+
+template <int ACT, int AUX>
+static int launch_nt8p_inst(const GemmNtArgs& p, int grid, hipStream_t stream) {
+    const size_t lds = (size_t)P8_RING_BYTES + 32768;   // 160 KiB: ring + bias table (N <= 8192)
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt8p_bf16_kernel<ACT, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_nt8p_bf16_kernel<ACT, AUX>), dim3(grid), dim3(NT256_THREADS), lds, stream, p);
+    return svla_launch_status();
 }
 
 template <int ACT, int AUX>
@@ -545,28 +785,42 @@ static int launch_nt256_inst(const GemmNtArgs& p, int grid, hipStream_t stream) 
     hipLaunchKernelGGL((gemm_nt256k64_bf16_kernel<ACT, AUX>), dim3(grid), dim3(NT256_THREADS), lds, stream, p);
     return svla_launch_status();
 }
+// Kernel choice (measured, tools/ab_gemm.py, profiles/r03_nt_ab.txt): the 8-phase kernel's main loop is 8-10 % faster everywhere, its epilogue
+// (issued behind a 6-half-tile-deep DMA stream) slightly slower, so it wins where the K loop is long or the tile count per A panel is
+// 4 or 6 and loses a few per cent at N = 512 / 2048 with K = 512.  dbg bits 128 / 256 force the 2-buffer / the 8-phase kernel.
+static inline bool nt_use_8p(const GemmNtArgs& p) {
+    if (p.N > 8192 || (p.dbg & 128)) return false;
+    if (p.dbg & 256) return true;
+    return p.K >= 1024 || p.N == 1024 || p.N == 1536;
+}
+#define NT256_CASE(A_, X_) return nt_use_8p(p) ? launch_nt8p_inst<A_, X_>(p, grid, stream) : launch_nt256_inst<A_, X_>(p, grid, stream)
 static int launch_nt256(const GemmNtArgs& p, int grid, hipStream_t stream) {
     const int aux = (p.residual ? 1 : 0) | (p.relu_mask ? 2 : 0);
-    if (p.bits_in) return p.act == ACT_NONE ? launch_nt256_inst<0, 4>(p, grid, stream) : SVLA_EINVAL;
+    if (p.bits_in) {
+        if (p.act != ACT_NONE) return SVLA_EINVAL;
+        NT256_CASE(0, 4);
+    }
     switch (p.act * 4 + aux) {
-        case 0: return launch_nt256_inst<0, 0>(p, grid, stream);
-        case 1: return launch_nt256_inst<0, 1>(p, grid, stream);
-        case 2: return launch_nt256_inst<0, 2>(p, grid, stream);
-        case 3: return launch_nt256_inst<0, 3>(p, grid, stream);
-        case 4: return launch_nt256_inst<1, 0>(p, grid, stream);
-        case 5: return launch_nt256_inst<1, 1>(p, grid, stream);
-        case 6: return launch_nt256_inst<1, 2>(p, grid, stream);
-        case 7: return launch_nt256_inst<1, 3>(p, grid, stream);
-        case 8: return launch_nt256_inst<2, 0>(p, grid, stream);
-        case 9: return launch_nt256_inst<2, 1>(p, grid, stream);
-        case 10: return launch_nt256_inst<2, 2>(p, grid, stream);
-        case 11: return launch_nt256_inst<2, 3>(p, grid, stream);
+        case 0: NT256_CASE(0, 0);
+        case 1: NT256_CASE(0, 1);
+        case 2: NT256_CASE(0, 2);
+        case 3: NT256_CASE(0, 3);
+        case 4: NT256_CASE(1, 0);
+        case 5: NT256_CASE(1, 1);
+        case 6: NT256_CASE(1, 2);
+        case 7: NT256_CASE(1, 3);
+        case 8: NT256_CASE(2, 0);
+        case 9: NT256_CASE(2, 1);
+        case 10: NT256_CASE(2, 2);
+        case 11: NT256_CASE(2, 3);
         default: return SVLA_EINVAL;
     }
 }
+#undef NT256_CASE
 
 static int g_force_small_tile = 0, g_dbg = 0;
-// on = 0/1: normal dispatch / force the 128x128 kernels; on = 10 + f: timing-only ablation flags f of the 256-tile kernel
+// on = 0/1: normal dispatch / force the 128x128 kernels; on = 10 + f: flags f of the 256-tile kernels -- timing-only ablations 1 / 2 / 64,
+// 128 / 256 = force the 2-buffer kernel (gemm_nt256k64) / the 8-phase kernel (gemm_nt8p) (A/B comparisons)
 extern "C" int svla_gemm_force_small_tile(int on) {
     if (on >= 10) { g_dbg = on - 10; g_force_small_tile = 0; }
     else { g_dbg = 0; g_force_small_tile = on; }

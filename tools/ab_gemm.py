@@ -27,21 +27,26 @@ for (M, n, k) in [(256 * 300 + 77, 512, 512), (256 * 270, 1536, 128), (256 * 700
     print(f"checked M={M} N={n} K={k}", flush=True)
 sel(0)
 
-M = 8192 * 181
-for (n, k) in [(512, 512), (1536, 512), (2048, 512), (512, 2048)]:
-    A = torch.randn(M, k, device="cuda").to(torch.bfloat16); B = torch.randn(n, k, device="cuda").to(torch.bfloat16)
+M = int(os.environ.get("AB_ROWS", 16384)) * 181
+for (n, k, flav) in [(512, 512, "plain"), (512, 512, "res"), (1536, 512, "bias"), (2048, 512, "relu"), (512, 2048, "res"), (512, 1536, "res"), (1024, 512, "bias")]:
+    A = torch.randn(M, k, device="cuda").to(torch.bfloat16); B = (torch.randn(n, k, device="cuda") * 0.05).to(torch.bfloat16)
     out = torch.empty(M, n, device="cuda", dtype=torch.bfloat16)
+    bias = torch.randn(n, device="cuda")
+    kw = {}
+    if flav == "res": kw = dict(bias=bias, residual=torch.randn(M, n, device="cuda").to(torch.bfloat16))
+    elif flav == "bias": kw = dict(bias=bias)
+    elif flav == "relu": kw = dict(bias=bias, act=1, relu_bits_out=torch.empty(ops.relu_bits_bytes(M, n), device="cuda", dtype=torch.uint8))
     res = {}
     for rep in range(3):
         for abl in variants:
             sel(abl)
-            for _ in range(2): ops.gemm_nt(A, B, M, n, k, out=out)
+            for _ in range(2): ops.gemm_nt(A, B, M, n, k, out=out, **kw)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(10): ops.gemm_nt(A, B, M, n, k, out=out)
+            for _ in range(10): ops.gemm_nt(A, B, M, n, k, out=out, **kw)
             e1.record(); torch.cuda.synchronize()
             res.setdefault(abl, []).append(e0.elapsed_time(e1) / 10)
     sel(0)
-    print(f"N={n} K={k}: " + "  ".join(f"v{a}: {min(t):.3f} ms ({2*M*n*k/min(t)/1e9:.0f} TF)" for a, t in res.items()), flush=True)
-    del A, B, out
+    print(f"N={n} K={k} {flav}: " + "  ".join(f"v{a}: {min(t):.3f} ms ({2*M*n*k/min(t)/1e9:.0f} TF)" for a, t in res.items()), flush=True)
+    del A, B, out, kw
