@@ -706,6 +706,7 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt8p_bf16_kernel(GemmNt
     }                                                                                                                    \
     asm volatile("s_setprio 0\n\ts_barrier" : "+v"(acc[i_][0]), "+v"(acc[i_][1])::"memory");
 
+    long long cyc_main = 0, cyc_epi = 0, t_mark = (p.dbg & 16) ? __builtin_readcyclecounter() : 0;      // timing-only instrumentation (dbg & 16)
     for (int ti = 0; ti < my_tiles; ++ti) {
         int m0, n0;
         tile_origin(ti, m0, n0);
@@ -754,9 +755,15 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt8p_bf16_kernel(GemmNt
             P8_COMPUTE(3)
         }
         if (ti == my_tiles - 1 && wm == 0) __builtin_amdgcn_s_barrier();      // pairs with group 1's last barrier
+        if (p.dbg & 16) { const long long t = __builtin_readcyclecounter(); cyc_main += t - t_mark; t_mark = t; }
         epi.Es = smem + ((c_par ^ 1) * 4 + 2) * 16384 + wrow_off;
         eb = epi.run(acc, m0, n0);
         relax = (p.dbg & 4) ? ((p.dbg & 8) ? 4 : 2) : 0;
+        if (p.dbg & 16) { const long long t = __builtin_readcyclecounter(); cyc_epi += t - t_mark; t_mark = t; }
+    }
+    if ((p.dbg & 16) && tid == 0) {      // cycles per K-tile of the main loop, cycles per tile of the epilogue, into the first floats of C
+        ((float*)p.C)[blockIdx.x * 2] = (float)cyc_main / (float)(my_tiles * nk);
+        ((float*)p.C)[blockIdx.x * 2 + 1] = (float)cyc_epi / (float)my_tiles;
     }
 #undef P8_LDS
 #undef P8_COMPUTE
@@ -772,6 +779,329 @@ static int launch_nt8p_inst(const GemmNtArgs& p, int grid, hipStream_t stream) {
     }
     hipLaunchKernelGGL((gemm_nt8p_bf16_kernel<ACT, AUX>), dim3(grid), dim3(NT256_THREADS), lds, stream, p);
     return svla_launch_status();
+}
+
+// =================================================================================================
+// "Rotating" 8-phase NT kernel: gemm_nt8p's operand pipeline WITHOUT an epilogue phase.
+// Why: measured with in-kernel cycle counters (tools/ab_gemm.py, AB_CYCLES=1), a tile's 128-KiB store burst costs its own 6-11 k
+// cycles AND ~1.2 k cycles per K-tile of the following main loop (the CU's vector-memory pipeline is in order: the operand DMA of
+// the next tile queues behind the stores), plus ~4.7 k cycles of pipeline restart per tile -- together 30-45 % of the kernel.
+// Idea: the reduction order inside a tile is free.  A workgroup keeps ONE n-tile for its whole life and walks m-blocks; row block
+// (wave group g, accumulator block i) of the wave layout starts its K loop at K-tile g * nk/2 + i and wraps around, so at any
+// global step s every block consumes the SAME weight slice W[n-tile, k(s) = s mod nk] (the DMA traffic is exactly gemm_nt8p's), but
+// the eight row blocks finish their output tiles at eight different steps.  A finished 32 x 64 slab per wave is drained while the
+// wave's other three blocks keep accumulating: scale / activation / dropout / bf16 packing interleaved with the MFMAs of the next
+// three phases, transposition through LDS, 4 global stores two phases later -- then the block re-initialises its accumulators
+// (from the LDS-resident bias table: the bias add costs nothing) and starts the next m-block.  No store bursts, no pipeline
+// restarts, the memory pipeline sees a steady mix of operand loads and 16 KiB of stores per K-tile.
+// Restrictions (others take the kernels above): no residual / mask operand, N % 256 == 0, 32 % (N / 256) == 0, (K / 64) % 8 == 0, bias => alpha == 1.
+#define R8_RING 131072
+#define R8_STAGE_BYTES 32768      // 8 x 4 KiB
+// drain schedule of one wave group inside its period (position pi = local step mod nk, phase p): row block b finishes its tile in
+// (pi = b-1, phase b), is packed in the next three compute segments (stages 1-3), re-initialised in the load segment of (pi = b, phase b)
+// and stored behind the MFMAs of that phase (stage 4).  With L = 4 pi + p: stage k of block b sits at L = 5 b - 4 + k.
+__host__ __device__ constexpr int r8_blk(int L) { return (L + 3) >= 0 ? (L + 3) / 5 : -1; }
+__host__ __device__ constexpr int r8_stage(int L) {
+    const int bk = r8_blk(L);
+    if (bk < 0 || bk > 3) return 0;
+    const int k = L + 4 - 5 * bk;
+    return (k >= 1 && k <= 4) ? k : 0;
+}
+template <int ACT, bool DROP, bool BITS>
+__global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt8r_bf16_kernel(GemmNtArgs p) {
+    p.drop = drop_resolve(p.drop);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = __builtin_amdgcn_readfirstlane(wid >> 2), wn = __builtin_amdgcn_readfirstlane(wid & 3);
+    const int ntn = p.N >> 8, MT = (p.M + 255) >> 8;
+    const int xcd = blockIdx.x & 7, lw = blockIdx.x >> 3, mslots = (int)(gridDim.x >> 3) / ntn;
+    if (lw >= mslots * ntn) return;
+    const int n0 = (lw % ntn) * 256, mslot = lw / ntn;
+    // m-blocks of this workgroup: mb(t) = (t * mslots + mslot) * 8 + xcd, t = 0 .. T-1 (the workgroups of one XCD that differ only in
+    // the n-tile walk the same m-blocks in step: the A panel is fetched from HBM once per XCD)
+    const int mb0 = mslot * 8 + xcd, mbs = mslots * 8;
+    const int T = mb0 < MT ? (MT - mb0 + mbs - 1) / mbs : 0;
+    if (T <= 0) return;
+    const int nk = p.K / BK64, nkh = nk >> 1;
+    // row block (g, i) starts its first tile at global step g * nk/2 + i: the two wave groups half a period apart, a group's blocks one step apart
+    const int total_steps = T * nk + nkh + 4;
+    auto tile_m0 = [&](int t) { return (mb0 + min(max(t, 0), T - 1) * mbs) * 256; };      // clamped: idle blocks read valid rows
+
+    // ---- DMA side: gemm_nt8p's ring, half-tile composition, issue order and waits.  Half-tile types per step: 0 = B0, 1 = B1,
+    // 2 = A0 (rows g*128 + 0..63 of both groups = row blocks 0, 1), 3 = A1 (row blocks 2, 3).  Wave w fills half-tile rows w*16 .. w*16+15,
+    // which for A half h belong to row block (w >> 2, 2h + ((w >> 1) & 1)): two blocks per wave, each with its own current m-block.
+    const int wrow_off = __builtin_amdgcn_readfirstlane(wid * 2048);
+    uint32_t offB[2][2], offA[2][2];          // [half][j]
+    const char* b_base = (const char*)p.B + (size_t)n0 * p.ldb * 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rho = wid * 16 + (lane >> 3) + 8 * j;
+        const int csw = ((lane & 7) ^ ((rho >> 1) & 7)) * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) offB[h][j] = (uint32_t)((((rho >> 5) * 64 + h * 32 + (rho & 31)) * p.ldb + csw) * 2);
+    }
+    const char* a_base[2];
+    int d_rem[2], d_tb[2];          // DMA cursor of the wave's block of A half h: steps left in its current tile, its tile index
+    auto set_dma_block = [&](int h) {
+        const int m0d = __builtin_amdgcn_readfirstlane(tile_m0(d_tb[h]));
+        a_base[h] = (const char*)p.A + (size_t)m0d * p.lda * 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rho = wid * 16 + (lane >> 3) + 8 * j;
+            const int csw = ((lane & 7) ^ ((rho >> 1) & 7)) * 8;
+            const int arow = (rho >> 6) * 128 + h * 64 + (rho & 63);
+            offA[h][j] = (uint32_t)(((min(m0d + arow, p.M - 1) - m0d) * p.lda + csw) * 2);      // M tail: clamp (never stored)
+        }
+    };
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        d_rem[h] = __builtin_amdgcn_readfirstlane((wid >> 2) * nkh + 2 * h + ((wid >> 1) & 1));      // idle steps before the block's first tile
+        d_tb[h] = -1;
+        if (d_rem[h] == 0) { d_tb[h] = 0; d_rem[h] = nk; }
+        set_dma_block(h);
+    }
+    int d_step = 0, d_kt = 0, d_par = 0;
+    auto issue = [&](const int ty) {
+        if (d_step < total_steps) {
+            const char* base = ty >= 2 ? a_base[ty - 2] : b_base;
+            const uint32_t kb = (uint32_t)(d_kt * BK64 * 2);
+            char* dst = smem + (d_par * 4 + ty) * 16384 + wrow_off;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t off = (ty == 0 ? offB[0][j] : ty == 1 ? offB[1][j] : ty == 2 ? offA[0][j] : offA[1][j]) + kb;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
+                                                 (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+            }
+        }
+        if (ty == 3) {          // the step's last half-tile: advance the DMA cursor
+            d_par ^= 1;
+            ++d_step;
+            if (++d_kt == nk) d_kt = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (--d_rem[h] == 0) { ++d_tb[h]; d_rem[h] = nk; set_dma_block(h); }
+        }
+    };
+
+    // ---- consumer side.  Fragment read address of k-step kk: B row (wn*32 + fr), physical chunk (2 kk + fh) ^ sw = 2 kk ^ (sw ^ fh), i.e.
+    // rb0 ^ (kk << 5); the A rows of block i (half-tile i >> 1, rows g*64 + (i & 1)*32 + fr) sit a wave-uniform distance further.
+    uint32_t rb0;
+    {
+        const int fr = lane & 31, fh = lane >> 5;
+        rb0 = (uint32_t)((wn * 32 + fr) * 128 + ((fh ^ ((fr >> 1) & 7)) << 4));
+    }
+#define RB(kk) (rb0 ^ ((kk) << 5))
+    const uint32_t a_minus_b = (uint32_t)(32768 + g * 8192 - wn * 4096);
+    f32x16 acc[4][2];
+    bf16x8 fa[4], fb0[4], fb1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // LDS behind the ring: one 4-KiB staging buffer per wave.  The bias of the wave's 64 columns lives in ONE VGPR (lane l: column l) and is
+    // broadcast into the accumulator layout with ds_bpermute when a block starts a new output tile (so the bias add itself costs nothing).
+    const int bias_v = p.bias ? __float_as_int(p.bias[n0 + wn * 64 + lane]) : 0;
+    char* Es = smem + R8_RING + wid * 4096;
+    // Every lane-dependent value of the drain code is derived from `lo`, an opaque per-step copy of the lane id: otherwise hipcc hoists
+    // ~35 VGPRs of loop-invariant address arithmetic out of the step loop and the main loop spills (vmcnt-counted scratch traffic).
+    int lo = lane;
+#define LO_FR (lo & 31)
+#define LO_FH (lo >> 5)
+    int pi = g ? nkh : 0;          // position of this wave group in its period
+    int tcur = -1;                 // tile index row block 0 of the group is working on (blocks 1-3 follow 1-3 steps later)
+    int d_m0 = 0;                  // first row of this group's 128 rows in the output tile being drained
+    bool d_valid = false, d_full = false;
+    unsigned obw[2] = {0u, 0u};
+    unsigned long long d_e0 = 0;      // dropout element index of (this lane's row of block 0, the wave's first column + 4*fh) of that tile
+    int sage = 0;          // phases for which the last store group may still be outstanding behind the DMA a wait covers
+    bf16_t* C = (bf16_t*)p.C;
+
+    // prologue: half-tiles 0..5 in flight, 0..2 landed and published
+    issue(0); issue(1); issue(2); issue(3); issue(0); issue(1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (g == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind
+    int c_par = 0;
+    long long cyc_wait = 0, t_w0 = 0;      // timing-only instrumentation (dbg & 16); dbg & 32: never relax a wait for stores in flight
+    const long long t_begin = (p.dbg & 16) ? __builtin_readcyclecounter() : 0;
+
+#define R8_LDS(off) (*(const bf16x8*)(smem + (off)))
+    // one (j, rg) group of 4 outputs of block BLK: scale, activation, dropout, bf16 packing into the staging buffer, ReLU sign bits
+#define R8_GROUP(BLK, GI)                                                                                                              \
+    {                                                                                                                                  \
+        constexpr int j_ = (GI) >> 2, rg_ = (GI) & 3;                                                                                  \
+        float v_[4];                                                                                                                   \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                                \
+            v_[e] = acc[BLK][j_][rg_ * 4 + e] * p.alpha;                                                                               \
+            if (ACT == ACT_RELU) v_[e] = fmaxf(v_[e], 0.f);                                                                            \
+            else if (ACT == ACT_GELU) v_[e] = gelu_f(v_[e]);                                                                           \
+        }                                                                                                                              \
+        if (DROP) {                                                                                                                    \
+            const unsigned keep_ = drop_keep4(p.drop, d_e0 + (unsigned)((BLK) * 32) * (unsigned long long)(p.drop.row_mult * p.N) + (j_ * 32 + 8 * rg_)); \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) v_[e] = ((keep_ >> e) & 1u) ? v_[e] * p.drop.scale : 0.f;                    \
+        }                                                                                                                              \
+        const unsigned pk0_ = pack_bf2(v_[0], v_[1]), pk1_ = pack_bf2(v_[2], v_[3]);                                                   \
+        *(u32x2*)(Es + (LO_FR * 128 + LO_FH * 8) + (((GI) ^ (lo & 7)) << 4)) = u32x2{pk0_, pk1_};                                      \
+        if (BITS) {                                                                                                                    \
+            const unsigned t0_ = pk_min_u16(pk0_ & 0x7fff7fffu, 0x00010001u), t1_ = pk_min_u16(pk1_ & 0x7fff7fffu, 0x00010001u);       \
+            obw[j_] |= (((t0_ | (t0_ >> 15)) & 3u) | (((t1_ | (t1_ >> 15)) & 3u) << 2)) << (8 * rg_ + 4 * LO_FH);                      \
+        }                                                                                                                              \
+    }
+#define R8_STORE(BLK)                                                                                                                  \
+    if (d_valid) {                                                                                                                     \
+        _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                                             \
+            const u32x4 w_ = *(const u32x4*)(Es + it * 1024 + ((lo >> 3) * 128 + (((lo & 7) ^ (lo >> 3)) << 4)));                      \
+            const int mr = d_m0 + (BLK) * 32 + it * 8 + (lo >> 3);                                                                     \
+            if (mr < p.M) *(u32x4*)(C + (size_t)mr * p.ldc + n0 + wn * 64 + (lo & 7) * 8) = w_;                                        \
+        }                                                                                                                              \
+        if (BITS) {                                                                                                                    \
+            const auto s0 = __builtin_amdgcn_permlane32_swap(obw[0], obw[0], false, false);                                            \
+            const auto s1 = __builtin_amdgcn_permlane32_swap(obw[1], obw[1], false, false);                                            \
+            const u32x2 ob = {obw[0] | s0[1], obw[1] | s1[1]};                                                                         \
+            const int m = d_m0 + (BLK) * 32 + LO_FR;                                                                                   \
+            if (LO_FH == 0 && m < p.M) *(u32x2*)(p.bits_out + relu_bits_word(m, n0 + wn * 64, p.N)) = ob;                              \
+        }                                                                                                                              \
+        sage = d_full ? 4 : 0;                                                                                                         \
+    }
+#define R8_MF(I_, KK, J) acc[I_][J] = mfma32((J) ? fb1[KK] : fb0[KK], fa[KK], acc[I_][J]);
+#define R8_PIN __builtin_amdgcn_sched_barrier(0);
+    // start of an output tile: accumulators = bias (column j*32 + 8*(r>>2) + 4*fh + (r&3) of the wave's 64; bias_v == 0 without a bias)
+#define R8_INIT(BLK)                                                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                                      \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                                 \
+            acc[BLK][j][r] = __int_as_float(__builtin_amdgcn_ds_bpermute((j * 32 + 8 * (r >> 2) + (r & 3) + 4 * LO_FH) << 2, bias_v));
+    // Compute segment of (period position PI, phase I_): the 8 MFMAs of block I_ in ONE straight-line block, with the statically scheduled
+    // drain work of this position pinned between MFMA pairs (a pair gives the packing of one 4-output group 64 matrix-pipe cycles of cover).
+#define R8_COMPUTE(PI, I_)                                                                                                             \
+    {                                                                                                                                  \
+        constexpr int L_ = 4 * (PI) + (I_), st_ = (PI) > 3 ? 0 : r8_stage(L_), bk_ = st_ ? r8_blk(L_) : 0;                             \
+        constexpr int g0_ = st_ == 1 ? 0 : st_ == 2 ? 3 : 6;                                                                           \
+        if (st_ == 1) { obw[0] = obw[1] = 0u; }                                                                                        \
+        asm volatile("s_barrier\n\ts_setprio 1" ::"v"(acc[I_][0]), "v"(acc[I_][1]) : "memory");      /* input-only: the MFMAs kill this value */ \
+        R8_MF(I_, 0, 0) R8_MF(I_, 0, 1)                                                                                                \
+        if (st_ >= 1 && st_ <= 3) { R8_PIN R8_GROUP(bk_, g0_) R8_PIN }                                                                 \
+        R8_MF(I_, 1, 0) R8_MF(I_, 1, 1)                                                                                                \
+        if (st_ >= 1 && st_ <= 3) { R8_PIN R8_GROUP(bk_, g0_ + 1) R8_PIN }                                                             \
+        R8_MF(I_, 2, 0) R8_MF(I_, 2, 1)                                                                                                \
+        if (st_ == 1 || st_ == 2) { R8_PIN R8_GROUP(bk_, (g0_ + 2) & 7) R8_PIN }                                                       \
+        R8_MF(I_, 3, 0) R8_MF(I_, 3, 1)                                                                                                \
+        if (st_ == 4) { R8_PIN R8_STORE(bk_) }                                                                                         \
+        asm volatile("s_setprio 0\n\ts_barrier" ::"v"(acc[I_][0]), "v"(acc[I_][1]) : "memory");                                        \
+    }
+    // One K step at period position PI (compile time; 9 = a quiet position): gemm_nt8p's four phases.  Block I_ starts a new tile in
+    // (PI == I_, phase I_): 32 ds_bpermute in that load segment, retired with the fragment reads in front of the phase's MFMAs.
+#define R8_WAIT_P1                                                                                                                     \
+    if (p.dbg & 16) t_w0 = __builtin_readcyclecounter();                                                                               \
+    if (!live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                        \
+    else if (sage >= 1 && !(p.dbg & 32)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      /* 8 + the 4 stores of the last drain (VM ops retire in order) */ \
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                                              \
+    if (p.dbg & 16) cyc_wait += __builtin_readcyclecounter() - t_w0;
+#define R8_WAIT_P3                                                                                                                     \
+    if (p.dbg & 16) t_w0 = __builtin_readcyclecounter();                                                                               \
+    if (!live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                        \
+    else if (sage >= 2 && !(p.dbg & 32)) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                             \
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                                              \
+    if (p.dbg & 16) cyc_wait += __builtin_readcyclecounter() - t_w0;
+#define R8_STEP(PI)                                                                                                                    \
+    {                                                                                                                                  \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) fb0[kk] = R8_LDS(kbase + RB(kk));                                             \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) fb1[kk] = R8_LDS(kbase + 16384 + RB(kk));                                     \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) fa[kk] = R8_LDS(kbase_a + RB(kk));                                            \
+        issue(2);                                                                                                                      \
+        if ((PI) == 0) { R8_INIT(0) }                                                                                                  \
+        if (sage > 0) --sage;                                                                                                          \
+        R8_COMPUTE(PI, 0)                                                                                                              \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) fa[kk] = R8_LDS(kbase_a + 4096 + RB(kk));                                     \
+        issue(3);                                                                                                                      \
+        if ((PI) == 1) { R8_INIT(1) }                                                                                                  \
+        R8_WAIT_P1                                                                                                                     \
+        if (sage > 0) --sage;                                                                                                          \
+        R8_COMPUTE(PI, 1)                                                                                                              \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) fa[kk] = R8_LDS(kbase_a + 16384 + RB(kk));                                    \
+        issue(0);                                                                                                                      \
+        if ((PI) == 2) { R8_INIT(2) }                                                                                                  \
+        if (sage > 0) --sage;                                                                                                          \
+        R8_COMPUTE(PI, 2)                                                                                                              \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) fa[kk] = R8_LDS(kbase_a + 16384 + 4096 + RB(kk));                             \
+        issue(1);                                                                                                                      \
+        if ((PI) == 3) { R8_INIT(3) }                                                                                                  \
+        R8_WAIT_P3                                                                                                                     \
+        if (sage > 0) --sage;                                                                                                          \
+        R8_COMPUTE(PI, 3)                                                                                                              \
+    }
+
+#pragma clang loop unroll(disable)
+    for (int s = 0; s < total_steps; ++s) {
+        const uint32_t kbase = (uint32_t)c_par * 65536u, kbase_a = kbase + a_minus_b;
+        c_par ^= 1;
+        const bool live = d_step < total_steps;
+        asm volatile("" : "+v"(lo));
+        if (pi == nk - 1) {          // block 0 finishes the group's current tile in this step: from here on, this is the tile being drained
+            d_valid = tcur >= 0 && tcur < T;
+            d_m0 = tile_m0(tcur) + g * 128;
+            d_full = d_m0 + 128 <= p.M;
+            if (DROP) d_e0 = (unsigned long long)(d_m0 + LO_FR) * (unsigned long long)(p.drop.row_mult * p.N) + (unsigned)(n0 + wn * 64 + 4 * LO_FH);
+            R8_STEP(-1)
+        } else if (pi == 0) {
+            ++tcur;
+            R8_STEP(0)
+        } else if (pi == 1) {
+            R8_STEP(1)
+        } else if (pi == 2) {
+            R8_STEP(2)
+        } else if (pi == 3) {
+            R8_STEP(3)
+        } else {
+            R8_STEP(9)
+        }
+        if (++pi == nk) pi = 0;
+    }
+    if (g == 0) __builtin_amdgcn_s_barrier();      // pairs with group 1's last barrier
+    if ((p.dbg & 16) && tid == 0) {      // cycles per step, cycles per step inside the two counted DMA waits, into the first floats of C
+        ((float*)p.C)[blockIdx.x * 2] = (float)(__builtin_readcyclecounter() - t_begin) / (float)total_steps;
+        ((float*)p.C)[blockIdx.x * 2 + 1] = (float)cyc_wait / (float)total_steps;
+    }
+#undef R8_LDS
+#undef RB
+#undef LO_FR
+#undef LO_FH
+#undef R8_GROUP
+#undef R8_STORE
+#undef R8_MF
+#undef R8_PIN
+#undef R8_INIT
+#undef R8_COMPUTE
+#undef R8_WAIT_P1
+#undef R8_WAIT_P3
+#undef R8_STEP
+}
+
+template <int ACT, bool DROP, bool BITS>
+static int launch_nt8r_inst(const GemmNtArgs& p, int n_cu, hipStream_t stream) {
+    const size_t lds = (size_t)R8_RING + R8_STAGE_BYTES;      // 160 KiB
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt8r_bf16_kernel<ACT, DROP, BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_nt8r_bf16_kernel<ACT, DROP, BITS>), dim3(n_cu), dim3(NT256_THREADS), lds, stream, p);
+    return svla_launch_status();
+}
+static int launch_nt8r(const GemmNtArgs& p, int n_cu, hipStream_t stream) {
+    const bool drop = p.drop.thr != 0, bits = p.act == ACT_RELU && p.bits_out;
+    switch (p.act) {
+        case ACT_NONE: return drop ? launch_nt8r_inst<ACT_NONE, true, false>(p, n_cu, stream) : launch_nt8r_inst<ACT_NONE, false, false>(p, n_cu, stream);
+        case ACT_RELU:
+            if (bits) return drop ? launch_nt8r_inst<ACT_RELU, true, true>(p, n_cu, stream) : launch_nt8r_inst<ACT_RELU, false, true>(p, n_cu, stream);
+            return drop ? launch_nt8r_inst<ACT_RELU, true, false>(p, n_cu, stream) : launch_nt8r_inst<ACT_RELU, false, false>(p, n_cu, stream);
+        default: return drop ? launch_nt8r_inst<ACT_GELU, true, false>(p, n_cu, stream) : launch_nt8r_inst<ACT_GELU, false, false>(p, n_cu, stream);
+    }
+}
+static inline bool nt_can_rotate(const GemmNtArgs& p) {
+    return !p.residual && !p.relu_mask && !p.bits_in && !p.out_f32 && (p.N % 256) == 0 && ((p.K / BK64) % 8) == 0 && (p.K % BK64) == 0 &&
+           (!p.bias || p.alpha == 1.f) && (32 % (p.N / 256)) == 0;
 }
 
 template <int ACT, int AUX>
@@ -848,6 +1178,11 @@ extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, lon
             if (n_cu < 8) n_cu = 8;
         }
         const int ntiles = ((M + 255) / 256) * ((N + 255) / 256);
+        // rotating kernel (no epilogue phase): needs enough m-blocks per workgroup to amortise its 7/8-tile start-up and drain
+        // (>= 6 m-blocks per workgroup; dbg bit 512 forces it for any size: tests)
+        if (nt_can_rotate(p) && !(g_dbg & (128 | 256)) && n_cu == 256 && ((g_dbg & 512) || (M + 255) / 256 >= 6 * 8 * (32 / (N / 256)))) {
+            return launch_nt8r(p, n_cu, (hipStream_t)stream);
+        }
         int grid = n_cu;                       // persistent: one 512-thread workgroup (160 KiB LDS) per CU
         while (grid > 8 && (grid / 8) * 8 > ntiles) grid -= 8;
         return launch_nt256(p, grid, (hipStream_t)stream);
@@ -996,6 +1331,7 @@ struct GemmTn256Args {
     float* dW; long ldw;
     float* db;
     int M, N, K, chunk_rows;
+    int dbg;      // timing-only ablations of gemm_tn8p: 64 = DMA stream + barriers alone, 32 = no DMA (fragment reads + MFMAs + barriers), 16 = nt loads
 };
 
 __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_tn256_bf16_kernel(GemmTn256Args p) {
@@ -1105,6 +1441,162 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_tn256_bf16_kernel(GemmT
     }
 }
 
+// =================================================================================================
+// 8-phase ("ping-pong") variant of the 256x256 weight-gradient kernel: same output tile, wave layout (2(n) x 4(k), 128 x 64 per
+// wave), fragment gathers and epilogue as gemm_tn256; the operand pipeline is the one of gemm_nt8p.  One reduction step (16 rows
+// of dY and X: 16 x 512 B + 16 x 512 B = one 16-KiB ring slot, filled by 2 DMA instructions per wave) is one phase:
+// [12 transposed fragment reads + DMA issue of step P+6] barrier [8 MFMAs] barrier, the two wave groups (n halves) one barrier
+// apart.  A slot is read in exactly one phase, so with 8 slots the DMA stream runs 6 steps (96 KiB) ahead; every wave waits for
+// its pieces of step P+1 at the end of load(P) (5 younger steps = 10 instructions may stay in flight).
+#define TNP_L 6
+__global__ void __launch_bounds__(NT256_THREADS, 2) gemm_tn8p_bf16_kernel(GemmTn256Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wn = wid >> 2, wk = __builtin_amdgcn_readfirstlane(wid & 3);
+    const int ntk = p.K / 256, ntile = (p.N / 256) * ntk;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = vid % ntile, chunk = vid / ntile;
+    const int n0 = (tile / ntk) * 256, k0 = (tile % ntk) * 256;
+    const int mbeg = chunk * p.chunk_rows;
+    const int mend = min(p.M, mbeg + p.chunk_rows);      // multiple of 64 (launcher)
+    const int nph = (mend - mbeg) / 16;
+    if (nph <= 0) return;
+
+    // DMA: wave w fills rows 2w, 2w+1 of the step's dY part (slot + 0) and of its X part (slot + 8192)
+    const int drow = wid * 2 + (lane >> 5);
+    const int dchunk = (lane & 31) ^ ((drow & 3) << 2);
+    const uint32_t offy = (uint32_t)((drow * p.ldy + n0 + dchunk * 8) * 2), offx = (uint32_t)((drow * p.ldx + k0 + dchunk * 8) * 2);
+    const char* ybase = (const char*)p.dY + (size_t)mbeg * p.ldy * 2;
+    const char* xbase = (const char*)p.X + (size_t)mbeg * p.ldx * 2;
+    const size_t ystep = (size_t)16 * p.ldy * 2, xstep = (size_t)16 * p.ldx * 2;
+    const int wrow_off = __builtin_amdgcn_readfirstlane(wid * 1024);
+    int dq = 0;
+    auto issue = [&]() {
+        if (dq < nph && !(p.dbg & 32)) {
+            char* dst = smem + (dq & 7) * 16384 + wrow_off;
+            if (p.dbg & 16) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ybase + offy),
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 2);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xbase + offx),
+                                                 (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 2);
+            } else {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ybase + offy),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xbase + offx),
+                                             (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
+            }
+            if (!(p.dbg & 8)) {      // timing-only (8): re-read the same 16 rows (operands served by the L2)
+                ybase += ystep;
+                xbase += xstep;
+            }
+        }
+        ++dq;
+    };
+    // fragment gather addresses inside a slot (see frag_tr256; rows r0 and r0 + 4 of the 16-row step)
+    uint32_t ay[4], ax[2];
+    {
+        const int pl = lane & 15, q = lane >> 4;
+        const int r0 = 8 * (q >> 1) + (pl >> 2);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int colq = wn * 128 + u * 32 + 16 * (q & 1) + 4 * (pl & 3);
+            ay[u] = (uint32_t)((r0 * 256 + (((colq >> 3) ^ ((r0 & 3) << 2)) << 3) + (colq & 7)) * 2);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int colq = wk * 64 + u * 32 + 16 * (q & 1) + 4 * (pl & 3);
+            ax[u] = (uint32_t)(8192 + (r0 * 256 + (((colq >> 3) ^ ((r0 & 3) << 2)) << 3) + (colq & 7)) * 2);
+        }
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x16 accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};   // bf16 1.0
+    const bool do_bias = p.db != nullptr;
+    int bturn = (tile % ntk);          // this workgroup takes a 16-row step of the bias gradient when bturn == 0
+
+#pragma unroll
+    for (int s = 0; s < TNP_L; ++s) issue();
+    if (nph > TNP_L) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wn == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind
+    const long long t_begin = (p.dbg & 4) ? __builtin_readcyclecounter() : 0;
+#pragma clang loop unroll(disable)
+    for (int ph = 0; ph < nph; ++ph) {
+        const uint32_t sb = (uint32_t)(ph & 7) * 16384u;
+        // Transposed fragment gathers from inline asm: behind the builtin, hipcc cannot tell the reads from the LDS-DMA writes still in
+        // flight and drains the whole DMA queue (s_waitcnt vmcnt(0)) in front of the first one.  Rows r0 and r0 + 4 (+ 4 * 512 B).
+        bf16x4 ylo[4], yhi[4], xlo[2], xhi[2];
+        if (p.dbg & 64) {
+            issue();
+            if (dq <= nph) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier\n\ts_barrier" ::: "memory");
+            continue;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048" : "=&v"(ylo[u]), "=&v"(yhi[u]) : "v"(sb + ay[u]) : "memory");
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048" : "=&v"(xlo[u]), "=&v"(xhi[u]) : "v"(sb + ax[u]) : "memory");
+        issue();
+        if (dq <= nph) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // steady state: steps ph+2 .. ph+6 may stay in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // tail of the chunk
+        const bool bt = do_bias && bturn == 0;
+        if (do_bias) bturn = (bturn + 1 == ntk) ? 0 : bturn + 1;
+        // barrier, then the fragment reads retire; the asm "modifies" fragments and accumulators, which pins the MFMAs behind it
+        asm volatile("s_barrier\n\ts_setprio 1\n\ts_waitcnt lgkmcnt(0)"
+                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(accb),
+                       "+v"(ylo[0]), "+v"(yhi[0]), "+v"(ylo[1]), "+v"(yhi[1]), "+v"(ylo[2]), "+v"(yhi[2]), "+v"(ylo[3]), "+v"(yhi[3]),
+                       "+v"(xlo[0]), "+v"(xhi[0]), "+v"(xlo[1]), "+v"(xhi[1])::"memory");
+        bf16x8 fy[4], fx[2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fy[u] = bf16x8{ylo[u][0], ylo[u][1], ylo[u][2], ylo[u][3], yhi[u][0], yhi[u][1], yhi[u][2], yhi[u][3]};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) fx[u] = bf16x8{xlo[u][0], xlo[u][1], xlo[u][2], xlo[u][3], xhi[u][0], xhi[u][1], xhi[u][2], xhi[u][3]};
+        if (bt) {      // wave-uniform; this wave's 32 bias columns are fragment u = wk
+            const bf16x8 fsel = wk == 0 ? fy[0] : wk == 1 ? fy[1] : wk == 2 ? fy[2] : fy[3];
+            accb = mfma32(fsel, ones, accb);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fy[i], fx[j], acc[i][j]);
+        asm volatile("s_setprio 0\n\ts_barrier"
+                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(accb)::"memory");
+    }
+    if (wn == 0) __builtin_amdgcn_s_barrier();      // pairs with group 1's last barrier
+    if (p.dbg & 4) {      // timing-only: shader cycles per phase of this workgroup instead of the gradient
+        if (tid == 0) p.dW[blockIdx.x] = (float)(__builtin_readcyclecounter() - t_begin) / (float)nph;
+        return;
+    }
+    // acc[i][j][reg]: n = n0 + wn*128 + i*32 + (reg&3) + 8*(reg>>2) + 4*(lane>>5);  k = k0 + wk*64 + j*32 + (lane&31)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int k = k0 + wk * 64 + j * 32 + (lane & 31);
+                atomicAdd(p.dW + (size_t)n * p.ldw + k, acc[i][j][r]);
+            }
+    if (do_bias && (lane & 31) == 0) {   // every column of accb holds the same sums: lanes 0 and 32 publish their 16 rows
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            atomicAdd(p.db + n0 + wn * 128 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), accb[r]);
+    }
+}
+
 extern "C" int svla_gemm_tn_f32acc(const bf16_t* dY, long ldy, const bf16_t* X, long ldx, float* dW, long ldw, float* db, int M,
                                    int N, int K, void* stream) {
     if (M <= 0 || (N % 128) || (K % 128) || (ldy % 8) || (ldx % 8)) return SVLA_EINVAL;
@@ -1114,12 +1606,21 @@ extern "C" int svla_gemm_tn_f32acc(const bf16_t* dY, long ldy, const bf16_t* X, 
         if (chunks < 1) chunks = 1;
         int chunk_rows = ((M + chunks - 1) / chunks + TN256_ROWS - 1) / TN256_ROWS * TN256_ROWS;
         chunks = (M + chunk_rows - 1) / chunk_rows;
-        GemmTn256Args q{dY, ldy, X, ldx, dW, ldw, db, M, N, K, chunk_rows};
+        GemmTn256Args q{dY, ldy, X, ldx, dW, ldw, db, M, N, K, chunk_rows, g_dbg};
         const size_t lds256 = (size_t)TN_NS * 2 * TN256_ROWS * 256 * sizeof(bf16_t);   // 128 KiB
         static bool attr256 = false;
         if (!attr256) {
             HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_tn256_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
             attr256 = true;
+        }
+        if (!(g_dbg & 128)) {
+            static bool attr8p = false;
+            if (!attr8p) {
+                HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_tn8p_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
+                attr8p = true;
+            }
+            hipLaunchKernelGGL(gemm_tn8p_bf16_kernel, dim3(ntile256 * chunks), dim3(NT256_THREADS), lds256, (hipStream_t)stream, q);
+            return svla_launch_status();
         }
         hipLaunchKernelGGL(gemm_tn256_bf16_kernel, dim3(ntile256 * chunks), dim3(NT256_THREADS), lds256, (hipStream_t)stream, q);
         return svla_launch_status();
