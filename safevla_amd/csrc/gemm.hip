@@ -295,158 +295,198 @@ __device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((row 
 
 // Epilogue of the 256x256 kernels (shared by the persistent 2-buffer kernel and the 8-phase kernel): bias / activation / dropout /
 // mask / residual in fp32 on the accumulator layout acc[i][j][reg] (row = wm*128 + i*32 + (lane&31), col = wn*64 + j*32 + (reg&3) +
-// 8*(reg>>2) + 4*(lane>>5)), one bf16 rounding, then each 32 x 64 slab is transposed through the wave-private 4 KiB LDS buffer so
+// 8*(reg>>2) + 4*(lane>>5)), one bf16 rounding, then each 32 x 64 slab is transposed through a wave-private 4 KiB LDS buffer so
 // that every global store instruction writes 8 full 128-byte lines.
-template <int ACT, int AUX, int HI_OFF, bool LDS_BIAS>
+// The epilogue is VALU-issue bound (measured with in-kernel cycle counters: ~4 cycles per vector instruction per SIMD, two waves per
+// SIMD), so its cost is its instruction count: addresses are a wave-uniform base + one lane offset (no 64-bit vector arithmetic), ReLU
+// and the sign bits work on the packed bf16 pairs (v_pk_max_i16 / v_pk_min_i16), the dropout hash of a slab shares its row products
+// (2 instead of ~4.6 quarter-rate v_mul_lo_u32 per hash, bit-identical masks), dropout is a compile-time flavour (no per-group branch).
+__device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_min_i16(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int ACT, int AUX, int HI_OFF, bool LDS_BIAS, bool DROP>
 struct Nt256Epi {
     static constexpr bool HAS_RES = (AUX & 1) != 0, HAS_MASK = (AUX & 2) != 0, HAS_BITS = AUX == 4, LDS_AUX = HAS_RES || HAS_MASK;
+    static constexpr bool PACKED_RELU = ACT == ACT_RELU && AUX == 0;      // nothing is added after the activation: ReLU commutes with the rounding
     const GemmNtArgs& p;
-    const int wm, wn, lane, fr, fh;
-    const bf16_t* aux;
+    const int wm, wn, lane;
+    const char* aux;
     long ldaux;
     // wave-private staging of one 32 x 64 bf16 slab (128-byte rows): write (row fr, 8-byte piece), read (row lane>>3 [+8 it], 16-byte
     // chunk lane&7).  Rows 0-15 start at Es, rows 16-31 at Es + hi_off (2048: one contiguous 4-KiB buffer; 16384: two 2-KiB stripes
     // of neighbouring ring slots, see gemm_nt8p)
     char* Es;
     static constexpr int hi_off = HI_OFF;
-    int e_wr, e_sw, e_rd;
     const float* bias_lds;    // LDS-resident copy of bias[0..N) (8-phase kernel: no vector-memory load in the bias path), or nullptr
     // the residual / mask slab is fetched row-major (8 full 128-byte lines per instruction), one slab ahead, and turned into the
     // accumulator layout through the wave's LDS buffer (the inverse of the output transposition)
-    u32x4 auxrm[2][4];
+    u32x4 auxrm[3][4];      // slab i lives in buffer i % 3: loaded TWO slabs ahead (one slab of epilogue work is ~1 k cycles, an HBM access ~2 k)
     // AUX == 4: the ReLU mask as 1 bit per element ([M, N/8] bytes): the 64 bits of this lane's slab row are ONE 8-byte load in
     // the accumulator layout -- no LDS round trip, 16x fewer mask bytes than a bf16 activation tensor
     u32x2 mbits[2];
     __device__ __forceinline__ Nt256Epi(const GemmNtArgs& p_, char* es_wave, const float* bias_lds_, int wid, int lane_)
-        : p(p_), wm(wid >> 2), wn(wid & 3), lane(lane_), fr(lane_ & 31), fh(lane_ >> 5) {
-        aux = HAS_RES ? p.residual : (HAS_MASK ? p.relu_mask : nullptr);
+        : p(p_), wm(__builtin_amdgcn_readfirstlane(wid >> 2)), wn(__builtin_amdgcn_readfirstlane(wid & 3)), lane(lane_) {
+        aux = (const char*)(HAS_RES ? p.residual : (HAS_MASK ? p.relu_mask : nullptr));
         ldaux = HAS_RES ? p.ldr : p.ldm;
         Es = es_wave;
         bias_lds = bias_lds_;
-        e_wr = (fr & 15) * 128 + (fr >> 4) * hi_off + fh * 8;
-        e_sw = fr & 7;
-        e_rd = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);
     }
     __device__ __forceinline__ int it_off(int it) const { return (it & 1) * 1024 + (it >> 1) * hi_off; }     // rows it*8 .. it*8+7
-    __device__ __forceinline__ void load_aux(int i, u32x4 (&buf)[4], int tm0, int tn0) {
+    // lo: an opaque copy of the lane id made where the epilogue starts -- everything lane-dependent is derived from it there, otherwise
+    // hipcc hoists ~35 VGPRs of address arithmetic across the main loop
+    __device__ __forceinline__ void load_aux(int i, u32x4 (&buf)[4], int tm0, int tn0, int lo) {
+        const uint32_t loff = (uint32_t)(((lo >> 3) * ldaux + (lo & 7) * 8) * 2);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int mr = min(tm0 + wm * 128 + i * 32 + it * 8 + (lane >> 3), p.M - 1);
-            buf[it] = *(const u32x4*)(aux + (size_t)mr * ldaux + tn0 + wn * 64 + (lane & 7) * 8);
+            const int r0 = tm0 + wm * 128 + i * 32 + it * 8;      // wave-uniform first row of this 8-row piece
+            if (r0 + 8 <= p.M) buf[it] = *(const u32x4*)(aux + ((size_t)r0 * ldaux + tn0 + wn * 64) * 2 + loff);
+            else buf[it] = *(const u32x4*)(aux + ((size_t)min(r0 + (lo >> 3), p.M - 1) * ldaux + tn0 + wn * 64 + (lo & 7) * 8) * 2);      // M tail: clamp (never stored)
         }
     }
-    __device__ __forceinline__ void load_bits(int i, u32x2& dst, int tm0, int tn0) {
-        const int mc = min(tm0 + wm * 128 + i * 32 + fr, p.M - 1);
+    __device__ __forceinline__ void load_bits(int i, u32x2& dst, int tm0, int tn0, int lo) {
+        const int mc = min(tm0 + wm * 128 + i * 32 + (lo & 31), p.M - 1);
         dst = *(const u32x2*)(p.bits_in + relu_bits_word(mc, tn0 + wn * 64, p.N));
     }
     // slab 0's operands: issued while the last K-tile is still being computed
     __device__ __forceinline__ void prefetch0(int m0, int n0) {
-        if (LDS_AUX && n0 + wn * 64 < p.N) load_aux(0, auxrm[0], m0, n0);
-        if (HAS_BITS && n0 + wn * 64 < p.N) load_bits(0, mbits[0], m0, n0);
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+        if (LDS_AUX && n0 + wn * 64 < p.N) { load_aux(0, auxrm[0], m0, n0, lo); load_aux(1, auxrm[1], m0, n0, lo); }
+        if (HAS_BITS && n0 + wn * 64 < p.N) load_bits(0, mbits[0], m0, n0, lo);
     }
     // returns whether this wave issued exactly 16 (+4 sign-bit) stores (full tile, columns inside N)
     __device__ __forceinline__ bool run(f32x16 (&acc)[4][2], int m0, int n0) {
-        bf16_t* C = (bf16_t*)p.C;
+        char* C = (char*)p.C;
         const bool wave_cols_valid = n0 + wn * 64 < p.N;      // wave-uniform: a wave's 64 output columns are all inside N or all outside
         if ((p.dbg & 2) || !wave_cols_valid) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
-        } else {
-            f32x4 bias4[2][4];
+            return false;
+        }
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+        const int fr = lo & 31, fh = lo >> 5;
+        const int e_wr = ((fr & 15) * 128 + (fr >> 4) * hi_off + fh * 8) | ((fr & 7) << 4);      // ^ (group << 4): the 8-byte piece of group (j, rg)
+        const int e_rd = (lo >> 3) * 128 + (((lo & 7) ^ (lo >> 3)) << 4);
+        const uint32_t c_loff = (uint32_t)(((lo >> 3) * p.ldc + (lo & 7) * 8) * 2);
+        f32x4 bias4[2][4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg)
-                    bias4[j][rg] = LDS_BIAS ? *(const f32x4*)(bias_lds + n0 + wn * 64 + j * 32 + 8 * rg + 4 * fh)
-                                            : (p.bias ? *(const f32x4*)(p.bias + n0 + wn * 64 + j * 32 + 8 * rg + 4 * fh) : f32x4{0.f, 0.f, 0.f, 0.f});
+            for (int rg = 0; rg < 4; ++rg)
+                bias4[j][rg] = LDS_BIAS ? *(const f32x4*)(bias_lds + n0 + wn * 64 + j * 32 + 8 * rg + 4 * fh)
+                                        : (p.bias ? *(const f32x4*)(p.bias + n0 + wn * 64 + j * 32 + 8 * rg + 4 * fh) : f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + wm * 128 + i * 32 + fr;
-                const int mc = min(m, p.M - 1);
-                if (LDS_AUX && i + 1 < 4) load_aux(i + 1, auxrm[(i + 1) & 1], m0, n0);
-                if (HAS_BITS && i + 1 < 4) load_bits(i + 1, mbits[(i + 1) & 1], m0, n0);
-                if (LDS_AUX) {
+        for (int i = 0; i < 4; ++i) {
+            const int mrow0 = m0 + wm * 128 + i * 32;      // wave-uniform
+            const int m = mrow0 + fr;
+            if (LDS_AUX && i + 2 < 4) load_aux(i + 2, auxrm[(i + 2) % 3], m0, n0, lo);
+            if (HAS_BITS && i + 1 < 4) load_bits(i + 1, mbits[(i + 1) & 1], m0, n0, lo);
+            if (LDS_AUX) {
 #pragma unroll
-                    for (int it = 0; it < 4; ++it) *(u32x4*)(Es + it_off(it) + e_rd) = auxrm[i & 1][it];
-                    __builtin_amdgcn_wave_barrier();
-                }
-                unsigned obw[2] = {0u, 0u};       // sign bits of this lane's 2 x 16 outputs, at their column positions
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int nb = n0 + wn * 64 + j * 32;
-                    u32x2 pk[4];
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const int n = nb + 8 * rg + 4 * fh;
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = acc[i][j][rg * 4 + e] * p.alpha + bias4[j][rg][e];
-                            if (ACT == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
-                            else if (ACT == ACT_GELU) v[e] = gelu_f(v[e]);
-                        }
-                        if (p.drop.thr) {      // wave-uniform
-                            const unsigned keep = drop_keep4(p.drop, (unsigned long long)m * p.drop.row_mult * p.N + n);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = ((keep >> e) & 1u) ? v[e] * p.drop.scale : 0.f;
-                        }
-                        if (HAS_MASK) {
-                            const u32x2 mk = HAS_RES ? *(const u32x2*)(p.relu_mask + (size_t)mc * p.ldm + n) : *(const u32x2*)(Es + e_wr + (((j * 4 + rg) ^ e_sw) << 4));
-                            if (!(bf_lo(mk[0]) > 0.f)) v[0] = 0.f;
-                            if (!(bf_hi(mk[0]) > 0.f)) v[1] = 0.f;
-                            if (!(bf_lo(mk[1]) > 0.f)) v[2] = 0.f;
-                            if (!(bf_hi(mk[1]) > 0.f)) v[3] = 0.f;
-                        }
-                        if (HAS_BITS) {
-                            const unsigned nib = mbits[i & 1][j] >> (8 * rg + 4 * fh);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (!((nib >> e) & 1u)) v[e] = 0.f;
-                        }
-                        if (HAS_RES) {
-                            const u32x2 rs = *(const u32x2*)(Es + e_wr + (((j * 4 + rg) ^ e_sw) << 4));
-                            v[0] += bf_lo(rs[0]); v[1] += bf_hi(rs[0]); v[2] += bf_lo(rs[1]); v[3] += bf_hi(rs[1]);
-                        }
-                        pk[rg][0] = pack_bf2(v[0], v[1]);
-                        pk[rg][1] = pack_bf2(v[2], v[3]);
-                        *(u32x2*)(Es + e_wr + (((j * 4 + rg) ^ e_sw) << 4)) = pk[rg];
-                        if (ACT == ACT_RELU && AUX == 0) {   // outputs are >= 0: "positive" == non-zero magnitude bits of the rounded value
-                            // per 16-bit half: min(magnitude, 1) (v_pk_min_u16), then fold bit 16 down to bit 1
-                            const unsigned t0 = pk_min_u16(pk[rg][0] & 0x7fff7fffu, 0x00010001u), t1 = pk_min_u16(pk[rg][1] & 0x7fff7fffu, 0x00010001u);
-                            const unsigned nib = ((t0 | (t0 >> 15)) & 3u) | (((t1 | (t1 >> 15)) & 3u) << 2);
-                            obw[j] |= nib << (8 * rg + 4 * fh);
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const u32x4 w = *(const u32x4*)(Es + it_off(it) + e_rd);
-                    const int mr = m0 + wm * 128 + i * 32 + it * 8 + (lane >> 3);
-                    if (p.dbg & 1) { asm volatile("" ::"v"(w)); }
-                    else if (mr < p.M) *(u32x4*)(C + (size_t)mr * p.ldc + n0 + wn * 64 + (lane & 7) * 8) = w;
-                }
-                if (ACT == ACT_RELU && AUX == 0 && p.bits_out) {
-                    // lanes fr and fr+32 hold the two interleaved nibble sets of row fr: merge, then ONE 8-byte store per row (store
-                    // instructions, not bytes, are what the CU's store path charges for)
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(obw[0], obw[0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(obw[1], obw[1], false, false);
-                    const u32x2 ob = {obw[0] | s0[1], obw[1] | s1[1]};
-                    if (fh == 0 && m < p.M) *(u32x2*)(p.bits_out + relu_bits_word(m, n0 + wn * 64, p.N)) = ob;
-                }
+                for (int it = 0; it < 4; ++it) *(u32x4*)(Es + it_off(it) + e_rd) = auxrm[i % 3][it];
                 __builtin_amdgcn_wave_barrier();
             }
+            // dropout: element index e = m * row_mult * N + n, pair index e >> 1 = P + c with P the pair of (this row, the wave's first
+            // column + 4 fh) and c = j*16 + rg*4 (+1): x = lo(pair) * C1 ^ hi(pair) * C2 ^ key = (P_lo * C1 + c * C1) ^ (P_hi * C2 [+ C2 on carry]) ^ key
+            uint32_t dP_lo = 0, dA1 = 0, dB1 = 0;
+            if (DROP) {
+                const unsigned long long P = ((unsigned long long)m * (unsigned long long)(p.drop.row_mult * (long long)p.N) + (unsigned)(n0 + wn * 64 + 4 * fh)) >> 1;
+                dP_lo = (uint32_t)P;
+                dA1 = dP_lo * 0x9E3779B1u;
+                dB1 = (uint32_t)(P >> 32) * 0x85EBCA77u;
+            }
+            unsigned obw[2] = {0u, 0u};       // sign bits of this lane's 2 x 16 outputs, at their column positions (before the final << 4 fh)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int gi = j * 4 + rg;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[i][j][rg * 4 + e] * p.alpha + bias4[j][rg][e];
+                        if (ACT == ACT_RELU && !PACKED_RELU) v[e] = fmaxf(v[e], 0.f);
+                        else if (ACT == ACT_GELU) v[e] = gelu_f(v[e]);
+                    }
+                    if (DROP) {
+                        unsigned keep = 0;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const uint32_t c = (uint32_t)(j * 16 + rg * 4 + h);
+                            const uint32_t hb = (dP_lo + c < c) ? dB1 + 0x85EBCA77u : dB1;
+                            unsigned x = (dA1 + c * 0x9E3779B1u) ^ hb ^ p.drop.key;
+                            x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+                            keep |= ((x & 0xffffu) >= p.drop.thr ? 1u : 0u) << (2 * h);
+                            keep |= ((x >> 16) >= p.drop.thr ? 2u : 0u) << (2 * h);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ((keep >> e) & 1u) ? v[e] * p.drop.scale : 0.f;
+                    }
+                    if (HAS_MASK) {
+                        const u32x2 mk = HAS_RES ? *(const u32x2*)(p.relu_mask + (size_t)min(m, p.M - 1) * p.ldm + n0 + wn * 64 + j * 32 + 8 * rg + 4 * fh)
+                                                 : *(const u32x2*)(Es + (e_wr ^ (gi << 4)));
+                        if (!(bf_lo(mk[0]) > 0.f)) v[0] = 0.f;
+                        if (!(bf_hi(mk[0]) > 0.f)) v[1] = 0.f;
+                        if (!(bf_lo(mk[1]) > 0.f)) v[2] = 0.f;
+                        if (!(bf_hi(mk[1]) > 0.f)) v[3] = 0.f;
+                    }
+                    if (HAS_BITS) {
+                        const unsigned nib = mbits[i & 1][j] >> (8 * rg + 4 * fh);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (!((nib >> e) & 1u)) v[e] = 0.f;
+                    }
+                    if (HAS_RES) {
+                        const u32x2 rs = *(const u32x2*)(Es + (e_wr ^ (gi << 4)));
+                        v[0] += bf_lo(rs[0]); v[1] += bf_hi(rs[0]); v[2] += bf_lo(rs[1]); v[3] += bf_hi(rs[1]);
+                    }
+                    u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                    if (PACKED_RELU) { pk[0] = pk_max_i16(pk[0], 0u); pk[1] = pk_max_i16(pk[1], 0u); }      // negative halves (and -0) -> +0
+                    *(u32x2*)(Es + (e_wr ^ (gi << 4))) = pk;
+                    if (PACKED_RELU && p.bits_out) {   // outputs are >= +0: min(half, 1) per 16-bit half, bit 16 folded down to bit 1
+                        const unsigned t0 = pk_min_i16(pk[0], 0x00010001u), t1 = pk_min_i16(pk[1], 0x00010001u);
+                        obw[j] |= (((t0 | (t0 >> 15)) & 3u) | (((t1 | (t1 >> 15)) & 3u) << 2)) << (8 * rg);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const u32x4 w = *(const u32x4*)(Es + it_off(it) + e_rd);
+                const int r0 = mrow0 + it * 8;      // wave-uniform
+                char* cb = C + ((size_t)r0 * p.ldc + n0 + wn * 64) * 2;
+                if (p.dbg & 1) { asm volatile("" ::"v"(w)); }
+                else if (r0 + 8 <= p.M) *(u32x4*)(cb + c_loff) = w;
+                else if (r0 + (lo >> 3) < p.M) *(u32x4*)(cb + c_loff) = w;
+            }
+            if (PACKED_RELU && p.bits_out) {
+                // lanes fr and fr+32 hold the two interleaved nibble sets of row fr: merge, then ONE 8-byte store per row (store
+                // instructions, not bytes, are what the CU's store path charges for)
+                const unsigned o0 = obw[0] << (4 * fh), o1 = obw[1] << (4 * fh);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(o0, o0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(o1, o1, false, false);
+                const u32x2 ob = {o0 | s0[1], o1 | s1[1]};
+                if (fh == 0 && m < p.M) *(u32x2*)(p.bits_out + relu_bits_word(m, n0 + wn * 64, p.N)) = ob;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        return (m0 + 256 <= p.M) && wave_cols_valid && !(p.dbg & 3);
+        return (m0 + 256 <= p.M) && !(p.dbg & 3);
     }
 };
 
-
 // ACT / AUX (bit 0: +residual, bit 1: ReLU mask) are compile-time: a runtime-selected epilogue unrolled over the 32 accumulator
 // pieces is ~100 KiB of code (128 inlined erff bodies ...) that evicts the main loop from the instruction cache once per tile.
-template <int ACT, int AUX>
+template <int ACT, int AUX, bool DROP>
 __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(GemmNtArgs p) {
     p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -513,7 +553,7 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
 
     f32x16 acc[4][2];
     const int fr = lane & 31, fh = lane >> 5;
-    Nt256Epi<ACT, AUX, 2048, false> epi(p, smem + (size_t)NS64 * 512 * BK64 * 2 + (size_t)__builtin_amdgcn_readfirstlane(wid) * 4096, nullptr, wid, lane);
+    Nt256Epi<ACT, AUX, 2048, false, DROP> epi(p, smem + (size_t)NS64 * 512 * BK64 * 2 + (size_t)__builtin_amdgcn_readfirstlane(wid) * 4096, nullptr, wid, lane);
     for (int s = 0; s < NS64 - 1; ++s) issue_next();
     int g = 0;
     bool prev_full = true;
@@ -596,7 +636,7 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
 // half-tile q+8 is issued in load(q+2), two full phases after the last read of q (which is in phase <= q; the reads of a phase are
 // retired by the lgkmcnt wait in front of its MFMAs, one barrier before the next phase of the same group).
 #define P8_RING_BYTES 131072
-template <int ACT, int AUX>
+template <int ACT, int AUX, bool DROP>
 __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt8p_bf16_kernel(GemmNtArgs p) {
     p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -644,9 +684,9 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt8p_bf16_kernel(GemmNt
     set_dma_tile(0);
     // ty: 0 = B0, 1 = B1, 2 = A0, 3 = A1 (compile-time at every call site); ring slot = 4 * (K-tile parity) + ty
     auto issue = [&](const int ty) {
-        if (d_live) {
-            const char* base = ty >= 2 ? a_base : b_base;
-            const uint32_t kb = (uint32_t)(d_kt * BK64 * 2);
+        if (d_live && !(p.dbg & 32)) {      // timing-only: dbg & 32 = no DMA at all, dbg & 8 = always K-tile 0 of the first tile (L2-resident operands)
+            const char* base = (p.dbg & 8) ? (ty >= 2 ? (const char*)p.A : (const char*)p.B) : (ty >= 2 ? a_base : b_base);
+            const uint32_t kb = (p.dbg & 8) ? 0u : (uint32_t)(d_kt * BK64 * 2);
             char* dst = smem + (d_par * 4 + ty) * 16384 + wrow_off;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -684,7 +724,7 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt8p_bf16_kernel(GemmNt
     // own next DMA into them is issued after its last staging access has retired).  The 32 KiB behind the ring hold bias[0..N).
     float* bias_lds = (float*)(smem + P8_RING_BYTES);
     for (int i = tid; i < p.N; i += NT256_THREADS) bias_lds[i] = p.bias ? p.bias[i] : 0.f;
-    Nt256Epi<ACT, AUX, 16384, true> epi(p, smem, bias_lds, wid, lane);
+    Nt256Epi<ACT, AUX, 16384, true, DROP> epi(p, smem, bias_lds, wid, lane);
 
     // prologue: half-tiles 0..5 in flight, 0..2 (the first K-tile's B0, B1, A0) landed and published
     issue(0); issue(1); issue(2); issue(3); issue(0); issue(1);
@@ -692,7 +732,6 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt8p_bf16_kernel(GemmNt
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind
     int c_par = 0;
-    int relax = 0;
     bool eb = false;       // the previous tile's epilogue left exactly 16 stores behind the DMA that was already in flight
 #define P8_LDS(off) (*(const bf16x8*)(smem + (off)))
     // The MFMAs are pure register operations: nothing but data dependences keeps them between the two barriers of their phase.  Both
@@ -734,7 +773,7 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt8p_bf16_kernel(GemmNt
             for (int kk = 0; kk < 4; ++kk) fa[kk] = P8_LDS(kbase + 4096 + ra[kk]);
             issue(3);
             if (!d_live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tail of this workgroup's stream: nothing is issued any more
-            else if (eb || relax > 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");      // 8 + the epilogue's 16 stores (VM ops retire in order)
+            else if (eb) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");      // 8 + the epilogue's 16 stores (VM ops retire in order)
             else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             eb = false;
             P8_COMPUTE(1)
@@ -746,19 +785,16 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt8p_bf16_kernel(GemmNt
             // ---- phase 3
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) fa[kk] = P8_LDS(kbase + 16384 + 4096 + ra[kk]);
-            if (kt == nk - 1) epi.prefetch0(m0, n0);
             issue(1);
             if (!d_live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (relax > 0) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");      // TIMING-ONLY experiment (dbg & 4): pretend the epilogue's stores need not complete
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            --relax;
+            if (kt == nk - 1) epi.prefetch0(m0, n0);      // behind the counted wait: ordinary loads in front of it would only tighten it
             P8_COMPUTE(3)
         }
         if (ti == my_tiles - 1 && wm == 0) __builtin_amdgcn_s_barrier();      // pairs with group 1's last barrier
         if (p.dbg & 16) { const long long t = __builtin_readcyclecounter(); cyc_main += t - t_mark; t_mark = t; }
         epi.Es = smem + ((c_par ^ 1) * 4 + 2) * 16384 + wrow_off;
         eb = epi.run(acc, m0, n0);
-        relax = (p.dbg & 4) ? ((p.dbg & 8) ? 4 : 2) : 0;
         if (p.dbg & 16) { const long long t = __builtin_readcyclecounter(); cyc_epi += t - t_mark; t_mark = t; }
     }
     if ((p.dbg & 16) && tid == 0) {      // cycles per K-tile of the main loop, cycles per tile of the epilogue, into the first floats of C
@@ -769,361 +805,40 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt8p_bf16_kernel(GemmNt
 #undef P8_COMPUTE
 }
 
-template <int ACT, int AUX>
+template <int ACT, int AUX, bool DROP>
 static int launch_nt8p_inst(const GemmNtArgs& p, int grid, hipStream_t stream) {
     const size_t lds = (size_t)P8_RING_BYTES + 32768;   // 160 KiB: ring + bias table (N <= 8192)
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt8p_bf16_kernel<ACT, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt8p_bf16_kernel<ACT, AUX, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_nt8p_bf16_kernel<ACT, AUX>), dim3(grid), dim3(NT256_THREADS), lds, stream, p);
+    hipLaunchKernelGGL((gemm_nt8p_bf16_kernel<ACT, AUX, DROP>), dim3(grid), dim3(NT256_THREADS), lds, stream, p);
     return svla_launch_status();
 }
 
-// =================================================================================================
-// "Rotating" 8-phase NT kernel: gemm_nt8p's operand pipeline WITHOUT an epilogue phase.
-// Why: measured with in-kernel cycle counters (tools/ab_gemm.py, AB_CYCLES=1), a tile's 128-KiB store burst costs its own 6-11 k
-// cycles AND ~1.2 k cycles per K-tile of the following main loop (the CU's vector-memory pipeline is in order: the operand DMA of
-// the next tile queues behind the stores), plus ~4.7 k cycles of pipeline restart per tile -- together 30-45 % of the kernel.
-// Idea: the reduction order inside a tile is free.  A workgroup keeps ONE n-tile for its whole life and walks m-blocks; row block
-// (wave group g, accumulator block i) of the wave layout starts its K loop at K-tile g * nk/2 + i and wraps around, so at any
-// global step s every block consumes the SAME weight slice W[n-tile, k(s) = s mod nk] (the DMA traffic is exactly gemm_nt8p's), but
-// the eight row blocks finish their output tiles at eight different steps.  A finished 32 x 64 slab per wave is drained while the
-// wave's other three blocks keep accumulating: scale / activation / dropout / bf16 packing interleaved with the MFMAs of the next
-// three phases, transposition through LDS, 4 global stores two phases later -- then the block re-initialises its accumulators
-// (from the LDS-resident bias table: the bias add costs nothing) and starts the next m-block.  No store bursts, no pipeline
-// restarts, the memory pipeline sees a steady mix of operand loads and 16 KiB of stores per K-tile.
-// Restrictions (others take the kernels above): no residual / mask operand, N % 256 == 0, 32 % (N / 256) == 0, (K / 64) % 8 == 0, bias => alpha == 1.
-#define R8_RING 131072
-#define R8_STAGE_BYTES 32768      // 8 x 4 KiB
-// drain schedule of one wave group inside its period (position pi = local step mod nk, phase p): row block b finishes its tile in
-// (pi = b-1, phase b), is packed in the next three compute segments (stages 1-3), re-initialised in the load segment of (pi = b, phase b)
-// and stored behind the MFMAs of that phase (stage 4).  With L = 4 pi + p: stage k of block b sits at L = 5 b - 4 + k.
-__host__ __device__ constexpr int r8_blk(int L) { return (L + 3) >= 0 ? (L + 3) / 5 : -1; }
-__host__ __device__ constexpr int r8_stage(int L) {
-    const int bk = r8_blk(L);
-    if (bk < 0 || bk > 3) return 0;
-    const int k = L + 4 - 5 * bk;
-    return (k >= 1 && k <= 4) ? k : 0;
-}
-template <int ACT, bool DROP, bool BITS>
-__global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt8r_bf16_kernel(GemmNtArgs p) {
-    p.drop = drop_resolve(p.drop);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int g = __builtin_amdgcn_readfirstlane(wid >> 2), wn = __builtin_amdgcn_readfirstlane(wid & 3);
-    const int ntn = p.N >> 8, MT = (p.M + 255) >> 8;
-    const int xcd = blockIdx.x & 7, lw = blockIdx.x >> 3, mslots = (int)(gridDim.x >> 3) / ntn;
-    if (lw >= mslots * ntn) return;
-    const int n0 = (lw % ntn) * 256, mslot = lw / ntn;
-    // m-blocks of this workgroup: mb(t) = (t * mslots + mslot) * 8 + xcd, t = 0 .. T-1 (the workgroups of one XCD that differ only in
-    // the n-tile walk the same m-blocks in step: the A panel is fetched from HBM once per XCD)
-    const int mb0 = mslot * 8 + xcd, mbs = mslots * 8;
-    const int T = mb0 < MT ? (MT - mb0 + mbs - 1) / mbs : 0;
-    if (T <= 0) return;
-    const int nk = p.K / BK64, nkh = nk >> 1;
-    // row block (g, i) starts its first tile at global step g * nk/2 + i: the two wave groups half a period apart, a group's blocks one step apart
-    const int total_steps = T * nk + nkh + 4;
-    auto tile_m0 = [&](int t) { return (mb0 + min(max(t, 0), T - 1) * mbs) * 256; };      // clamped: idle blocks read valid rows
-
-    // ---- DMA side: gemm_nt8p's ring, half-tile composition, issue order and waits.  Half-tile types per step: 0 = B0, 1 = B1,
-    // 2 = A0 (rows g*128 + 0..63 of both groups = row blocks 0, 1), 3 = A1 (row blocks 2, 3).  Wave w fills half-tile rows w*16 .. w*16+15,
-    // which for A half h belong to row block (w >> 2, 2h + ((w >> 1) & 1)): two blocks per wave, each with its own current m-block.
-    const int wrow_off = __builtin_amdgcn_readfirstlane(wid * 2048);
-    uint32_t offB[2][2], offA[2][2];          // [half][j]
-    const char* b_base = (const char*)p.B + (size_t)n0 * p.ldb * 2;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int rho = wid * 16 + (lane >> 3) + 8 * j;
-        const int csw = ((lane & 7) ^ ((rho >> 1) & 7)) * 8;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) offB[h][j] = (uint32_t)((((rho >> 5) * 64 + h * 32 + (rho & 31)) * p.ldb + csw) * 2);
-    }
-    const char* a_base[2];
-    int d_rem[2], d_tb[2];          // DMA cursor of the wave's block of A half h: steps left in its current tile, its tile index
-    auto set_dma_block = [&](int h) {
-        const int m0d = __builtin_amdgcn_readfirstlane(tile_m0(d_tb[h]));
-        a_base[h] = (const char*)p.A + (size_t)m0d * p.lda * 2;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int rho = wid * 16 + (lane >> 3) + 8 * j;
-            const int csw = ((lane & 7) ^ ((rho >> 1) & 7)) * 8;
-            const int arow = (rho >> 6) * 128 + h * 64 + (rho & 63);
-            offA[h][j] = (uint32_t)(((min(m0d + arow, p.M - 1) - m0d) * p.lda + csw) * 2);      // M tail: clamp (never stored)
-        }
-    };
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        d_rem[h] = __builtin_amdgcn_readfirstlane((wid >> 2) * nkh + 2 * h + ((wid >> 1) & 1));      // idle steps before the block's first tile
-        d_tb[h] = -1;
-        if (d_rem[h] == 0) { d_tb[h] = 0; d_rem[h] = nk; }
-        set_dma_block(h);
-    }
-    int d_step = 0, d_kt = 0, d_par = 0;
-    auto issue = [&](const int ty) {
-        if (d_step < total_steps) {
-            const char* base = ty >= 2 ? a_base[ty - 2] : b_base;
-            const uint32_t kb = (uint32_t)(d_kt * BK64 * 2);
-            char* dst = smem + (d_par * 4 + ty) * 16384 + wrow_off;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const uint32_t off = (ty == 0 ? offB[0][j] : ty == 1 ? offB[1][j] : ty == 2 ? offA[0][j] : offA[1][j]) + kb;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
-                                                 (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
-            }
-        }
-        if (ty == 3) {          // the step's last half-tile: advance the DMA cursor
-            d_par ^= 1;
-            ++d_step;
-            if (++d_kt == nk) d_kt = 0;
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                if (--d_rem[h] == 0) { ++d_tb[h]; d_rem[h] = nk; set_dma_block(h); }
-        }
-    };
-
-    // ---- consumer side.  Fragment read address of k-step kk: B row (wn*32 + fr), physical chunk (2 kk + fh) ^ sw = 2 kk ^ (sw ^ fh), i.e.
-    // rb0 ^ (kk << 5); the A rows of block i (half-tile i >> 1, rows g*64 + (i & 1)*32 + fr) sit a wave-uniform distance further.
-    uint32_t rb0;
-    {
-        const int fr = lane & 31, fh = lane >> 5;
-        rb0 = (uint32_t)((wn * 32 + fr) * 128 + ((fh ^ ((fr >> 1) & 7)) << 4));
-    }
-#define RB(kk) (rb0 ^ ((kk) << 5))
-    const uint32_t a_minus_b = (uint32_t)(32768 + g * 8192 - wn * 4096);
-    f32x16 acc[4][2];
-    bf16x8 fa[4], fb0[4], fb1[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // LDS behind the ring: one 4-KiB staging buffer per wave.  The bias of the wave's 64 columns lives in ONE VGPR (lane l: column l) and is
-    // broadcast into the accumulator layout with ds_bpermute when a block starts a new output tile (so the bias add itself costs nothing).
-    const int bias_v = p.bias ? __float_as_int(p.bias[n0 + wn * 64 + lane]) : 0;
-    char* Es = smem + R8_RING + wid * 4096;
-    // Every lane-dependent value of the drain code is derived from `lo`, an opaque per-step copy of the lane id: otherwise hipcc hoists
-    // ~35 VGPRs of loop-invariant address arithmetic out of the step loop and the main loop spills (vmcnt-counted scratch traffic).
-    int lo = lane;
-#define LO_FR (lo & 31)
-#define LO_FH (lo >> 5)
-    int pi = g ? nkh : 0;          // position of this wave group in its period
-    int tcur = -1;                 // tile index row block 0 of the group is working on (blocks 1-3 follow 1-3 steps later)
-    int d_m0 = 0;                  // first row of this group's 128 rows in the output tile being drained
-    bool d_valid = false, d_full = false;
-    unsigned obw[2] = {0u, 0u};
-    unsigned long long d_e0 = 0;      // dropout element index of (this lane's row of block 0, the wave's first column + 4*fh) of that tile
-    int sage = 0;          // phases for which the last store group may still be outstanding behind the DMA a wait covers
-    bf16_t* C = (bf16_t*)p.C;
-
-    // prologue: half-tiles 0..5 in flight, 0..2 landed and published
-    issue(0); issue(1); issue(2); issue(3); issue(0); issue(1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (g == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind
-    int c_par = 0;
-    long long cyc_wait = 0, t_w0 = 0;      // timing-only instrumentation (dbg & 16); dbg & 32: never relax a wait for stores in flight
-    const long long t_begin = (p.dbg & 16) ? __builtin_readcyclecounter() : 0;
-
-#define R8_LDS(off) (*(const bf16x8*)(smem + (off)))
-    // one (j, rg) group of 4 outputs of block BLK: scale, activation, dropout, bf16 packing into the staging buffer, ReLU sign bits
-#define R8_GROUP(BLK, GI)                                                                                                              \
-    {                                                                                                                                  \
-        constexpr int j_ = (GI) >> 2, rg_ = (GI) & 3;                                                                                  \
-        float v_[4];                                                                                                                   \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                                \
-            v_[e] = acc[BLK][j_][rg_ * 4 + e] * p.alpha;                                                                               \
-            if (ACT == ACT_RELU) v_[e] = fmaxf(v_[e], 0.f);                                                                            \
-            else if (ACT == ACT_GELU) v_[e] = gelu_f(v_[e]);                                                                           \
-        }                                                                                                                              \
-        if (DROP) {                                                                                                                    \
-            const unsigned keep_ = drop_keep4(p.drop, d_e0 + (unsigned)((BLK) * 32) * (unsigned long long)(p.drop.row_mult * p.N) + (j_ * 32 + 8 * rg_)); \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) v_[e] = ((keep_ >> e) & 1u) ? v_[e] * p.drop.scale : 0.f;                    \
-        }                                                                                                                              \
-        const unsigned pk0_ = pack_bf2(v_[0], v_[1]), pk1_ = pack_bf2(v_[2], v_[3]);                                                   \
-        *(u32x2*)(Es + (LO_FR * 128 + LO_FH * 8) + (((GI) ^ (lo & 7)) << 4)) = u32x2{pk0_, pk1_};                                      \
-        if (BITS) {                                                                                                                    \
-            const unsigned t0_ = pk_min_u16(pk0_ & 0x7fff7fffu, 0x00010001u), t1_ = pk_min_u16(pk1_ & 0x7fff7fffu, 0x00010001u);       \
-            obw[j_] |= (((t0_ | (t0_ >> 15)) & 3u) | (((t1_ | (t1_ >> 15)) & 3u) << 2)) << (8 * rg_ + 4 * LO_FH);                      \
-        }                                                                                                                              \
-    }
-#define R8_STORE(BLK)                                                                                                                  \
-    if (d_valid) {                                                                                                                     \
-        _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                                             \
-            const u32x4 w_ = *(const u32x4*)(Es + it * 1024 + ((lo >> 3) * 128 + (((lo & 7) ^ (lo >> 3)) << 4)));                      \
-            const int mr = d_m0 + (BLK) * 32 + it * 8 + (lo >> 3);                                                                     \
-            if (mr < p.M) *(u32x4*)(C + (size_t)mr * p.ldc + n0 + wn * 64 + (lo & 7) * 8) = w_;                                        \
-        }                                                                                                                              \
-        if (BITS) {                                                                                                                    \
-            const auto s0 = __builtin_amdgcn_permlane32_swap(obw[0], obw[0], false, false);                                            \
-            const auto s1 = __builtin_amdgcn_permlane32_swap(obw[1], obw[1], false, false);                                            \
-            const u32x2 ob = {obw[0] | s0[1], obw[1] | s1[1]};                                                                         \
-            const int m = d_m0 + (BLK) * 32 + LO_FR;                                                                                   \
-            if (LO_FH == 0 && m < p.M) *(u32x2*)(p.bits_out + relu_bits_word(m, n0 + wn * 64, p.N)) = ob;                              \
-        }                                                                                                                              \
-        sage = d_full ? 4 : 0;                                                                                                         \
-    }
-#define R8_MF(I_, KK, J) acc[I_][J] = mfma32((J) ? fb1[KK] : fb0[KK], fa[KK], acc[I_][J]);
-#define R8_PIN __builtin_amdgcn_sched_barrier(0);
-    // start of an output tile: accumulators = bias (column j*32 + 8*(r>>2) + 4*fh + (r&3) of the wave's 64; bias_v == 0 without a bias)
-#define R8_INIT(BLK)                                                                                                                   \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                                      \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                                 \
-            acc[BLK][j][r] = __int_as_float(__builtin_amdgcn_ds_bpermute((j * 32 + 8 * (r >> 2) + (r & 3) + 4 * LO_FH) << 2, bias_v));
-    // Compute segment of (period position PI, phase I_): the 8 MFMAs of block I_ in ONE straight-line block, with the statically scheduled
-    // drain work of this position pinned between MFMA pairs (a pair gives the packing of one 4-output group 64 matrix-pipe cycles of cover).
-#define R8_COMPUTE(PI, I_)                                                                                                             \
-    {                                                                                                                                  \
-        constexpr int L_ = 4 * (PI) + (I_), st_ = (PI) > 3 ? 0 : r8_stage(L_), bk_ = st_ ? r8_blk(L_) : 0;                             \
-        constexpr int g0_ = st_ == 1 ? 0 : st_ == 2 ? 3 : 6;                                                                           \
-        if (st_ == 1) { obw[0] = obw[1] = 0u; }                                                                                        \
-        asm volatile("s_barrier\n\ts_setprio 1" ::"v"(acc[I_][0]), "v"(acc[I_][1]) : "memory");      /* input-only: the MFMAs kill this value */ \
-        R8_MF(I_, 0, 0) R8_MF(I_, 0, 1)                                                                                                \
-        if (st_ >= 1 && st_ <= 3) { R8_PIN R8_GROUP(bk_, g0_) R8_PIN }                                                                 \
-        R8_MF(I_, 1, 0) R8_MF(I_, 1, 1)                                                                                                \
-        if (st_ >= 1 && st_ <= 3) { R8_PIN R8_GROUP(bk_, g0_ + 1) R8_PIN }                                                             \
-        R8_MF(I_, 2, 0) R8_MF(I_, 2, 1)                                                                                                \
-        if (st_ == 1 || st_ == 2) { R8_PIN R8_GROUP(bk_, (g0_ + 2) & 7) R8_PIN }                                                       \
-        R8_MF(I_, 3, 0) R8_MF(I_, 3, 1)                                                                                                \
-        if (st_ == 4) { R8_PIN R8_STORE(bk_) }                                                                                         \
-        asm volatile("s_setprio 0\n\ts_barrier" ::"v"(acc[I_][0]), "v"(acc[I_][1]) : "memory");                                        \
-    }
-    // One K step at period position PI (compile time; 9 = a quiet position): gemm_nt8p's four phases.  Block I_ starts a new tile in
-    // (PI == I_, phase I_): 32 ds_bpermute in that load segment, retired with the fragment reads in front of the phase's MFMAs.
-#define R8_WAIT_P1                                                                                                                     \
-    if (p.dbg & 16) t_w0 = __builtin_readcyclecounter();                                                                               \
-    if (!live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                        \
-    else if (sage >= 1 && !(p.dbg & 32)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      /* 8 + the 4 stores of the last drain (VM ops retire in order) */ \
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                                              \
-    if (p.dbg & 16) cyc_wait += __builtin_readcyclecounter() - t_w0;
-#define R8_WAIT_P3                                                                                                                     \
-    if (p.dbg & 16) t_w0 = __builtin_readcyclecounter();                                                                               \
-    if (!live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                        \
-    else if (sage >= 2 && !(p.dbg & 32)) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                             \
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                                              \
-    if (p.dbg & 16) cyc_wait += __builtin_readcyclecounter() - t_w0;
-#define R8_STEP(PI)                                                                                                                    \
-    {                                                                                                                                  \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) fb0[kk] = R8_LDS(kbase + RB(kk));                                             \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) fb1[kk] = R8_LDS(kbase + 16384 + RB(kk));                                     \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) fa[kk] = R8_LDS(kbase_a + RB(kk));                                            \
-        issue(2);                                                                                                                      \
-        if ((PI) == 0) { R8_INIT(0) }                                                                                                  \
-        if (sage > 0) --sage;                                                                                                          \
-        R8_COMPUTE(PI, 0)                                                                                                              \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) fa[kk] = R8_LDS(kbase_a + 4096 + RB(kk));                                     \
-        issue(3);                                                                                                                      \
-        if ((PI) == 1) { R8_INIT(1) }                                                                                                  \
-        R8_WAIT_P1                                                                                                                     \
-        if (sage > 0) --sage;                                                                                                          \
-        R8_COMPUTE(PI, 1)                                                                                                              \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) fa[kk] = R8_LDS(kbase_a + 16384 + RB(kk));                                    \
-        issue(0);                                                                                                                      \
-        if ((PI) == 2) { R8_INIT(2) }                                                                                                  \
-        if (sage > 0) --sage;                                                                                                          \
-        R8_COMPUTE(PI, 2)                                                                                                              \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) fa[kk] = R8_LDS(kbase_a + 16384 + 4096 + RB(kk));                             \
-        issue(1);                                                                                                                      \
-        if ((PI) == 3) { R8_INIT(3) }                                                                                                  \
-        R8_WAIT_P3                                                                                                                     \
-        if (sage > 0) --sage;                                                                                                          \
-        R8_COMPUTE(PI, 3)                                                                                                              \
-    }
-
-#pragma clang loop unroll(disable)
-    for (int s = 0; s < total_steps; ++s) {
-        const uint32_t kbase = (uint32_t)c_par * 65536u, kbase_a = kbase + a_minus_b;
-        c_par ^= 1;
-        const bool live = d_step < total_steps;
-        asm volatile("" : "+v"(lo));
-        if (pi == nk - 1) {          // block 0 finishes the group's current tile in this step: from here on, this is the tile being drained
-            d_valid = tcur >= 0 && tcur < T;
-            d_m0 = tile_m0(tcur) + g * 128;
-            d_full = d_m0 + 128 <= p.M;
-            if (DROP) d_e0 = (unsigned long long)(d_m0 + LO_FR) * (unsigned long long)(p.drop.row_mult * p.N) + (unsigned)(n0 + wn * 64 + 4 * LO_FH);
-            R8_STEP(-1)
-        } else if (pi == 0) {
-            ++tcur;
-            R8_STEP(0)
-        } else if (pi == 1) {
-            R8_STEP(1)
-        } else if (pi == 2) {
-            R8_STEP(2)
-        } else if (pi == 3) {
-            R8_STEP(3)
-        } else {
-            R8_STEP(9)
-        }
-        if (++pi == nk) pi = 0;
-    }
-    if (g == 0) __builtin_amdgcn_s_barrier();      // pairs with group 1's last barrier
-    if ((p.dbg & 16) && tid == 0) {      // cycles per step, cycles per step inside the two counted DMA waits, into the first floats of C
-        ((float*)p.C)[blockIdx.x * 2] = (float)(__builtin_readcyclecounter() - t_begin) / (float)total_steps;
-        ((float*)p.C)[blockIdx.x * 2 + 1] = (float)cyc_wait / (float)total_steps;
-    }
-#undef R8_LDS
-#undef RB
-#undef LO_FR
-#undef LO_FH
-#undef R8_GROUP
-#undef R8_STORE
-#undef R8_MF
-#undef R8_PIN
-#undef R8_INIT
-#undef R8_COMPUTE
-#undef R8_WAIT_P1
-#undef R8_WAIT_P3
-#undef R8_STEP
-}
-
-template <int ACT, bool DROP, bool BITS>
-static int launch_nt8r_inst(const GemmNtArgs& p, int n_cu, hipStream_t stream) {
-    const size_t lds = (size_t)R8_RING + R8_STAGE_BYTES;      // 160 KiB
-    static bool attr = false;
-    if (!attr) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt8r_bf16_kernel<ACT, DROP, BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
-    hipLaunchKernelGGL((gemm_nt8r_bf16_kernel<ACT, DROP, BITS>), dim3(n_cu), dim3(NT256_THREADS), lds, stream, p);
-    return svla_launch_status();
-}
-static int launch_nt8r(const GemmNtArgs& p, int n_cu, hipStream_t stream) {
-    const bool drop = p.drop.thr != 0, bits = p.act == ACT_RELU && p.bits_out;
-    switch (p.act) {
-        case ACT_NONE: return drop ? launch_nt8r_inst<ACT_NONE, true, false>(p, n_cu, stream) : launch_nt8r_inst<ACT_NONE, false, false>(p, n_cu, stream);
-        case ACT_RELU:
-            if (bits) return drop ? launch_nt8r_inst<ACT_RELU, true, true>(p, n_cu, stream) : launch_nt8r_inst<ACT_RELU, false, true>(p, n_cu, stream);
-            return drop ? launch_nt8r_inst<ACT_RELU, true, false>(p, n_cu, stream) : launch_nt8r_inst<ACT_RELU, false, false>(p, n_cu, stream);
-        default: return drop ? launch_nt8r_inst<ACT_GELU, true, false>(p, n_cu, stream) : launch_nt8r_inst<ACT_GELU, false, false>(p, n_cu, stream);
-    }
-}
-static inline bool nt_can_rotate(const GemmNtArgs& p) {
-    return !p.residual && !p.relu_mask && !p.bits_in && !p.out_f32 && (p.N % 256) == 0 && ((p.K / BK64) % 8) == 0 && (p.K % BK64) == 0 &&
-           (!p.bias || p.alpha == 1.f) && (32 % (p.N / 256)) == 0;
-}
-
-template <int ACT, int AUX>
+template <int ACT, int AUX, bool DROP>
 static int launch_nt256_inst(const GemmNtArgs& p, int grid, hipStream_t stream) {
     const size_t lds = (size_t)NS64 * 512 * BK64 * 2 + 32768;   // 160 KiB
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt256k64_bf16_kernel<ACT, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt256k64_bf16_kernel<ACT, AUX, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_nt256k64_bf16_kernel<ACT, AUX>), dim3(grid), dim3(NT256_THREADS), lds, stream, p);
+    hipLaunchKernelGGL((gemm_nt256k64_bf16_kernel<ACT, AUX, DROP>), dim3(grid), dim3(NT256_THREADS), lds, stream, p);
     return svla_launch_status();
 }
-// Kernel choice (measured, tools/ab_gemm.py, profiles/r03_nt_ab.txt): the 8-phase kernel's main loop is 8-10 % faster everywhere, its epilogue
-// (issued behind a 6-half-tile-deep DMA stream) slightly slower, so it wins where the K loop is long or the tile count per A panel is
-// 4 or 6 and loses a few per cent at N = 512 / 2048 with K = 512.  dbg bits 128 / 256 force the 2-buffer / the 8-phase kernel.
+// Kernel choice (measured, tools/ab_gemm.py, profiles/r03_nt_ab.txt): with the trimmed epilogue the 8-phase kernel wins on every shape of the
+// update (+2 ... +7 %); the 2-buffer kernel stays for N > 8192 (the LDS bias table) and as the A/B partner.  dbg bits 128 / 256 force the
+// 2-buffer / the 8-phase kernel.
 static inline bool nt_use_8p(const GemmNtArgs& p) {
     if (p.N > 8192 || (p.dbg & 128)) return false;
-    if (p.dbg & 256) return true;
-    return p.K >= 1024 || p.N == 1024 || p.N == 1536;
+    return true;
 }
-#define NT256_CASE(A_, X_) return nt_use_8p(p) ? launch_nt8p_inst<A_, X_>(p, grid, stream) : launch_nt256_inst<A_, X_>(p, grid, stream)
+// dropout is a compile-time flavour of the epilogue; instantiated for every (activation, operand) combination it can be requested with
+#define NT256_CASE(A_, X_)                                                                                                               \
+    return p.drop.thr ? (nt_use_8p(p) ? launch_nt8p_inst<A_, X_, true>(p, grid, stream) : launch_nt256_inst<A_, X_, true>(p, grid, stream))   \
+                      : (nt_use_8p(p) ? launch_nt8p_inst<A_, X_, false>(p, grid, stream) : launch_nt256_inst<A_, X_, false>(p, grid, stream))
 static int launch_nt256(const GemmNtArgs& p, int grid, hipStream_t stream) {
     const int aux = (p.residual ? 1 : 0) | (p.relu_mask ? 2 : 0);
     if (p.bits_in) {
@@ -1178,11 +893,6 @@ extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, lon
             if (n_cu < 8) n_cu = 8;
         }
         const int ntiles = ((M + 255) / 256) * ((N + 255) / 256);
-        // rotating kernel (no epilogue phase): needs enough m-blocks per workgroup to amortise its 7/8-tile start-up and drain
-        // (>= 6 m-blocks per workgroup; dbg bit 512 forces it for any size: tests)
-        if (nt_can_rotate(p) && !(g_dbg & (128 | 256)) && n_cu == 256 && ((g_dbg & 512) || (M + 255) / 256 >= 6 * 8 * (32 / (N / 256)))) {
-            return launch_nt8r(p, n_cu, (hipStream_t)stream);
-        }
         int grid = n_cu;                       // persistent: one 512-thread workgroup (160 KiB LDS) per CU
         while (grid > 8 && (grid / 8) * 8 > ntiles) grid -= 8;
         return launch_nt256(p, grid, (hipStream_t)stream);

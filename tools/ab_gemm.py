@@ -11,50 +11,33 @@ sel = lambda v: lib().call("svla_gemm_force_small_tile", 10 + v)
 
 # ---- correctness: every epilogue flavour, ragged M, several K
 torch.manual_seed(0)
-for (M, n, k) in [(256 * 300 + 77, 512, 512), (256 * 270, 1536, 128), (256 * 700 + 1, 256, 384), (256 * 256 + 255, 2048, 2048), (256 * 333 + 100, 1024, 1024), (256 * 1300, 512, 1536)]:
+for (M, n, k) in [(256 * 300 + 77, 512, 512), (256 * 270, 1536, 128), (256 * 700 + 1, 256, 384), (256 * 256 + 255, 2048, 2048), (256 * 333 + 100, 1024, 1024)]:
     A = torch.randn(M, k, device="cuda").to(torch.bfloat16); B = (torch.randn(n, k, device="cuda") * 0.05).to(torch.bfloat16)
     bias = torch.randn(n, device="cuda"); res = torch.randn(M, n, device="cuda").to(torch.bfloat16)
     mask = torch.randn(M, n, device="cuda").to(torch.bfloat16)
     for name, kw in [("plain", {}), ("bias+relu", dict(bias=bias, act=1)), ("bias+gelu", dict(bias=bias, act=2)), ("bias+res", dict(bias=bias, residual=res)),
                      ("mask", dict(relu_mask=mask)), ("mask+res", dict(relu_mask=mask, residual=res, alpha=0.5)), ("relu+res", dict(bias=bias, act=1, residual=res)), ("gelu+res", dict(bias=bias, act=2, residual=res))]:
         lib().call("svla_gemm_force_small_tile", 1); ref = ops.gemm_nt(A, B, M, n, k, **kw); torch.cuda.synchronize()
-        for v in [0]:
+        for v in [0, 128]:
             for rep in range(3):
                 sel(v); out = torch.full_like(ref, float("nan")); ops.gemm_nt(A, B, M, n, k, out=out, **kw); torch.cuda.synchronize()
                 bad = (out.view(torch.int16) != ref.view(torch.int16)).sum().item()
                 if bad: print(f"MISMATCH v{v} M={M} N={n} K={k} {name}: {bad} elements differ (rep {rep})", flush=True); break
-    # rotating kernel (flag 512 forces it where eligible): different summation order, so compare with a tolerance + the sign bits
-    if k % 512 == 0 and n % 256 == 0 and 32 % (n // 256) == 0:
-        for name, kw in [("plain", {}), ("bias", dict(bias=bias)), ("bias+relu+bits", dict(bias=bias, act=1)), ("bias+gelu", dict(bias=bias, act=2)), ("alpha", dict(alpha=0.5))]:
-            lib().call("svla_gemm_force_small_tile", 1); ref = ops.gemm_nt(A, B, M, n, k, **kw).float(); torch.cuda.synchronize()
-            for rep in range(6):
-                sel(512 | (32 if rep >= 3 else 0)); out = torch.full((M, n), float("nan"), device="cuda", dtype=torch.bfloat16)
-                kw2 = dict(kw)
-                if "relu" in name: kw2["relu_bits_out"] = torch.zeros(ops.relu_bits_bytes(M, n), device="cuda", dtype=torch.uint8)
-                ops.gemm_nt(A, B, M, n, k, out=out, **kw2); torch.cuda.synchronize()
-                d = (out.float() - ref).abs(); tol = 8e-3 * ref.abs() + 2e-2
-                nbad = (~(d <= tol)).sum().item()
-                if nbad: print(f"ROTATING MISMATCH M={M} N={n} K={k} {name}: {nbad} elements beyond tolerance, max abs diff {d[d==d].max().item() if (d==d).any() else float('nan'):.3e}, nan {(out!=out).sum().item()} (rep {rep})", flush=True); break
-                if "relu" in name:      # the sign bits must describe the stored output: feed them back as a mask
-                    sel(0); ones = torch.ones(M, n, device="cuda", dtype=torch.bfloat16)
-                    eye = torch.eye(n, device="cuda", dtype=torch.bfloat16)
-                    msk = ops.gemm_nt(ones[:, :n], eye, M, n, n, relu_bits=kw2["relu_bits_out"]) if n <= 2048 else None
-                    if msk is not None and not torch.equal(msk.float() > 0, out.float() > 0): print(f"ROTATING sign bits differ from output M={M} N={n} {name}", flush=True); break
-            else:
-                print(f"   rotating ok: {name} (max abs diff {d.max().item():.3e}, {(d > 0).float().mean().item()*100:.2f} % of elements differ from the 128-tile kernel)", flush=True)
     del A, B, res, mask
     print(f"checked M={M} N={n} K={k}", flush=True)
 sel(0)
 
 M = int(os.environ.get("AB_ROWS", 16384)) * 181
-for (n, k, flav) in [(512, 512, "plain"), (512, 512, "res"), (1536, 512, "bias"), (2048, 512, "relu"), (512, 2048, "res"), (512, 1536, "res"), (1024, 512, "bias")]:
+for (n, k, flav) in [(512, 512, "plain"), (512, 512, "res"), (512, 512, "res+drop"), (1536, 512, "bias"), (2048, 512, "relu"), (2048, 512, "relu+drop"), (512, 2048, "res"), (512, 2048, "res+drop"), (512, 1536, "res"), (1024, 512, "bias"), (2048, 512, "bits_in")]:
     A = torch.randn(M, k, device="cuda").to(torch.bfloat16); B = (torch.randn(n, k, device="cuda") * 0.05).to(torch.bfloat16)
     out = torch.empty(M, n, device="cuda", dtype=torch.bfloat16)
     bias = torch.randn(n, device="cuda")
     kw = {}
-    if flav == "res": kw = dict(bias=bias, residual=torch.randn(M, n, device="cuda").to(torch.bfloat16))
+    if flav.startswith("res"): kw = dict(bias=bias, residual=torch.randn(M, n, device="cuda").to(torch.bfloat16))
     elif flav == "bias": kw = dict(bias=bias)
-    elif flav == "relu": kw = dict(bias=bias, act=1, relu_bits_out=torch.empty(ops.relu_bits_bytes(M, n), device="cuda", dtype=torch.uint8))
+    elif flav.startswith("relu"): kw = dict(bias=bias, act=1, relu_bits_out=torch.empty(ops.relu_bits_bytes(M, n), device="cuda", dtype=torch.uint8))
+    elif flav == "bits_in": kw = dict(relu_bits=torch.randint(0, 255, (ops.relu_bits_bytes(M, n),), device="cuda", dtype=torch.uint8), alpha=1.0 / 0.9)
+    if flav.endswith("+drop"): kw["drop"] = ops.Dropout(1234, 5, 0.1)
     res = {}
     for rep in range(3):
         for abl in variants:
@@ -67,14 +50,10 @@ for (n, k, flav) in [(512, 512, "plain"), (512, 512, "res"), (1536, 512, "bias")
             e1.record(); torch.cuda.synchronize()
             res.setdefault(abl, []).append(e0.elapsed_time(e1) / 10)
     if os.environ.get("AB_CYCLES"):
-        sel(256 + 16); ops.gemm_nt(A, B, M, n, k, out=out, **kw); torch.cuda.synchronize()
-        c = out.view(-1)[:1024].view(torch.float32)[:512].view(256, 2)
-        print(f"   8-phase kernel: {c[:, 0].mean().item():.0f} shader cycles per K-tile in the main loop (2048 = MFMA-bound), {c[:, 1].mean().item():.0f} per tile in the epilogue", flush=True)
-        if flav not in ("res",):
-            for fl in (16, 16 + 64, 16 + 1024, 16 + 2048, 16 + 1024 + 2048):
-                sel(fl); ops.gemm_nt(A, B, M, n, k, out=out, **kw); torch.cuda.synchronize()
-                c = out.view(-1)[:1024].view(torch.float32)[:512].view(256, 2)
-                print(f"   rotating kernel (flags {fl}): {c[:, 0].mean().item():.0f} shader cycles per step (2048 = MFMA-bound), {c[:, 1].mean().item():.0f} of them inside the two counted DMA waits", flush=True)
+        for extra, tag in ((0, "full"), (2, "no epilogue"), (2 + 8, "no epilogue, operands from L2"), (2 + 32, "no epilogue, no DMA")):
+            sel(256 + 16 + extra); ops.gemm_nt(A, B, M, n, k, out=out, **kw); torch.cuda.synchronize()
+            c = out.view(-1)[:1024].view(torch.float32)[:512].view(256, 2)
+            print(f"   8-phase kernel ({tag}): {c[:, 0].mean().item():.0f} shader cycles per K-tile in the main loop (2048 = MFMA-bound), {c[:, 1].mean().item():.0f} per tile in the epilogue", flush=True)
     sel(0)
     print(f"N={n} K={k} {flav}: " + "  ".join(f"v{a}: {min(t):.3f} ms ({2*M*n*k/min(t)/1e9:.0f} TF)" for a, t in res.items()), flush=True)
     del A, B, out, kw
