@@ -247,6 +247,19 @@ def stock_rocm_baseline(dev, L=12, train_mode=True, T=64, B=8):
     return out
 
 
+def kernel_sources_sha():
+    """sha256 over the HIP sources + headers the library is built from (what a profiles/*_pmc_hbm_traffic.json must have been measured on)."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "safevla_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "safevla_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def parity_gate(dev, T=8, B=4):
     """the parity gate of the same run.  One seeded (T x B)-row minibatch through the CPU oracle (the checker) and through
     the HIP path with the same weights, eval mode: the fp32 verification mode must agree at fp32 tolerance (1e-4), the bf16 product path
@@ -371,6 +384,10 @@ def main():
     ap.add_argument("--env-chunk", type=int, default=0, help="envs per gradient-accumulation chunk (0: the whole local minibatch in one pass -- 16 384 rows "
                     "keep ~140 GB of one tower's activations resident, which is what 288 GB of HBM are for; measured +1.9 %% over 2 chunks of 32)")
     ap.add_argument("--cost-limit", type=float, default=2.31964)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): every GPU runs --envs-per-gpu envs; strong: --global-envs envs (BASELINE configs[3]: Fetch, 256) are sharded "
+                         "over the ranks with parallel.shard_envs, the reference's evenly_distribute_count_into_bins (training/online/base.py:208-224)")
+    ap.add_argument("--global-envs", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -401,6 +418,10 @@ def main():
         parallel.broadcast_model_(model)
     torch.manual_seed(1234 + rank)   # per-rank streams from here on (sampling, synthetic environments)
     T, B = args.T, args.envs_per_gpu
+    if args.scaling == "strong":      # fixed total work: this rank's share of the global env list (uneven shards are legal)
+        _first, B = parallel.shard_envs(args.global_envs, world, rank)      # (first env, number of envs) of this rank
+        if B <= 0:
+            raise SystemExit(f"bench.py --scaling strong: {args.global_envs} envs cannot feed {world} ranks")
     chunk = args.env_chunk if 0 < args.env_chunk < B else None
     cfg = PPOLagConfig(env_chunk=chunk, cost_limit=args.cost_limit)
     eng = PPOLagEngine(model, cfg)
@@ -419,13 +440,14 @@ def main():
         cfg = PPOLagConfig(env_chunk=chunk, cost_limit=args.cost_limit)
         eng = PPOLagEngine(model, cfg)
         ms, info, step = timed_updates(eng, st, nxt, ep, args.steps, args.warmup, world, dev)
-    env_steps = T * B * world
+    env_steps = T * (args.global_envs if args.scaling == "strong" else B * world)
     S, R = 169 + args.L, T * B
     U = int(st.observations["goal_token_ids"][:T].reshape(R, -1).unique(dim=0).shape[0])
     algo = flops_per_update(R, S, args.L, U, cfg.update_repeats)
 
     roof = None
     gt = None
+    parity_failed = False
     if not args.no_roofline:
         # one extra, instrumented update: EVERY rank runs it (it contains the gradient / cost all-reduces), rank 0 times its
         # MFMA-kernel launches with HIP events
@@ -439,19 +461,24 @@ def main():
         allk = gt.summary()
         g = allk["gemm_nt256"]
         executed = sum(v["flops"] for v in allk.values())
-        traffic, traffic_src = None, None   # HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/, collected offline)
-        for cand in ("r02_pmc_hbm_traffic.json", "r01g_pmc_hbm_traffic.json"):
+        # HBM bytes per launch from the rocprofv3 PMC passes of this same command (tools/profile_round.sh -> profiles/).  The file carries the
+        # hash of the kernel sources it was measured on: a file from another build is refused (traffic = null) instead of being quoted
+        traffic, traffic_src = None, None
+        for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_hbm_traffic.json")), reverse=True):
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", cand)))["kernels"]
-                inst = [v for k, v in pm.items() if "gemm_nt256" in k]      # one entry per epilogue instantiation: launch-weighted mean
+                doc = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                if doc.get("kernel_sources_sha256") != kernel_sources_sha():
+                    continue
+                inst = [v for k, v in doc["kernels"].items() if "gemm_nt8p" in k or "gemm_nt256" in k]      # one entry per epilogue instantiation: launch-weighted mean
                 traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in inst) / sum(v["launches"] for v in inst))
                 traffic_src = cand
                 break
             except Exception:
                 pass
-        roof = {"bound": "mfma", "kernel": "gemm_nt256k64_bf16_kernel (svla_gemm_nt_bf16, persistent 256x256 tile, BK=64)", "achieved": round(g["tflops"], 1),
+        roof = {"bound": "mfma", "kernel": "gemm_nt8p_bf16_kernel (svla_gemm_nt_bf16: persistent 256x256x64 tile, 8-phase ping-pong over a 16-KiB half-tile LDS-DMA ring)", "achieved": round(g["tflops"], 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(g["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_unit": f"HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/{traffic_src}; launch-weighted over the epilogue instantiations)",
+                "traffic_unit": (f"HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/{traffic_src}, same kernel sources as this build; launch-weighted over the epilogue instantiations)"
+                                 if traffic is not None else "null: no profiles/*_pmc_hbm_traffic.json was measured on this build's kernel sources (tools/profile_round.sh)"),
                 "launches_per_update": g["launches"], "avg_launch_ms": round(g["avg_ms"], 4), "flops_per_launch": g["flops"] / max(1, g["launches"]),
                 "share_of_update": round(g["total_s"] / (ms * 1e-3), 3),
                 "other_mfma_kernels": {k: {"achieved_tflops": round(v["tflops"], 1), "launches": v["launches"], "avg_launch_ms": round(v["avg_ms"], 4),
@@ -504,12 +531,14 @@ def main():
         out = {"metric": "env-steps/sec through PPO-Lagrangian update", "value": round(env_steps / (ms * 1e-3), 1), "unit": "env-steps/s",
                "n_gpus": world, "rccl_ranks": (torch.distributed.get_world_size() if world > 1 else 1),
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"C3: {args.task}, {B} envs/GPU x T={T}-step rollout, cost constraint active (cost_limit {args.cost_limit}) "
-                                      f"(BASELINE configs[2]{'' if world == 1 else ', replicated per GPU: weak scaling'}), "
+               "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": (f"C4: {args.task}, {args.global_envs} envs sharded over {world} GPU(s) ({B} on rank 0) x T={T}-step rollout "
+                                       f"(BASELINE configs[3], strong scaling), cost_limit {args.cost_limit}, " if args.scaling == "strong" else
+                                       f"C3: {args.task}, {B} envs/GPU x T={T}-step rollout, cost constraint active (cost_limit {args.cost_limit}) "
+                                       f"(BASELINE configs[2]{'' if world == 1 else ', replicated per GPU: weak scaling'}), ") +
                                       f"L={args.L} goal tokens, S={S} fusion tokens, 3 towers x 4 epochs x 1 minibatch"
                                       f"{'' if chunk is None else f' in {B // chunk} env-chunks of {chunk}'}, Adam+clip",
-                          "global_envs": B * world, "rollout_steps": T, "rows_per_gpu": R, "parallelism": f"dp{world}", "env_chunk": chunk,
+                          "global_envs": args.global_envs if args.scaling == "strong" else B * world, "rollout_steps": T, "rows_per_gpu": R, "parallelism": f"dp{world}", "env_chunk": chunk,
                           "stage_losses": list(cfg.stage_losses), "weights": "random-init, reference geometry (168.9 M params)",
                           "dropout": 0.0 if args.eval_mode else 0.1},
                "reference_equivalent_tflop_per_update": round(algo / 1e12, 1),
@@ -517,10 +546,16 @@ def main():
                        "layer only for the consumed token, T5 once per unique goal) -- see roofline.executed_mfma_*",
                "loss": {k: (round(v, 5) if isinstance(v, float) else v) for k, v in info.items()},
                "roofline": roof, "cpu_baseline": cpu, "acting": acting, "north_star_batch256": ns, "secondary": secondary}
+        pg = (cpu or {}).get("parity_gate")
+        if pg is not None:      # the gate ran: a regression against the CPU oracle (or an exception inside the gate) fails the run
+            out["parity_ok"] = bool("error" not in pg and pg.get("fp32", {}).get("passed") and pg.get("bf16", {}).get("passed"))
+            parity_failed = not out["parity_ok"]
         print(json.dumps(out), flush=True)
     if world > 1:
         parallel.barrier()
         torch.distributed.destroy_process_group()
+    if parity_failed:
+        raise SystemExit("bench.py: parity gate FAILED against the CPU oracle (see cpu_baseline.parity_gate in the line above)")
 
 
 if __name__ == "__main__":

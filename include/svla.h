@@ -20,12 +20,12 @@ typedef uint16_t svla_bf16;
 /* Train-mode dropout.  The reference leaves the policy in train() mode (allenact_dino_transformer.py:193), so the dropout 0.1 of
  * nn.TransformerEncoderLayer (attention probabilities, both sub-layer outputs, the feed-forward activation; :545-552) is active in
  * rollouts and updates.  Here it is counter-based and stateless (forward and backward regenerate the same mask, nothing is stored):
- *   r    = lowbias32((uint32)(e>>1) * 0x9E3779B1 ^ (uint32)(e>>33) * 0x85EBCA77 ^ seed ^ stream * 0xC2B2AE3D)
+ *   r    = mix24((uint32)(e>>1) * 0x9E3779B1 ^ (uint32)(e>>33) * 0x85EBCA77 ^ seed ^ stream * 0xC2B2AE3D)
  *   keep = ((e & 1) ? r >> 16 : r & 0xffff) >= (uint32)(p * 65536 + 0.5);   kept values are scaled by 1 / (1 - p)
  * with e = the element's flat index in its site's logical tensor: (row * row_mult) * N + col for [rows, N] activations (row_mult
  * > 1 when only every row_mult-th row of the logical tensor is materialised), ((row*H + head)*S + query)*S4 + key for attention
  * probabilities with the key stride S rounded up to a multiple of 4.  seed_dev != NULL: the pass seed is read from device memory
- * when the kernel starts instead of `seed` (a captured HIP graph of the launch-bound acting step replays with fresh noise).  lowbias32(x): x ^= x>>16; x *= 0x7FEB352D; x ^= x>>15; x *= 0x846CA68B; x ^= x>>16.  NULL / p == 0: no dropout. */
+ * when the kernel starts instead of `seed` (a captured HIP graph of the launch-bound acting step replays with fresh noise).  mix24(x): x ^= x>>16; x = (x & 0xffffff) * 0xEB352D; x ^= x>>13; x = (x & 0xffffff) * 0x6CA68B; x ^= x>>16 (mod 2^32: the 24-bit multiplies are full-rate on CDNA, 32-bit ones quarter-rate).  NULL / p == 0: no dropout. */
 typedef struct svla_dropout { unsigned seed, stream; float p; int row_mult; const unsigned* seed_dev; } svla_dropout;
 
 /* ---- rollout statistics ------------------------------------------------------------------------------ */

@@ -143,7 +143,9 @@ def hash_keep(seed: int, stream: int, p: float, idx: np.ndarray) -> np.ndarray:
         x = (pair & np.uint64(0xFFFFFFFF)).astype(np.uint32) * np.uint32(0x9E3779B1)
         x ^= (pair >> np.uint64(32)).astype(np.uint32) * np.uint32(0x85EBCA77)
         x ^= key
-        x ^= x >> np.uint32(16); x *= np.uint32(0x7FEB352D); x ^= x >> np.uint32(15); x *= np.uint32(0x846CA68B); x ^= x >> np.uint32(16)
+        # mixer (safevla_amd/csrc/common.h: drop_mix): xorshift-multiply rounds on 24-bit multiplies, low 32 bits of (x & 0xffffff) * K
+        m24 = np.uint32(0xFFFFFF)
+        x ^= x >> np.uint32(16); x = (x & m24) * np.uint32(0xEB352D); x ^= x >> np.uint32(13); x = (x & m24) * np.uint32(0x6CA68B); x ^= x >> np.uint32(16)
         bits = np.where((idx & np.uint64(1)) != 0, x >> np.uint32(16), x & np.uint32(0xFFFF))
         thr = np.uint32(np.float32(p) * np.float32(65536.0) + np.float32(0.5))
     return bits >= thr

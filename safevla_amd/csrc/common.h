@@ -85,11 +85,17 @@ __device__ __forceinline__ DropCfg drop_resolve(DropCfg c) {
     if (c.thr && c.seed_dev) c.key = *c.seed_dev ^ c.stream_key;
     return c;
 }
+// mixer of the dropout hash: two xorshift-multiply rounds on 24-bit multiplies (v_mul_u32_u24 is full rate on CDNA, the 32-bit
+// v_mul_lo_u32 of the usual lowbias32 quarter rate -- the hash is the VALU hot spot of every train-mode epilogue and of the attention
+// kernels).  umul24(x, K) = low 32 bits of (x & 0xffffff) * K, K < 2^24.
+__device__ __forceinline__ unsigned drop_mix(unsigned x) {
+    x ^= x >> 16; x = __umul24(x, 0xEB352Du); x ^= x >> 13; x = __umul24(x, 0x6CA68Bu); x ^= x >> 16;
+    return x;
+}
 // 32 random bits for the element pair (e >> 1): low half -> even element, high half -> odd element
 __device__ __forceinline__ unsigned drop_bits(unsigned key, unsigned long long pair) {
     unsigned x = ((unsigned)pair * 0x9E3779B1u) ^ ((unsigned)(pair >> 32) * 0x85EBCA77u) ^ key;
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-    return x;
+    return drop_mix(x);
 }
 // keep-mask (bit i <=> element e0 + i kept) of 4 consecutive elements, e0 % 4 == 0
 __device__ __forceinline__ unsigned drop_keep4(const DropCfg& c, unsigned long long e0) {

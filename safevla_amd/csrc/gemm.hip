@@ -425,7 +425,7 @@ struct Nt256Epi {
                             const uint32_t c = (uint32_t)(j * 16 + rg * 4 + h);
                             const uint32_t hb = (dP_lo + c < c) ? dB1 + 0x85EBCA77u : dB1;
                             unsigned x = (dA1 + c * 0x9E3779B1u) ^ hb ^ p.drop.key;
-                            x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+                            x = drop_mix(x);
                             keep |= ((x & 0xffffu) >= p.drop.thr ? 1u : 0u) << (2 * h);
                             keep |= ((x >> 16) >= p.drop.thr ? 2u : 0u) << (2 * h);
                         }
@@ -864,7 +864,7 @@ static int launch_nt256(const GemmNtArgs& p, int grid, hipStream_t stream) {
 #undef NT256_CASE
 
 static int g_force_small_tile = 0, g_dbg = 0;
-// on = 0/1: normal dispatch / force the 128x128 kernels; on = 10 + f: flags f of the 256-tile kernels -- timing-only ablations 1 / 2 / 64,
+// on = 0/1/2: normal dispatch / force the 128x128 kernels / force the 256-tile kernels wherever their shape constraints hold (tests); on = 10 + f: flags f of the 256-tile kernels -- timing-only ablations 1 / 2 / 64,
 // 128 / 256 = force the 2-buffer kernel (gemm_nt256k64) / the 8-phase kernel (gemm_nt8p) (A/B comparisons)
 extern "C" int svla_gemm_force_small_tile(int on) {
     if (on >= 10) { g_dbg = on - 10; g_force_small_tile = 0; }
@@ -883,7 +883,7 @@ extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, lon
     GemmNtArgs p{A, lda, B, ldb, bias, residual, ldr, relu_mask, ldm, C, ldc, M, N, K, act, out_f32, alpha, relu_bits_out, relu_bits, drop_cfg(drop), g_dbg};
     // N % 256 == 128 with N >= 384 (the ViT-S widths 384 and 1152): the last n-tile is a half tile (75 % / 90 % of the MFMA work useful) --
     // still well ahead of the 128-tile kernel
-    if (!out_f32 && ((N % 256) == 0 || ((N % 128) == 0 && N >= 384)) && (K % BK64) == 0 && K >= 2 * BK64 && (long)((M + 255) / 256) * ((N + 255) / 256) >= 256 && !g_force_small_tile) {
+    if (!out_f32 && ((N % 256) == 0 || ((N % 128) == 0 && N >= 384)) && (K % BK64) == 0 && K >= 2 * BK64 && ((long)((M + 255) / 256) * ((N + 255) / 256) >= 256 || g_force_small_tile == 2) && g_force_small_tile != 1) {
         static int n_cu = 0;
         if (!n_cu) {
             int dev = 0;
@@ -1310,7 +1310,18 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_tn8p_bf16_kernel(GemmTn
 extern "C" int svla_gemm_tn_f32acc(const bf16_t* dY, long ldy, const bf16_t* X, long ldx, float* dW, long ldw, float* db, int M,
                                    int N, int K, void* stream) {
     if (M <= 0 || (N % 128) || (K % 128) || (ldy % 8) || (ldx % 8)) return SVLA_EINVAL;
-    if ((N % 256) == 0 && (K % 256) == 0 && (M % TN256_ROWS) == 0 && M >= 32768 && !g_force_small_tile) {   // (59.6 k-row minibatches: 256 rows x 233 tokens)
+    if (g_force_small_tile == 2 && (N % 256) == 0 && (K % 256) == 0 && M >= 2 * TN256_ROWS && (M % TN256_ROWS) != 0) {
+        // forced big-tile mode (tests: the reference goldens through the kernels that carry the update): whole 64-row groups on the 256-tile
+        // kernel, the ragged tail on the small one
+        const int mb = M / TN256_ROWS * TN256_ROWS;
+        int rc = svla_gemm_tn_f32acc(dY, ldy, X, ldx, dW, ldw, db, mb, N, K, stream);
+        if (rc) return rc;
+        g_force_small_tile = 1;
+        rc = svla_gemm_tn_f32acc(dY + (size_t)mb * ldy, ldy, X + (size_t)mb * ldx, ldx, dW, ldw, db, M - mb, N, K, stream);
+        g_force_small_tile = 2;
+        return rc;
+    }
+    if ((N % 256) == 0 && (K % 256) == 0 && (M % TN256_ROWS) == 0 && (M >= 32768 || g_force_small_tile == 2) && g_force_small_tile != 1) {   // (59.6 k-row minibatches: 256 rows x 233 tokens)
         const int ntile256 = (N / 256) * (K / 256);
         int chunks = 256 / ntile256;                                  // <= one workgroup per CU (no second dispatch wave)
         if (chunks < 1) chunks = 1;

@@ -64,12 +64,14 @@ class PPOLagEngine:
         self.opt_step = 0                     # optimiser steps taken (any tower)
         self.tower_steps = [0, 0, 0]          # torch.optim.Adam's per-parameter ``step`` (identical within a tower)
         self._pending = []                    # async all-reduce handles of the current minibatch
-        self._count_cache = {}
         self._chunk_cache = {}                # small minibatches: recorded launch sequences per env-chunk, valid within one update
         dev = model.device_
         self._gnorm_sq = torch.zeros(1, device=dev, dtype=torch.float64)
         self._sums = torch.zeros(5, device=dev, dtype=torch.float64)   # v_sq, action, -entropy, hl-gauss CE (discrete critic), c_v_sq
         self.gemm_flops = 0
+        if not hasattr(model, "_invalidate_hooks"):
+            model._invalidate_hooks = []
+        model._invalidate_hooks.append(self._chunk_cache.clear)      # load_state_dict / broadcast replace the frozen encoder's tensors
         if parallel.is_dist():      # independent dropout noise per rank (every rank holds different environments)
             for t in model.towers:
                 t.drop_seed_base += 7919 * torch.distributed.get_rank()
@@ -221,13 +223,13 @@ class PPOLagEngine:
                           cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps, gnorm_sq=self._gnorm_sq, max_norm=cfg.max_grad_norm)
             self.model.towers[k].refresh_transposes()
 
-    def _global_rows(self, local_rows: int, dev) -> int:
-        """Rows of the minibatch over all ranks: reduced once per local geometry, then cached (no per-minibatch host sync)."""
+    def _global_rows(self, local_rows, dev):
+        """Global row counts of a list of local counts (every minibatch of the update + the whole rollout): ONE all-reduce, issued by every
+        rank at the same point of update() whatever its shard size -- env shards may be uneven (parallel.shard_envs), so a per-value cache
+        would make ranks issue different numbers of collectives."""
         if not parallel.is_dist():
-            return int(local_rows)
-        if local_rows not in self._count_cache:
-            self._count_cache[local_rows] = parallel.global_count(local_rows, dev)
-        return self._count_cache[local_rows]
+            return [int(r) for r in local_rows]
+        return parallel.global_counts(local_rows, dev)
 
     # ---- one full PPO-Lagrangian update on a filled storage --------------------------------------------------------------
     def update(self, storage: RolloutStorage, next_value: torch.Tensor, next_c_value: torch.Tensor,
@@ -241,12 +243,16 @@ class PPOLagEngine:
         T, B = storage.T, storage.B
         info_acc = torch.zeros(5, device=dev, dtype=torch.float64)
         n_mb = 0
+        bounds = [round(i * B / cfg.num_mini_batch) for i in range(cfg.num_mini_batch + 1)]
+        counts = self._global_rows([T * (bounds[i + 1] - bounds[i]) for i in range(cfg.num_mini_batch)] + [T * B], dev)
+        if parallel.is_dist() and cfg.num_mini_batch > 1:
+            # the i-th minibatch of every rank forms ONE global minibatch: all ranks must walk them in the same order
+            generator = torch.Generator().manual_seed(0x5AFE + self.opt_step)
         for _ in range(cfg.update_repeats):
-            bounds = [round(i * B / cfg.num_mini_batch) for i in range(cfg.num_mini_batch + 1)]
             order = torch.randperm(cfg.num_mini_batch, generator=generator).tolist() if cfg.num_mini_batch > 1 else [0]
             for i in order:
                 b0, b1 = bounds[i], bounds[i + 1]
-                n_total = self._global_rows(T * (b1 - b0), dev)
+                n_total = counts[i]
                 m.zero_grad()
                 self._sums.zero_()
                 chunk = cfg.env_chunk or (b1 - b0)
@@ -261,4 +267,4 @@ class PPOLagEngine:
         value, action, ent, c_value = 0.5 * (s[3] if m.critic_type == "discrete" else s[0]), s[1], s[2], 0.5 * s[4]
         return {"ppo_total": cfg.value_loss_coef * value + cfg.action_weight * action + cfg.entropy_coef * ent, "value": value,
                 "action": action, "entropy": ent, "c_value": c_value, "lagrangian_multiplier": lam, "Jc": Jc,
-                "env_steps": self._global_rows(T * B, dev)}
+                "env_steps": counts[-1]}

@@ -52,6 +52,11 @@ class SafePPOLogGrad:
         aw = float(self.action_loss_schedule(step_count))
         inv_n = 1.0 / float(n_total if n_total is not None else R)
         f = lambda t: t.reshape(R).contiguous().float()
+        for key in (self.adv_key,) + ((self.c_adv_key,) if self.safe else ()):
+            if key not in batch:
+                raise KeyError(f"{type(self).__name__}(normalize_advantage=True) reads batch['{key}']: build the batch with "
+                               "RolloutStorage.batch_slice(..., normalized=True), or construct the loss with normalize_advantage=False "
+                               "(what the reference config does: dinov2_vits_tsfm_base.py:314-322)")
         c_adv = f(batch[self.c_adv_key]) if self.safe else None
         ex = getattr(actor_critic_output, "extras", {}) or {}
         if self.discrete_critics:
@@ -97,9 +102,10 @@ class PPOLogGrad(SafePPOLogGrad):
 class _ValueLoss:
     values_key, returns_key, info_key = "values", "returns", "value"
 
-    def __init__(self, clip_param: float = 0.1, use_clipped_value_loss: bool = False, clip_decay: Optional[Callable[[int], float]] = None, **kw):
-        """Upstream AllenAct ``PPOValue(clip_param, use_clipped_value_loss=True, clip_decay=None)`` [3P]; the reference instantiates it
-        with ``use_clipped_value_loss=False`` through ``NewPPOConfig`` (dinov2_vits_tsfm_base.py:314-322,337-342)."""
+    def __init__(self, clip_param: float = 0.1, use_clipped_value_loss: bool = True, clip_decay: Optional[Callable[[int], float]] = None, **kw):
+        """Upstream AllenAct ``PPOValue(clip_param, use_clipped_value_loss=True, clip_decay=None)`` [3P] -- same defaults; the reference
+        instantiates it with ``use_clipped_value_loss=False`` through ``NewPPOConfig`` (dinov2_vits_tsfm_base.py:314-322,337-342), and so
+        does every config in this repo (train.py, bench.py)."""
         self.clip_param, self.use_clipped_value_loss = clip_param, use_clipped_value_loss
         self.clip_decay = clip_decay if clip_decay is not None else (lambda x: 1.0)
 

@@ -791,6 +791,17 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
             if frozen:
                 t.visual_encoder.text_encoder.sync(t.adt)
                 t._t5_cache = (None, None)
+        if frozen:
+            # T5Frozen.sync() REPLACES the encoder's runtime tensors: recorded acting steps (and the engine's recorded env-chunks, through
+            # the hook below) hold the old ones alive and would keep acting on the previous encoder while updates use the new one
+            self.invalidate_recorded()
+
+    def invalidate_recorded(self):
+        """Drop every recorded launch sequence / captured graph that may reference replaced tensors."""
+        if getattr(self, "_acting_graphs", None) is not None:
+            self._acting_graphs.clear()
+        for hook in getattr(self, "_invalidate_hooks", []):
+            hook()
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         r = super().load_state_dict(state_dict, strict=strict, **kw)
@@ -941,6 +952,8 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
                 t._ar_steps = torch.arange(t.max_steps, device=dev)
                 if getattr(t, "_seed_dev_buf", None) is None:
                     t._seed_dev_buf = torch.tensor([(t.drop_seed_base * 0x9E3779B1) & 0x7FFFFFFF], device=dev, dtype=torch.int32)
+            for k_old in [k_ for k_ in self._acting_graphs if k_[4] != key[4]]:      # plans of replaced KV caches keep B x max_steps x 1024 x layers x 3 alive
+                del self._acting_graphs[k_old]
             self._acting_graphs[key] = st
         # per-step inputs -> static buffers
         st.tokens.copy_(prep.tokens); st.prev_actions.copy_(prep.prev_actions); st.masks.copy_(prep.masks); st.hand.copy_(prep.hand)

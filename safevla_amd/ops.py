@@ -263,8 +263,10 @@ def relu_bits_bytes(M: int, N: int) -> int:
     return ((M + 31) // 32) * 32 * (N // 8)
 
 
-def gemm_force_small_tile(on: bool):
-    lib().call("svla_gemm_force_small_tile", int(bool(on)))
+def gemm_force_small_tile(on):
+    """0 / False: normal dispatch; 1 / True: force the 128-tile GEMM kernels; 2: force the 256-tile kernels (the ones that carry the update)
+    wherever their shape constraints hold, whatever the problem size (tests at golden-fixture sizes)."""
+    lib().call("svla_gemm_force_small_tile", int(on))
 
 
 def gemm_tn_acc(dY, X, dW, M, N, K, ldy=None, ldx=None, ldw=None, db=None):

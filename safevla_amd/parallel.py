@@ -99,6 +99,15 @@ def global_count(local: int, device, group=None) -> int:
     return int(round(t.item()))
 
 
+def global_counts(local, device, group=None):
+    """Element-wise global sums of a list of local counts in ONE all-reduce (the same collective on every rank, whatever its shard)."""
+    if not is_dist():
+        return [int(v) for v in local]
+    t = torch.tensor([float(v) for v in local], device=device, dtype=torch.float64)
+    dist.all_reduce(t, group=group)
+    return [int(round(v)) for v in t.tolist()]
+
+
 def mean_episode_cost(sum_cost: float, n_episodes: float, device, group=None) -> Tuple[float, float]:
     """Global Jc = sum of finished-episode costs / number of finished episodes (identical on every rank)."""
     t = torch.tensor([float(sum_cost), float(n_episodes)], device=device, dtype=torch.float64)

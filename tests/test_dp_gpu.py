@@ -47,3 +47,28 @@ def test_two_ranks_equal_single_process_gradient(tmp_path, backend):
     assert err < 2e-3, err
     cos = torch.nn.functional.cosine_similarity(got["flat_g"].double(), want_g.double(), dim=0).item()
     assert cos > 0.99999, cos
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_well_formed_line(scaling):
+    """bench.py itself under two ranks (gloo: they share the test box's one GPU), launched the way the driver launches it for N > 1, so that
+    the first real SCALE run cannot die on plumbing.  "strong": 7 envs sharded 4 + 3 -- uneven shards through the engine's single
+    count all-reduce."""
+    import json
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SVLA_DIST_BACKEND="gloo")
+    port = 29950 + (os.getpid() % 40) + (0 if scaling == "weak" else 41)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--T", "8",
+           "--envs-per-gpu", "4", "--no-cpu-baseline", "--no-secondary", "--scaling", scaling, "--global-envs", "7"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["scaling"] == scaling and out["steps"] == 1
+    envs = 7 if scaling == "strong" else 8
+    assert out["config"]["global_envs"] == envs and out["loss"]["env_steps"] == 8 * envs
+    assert out["value"] > 0 and abs(out["value"] - 8 * envs / (out["ms_per_step"] * 1e-3)) < 1e-2 * out["value"]
+    assert out["roofline"] is not None and "frac" in out["roofline"]

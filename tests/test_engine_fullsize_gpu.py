@@ -47,6 +47,37 @@ def test_c2_chunked_accumulation_equals_unchunked_gradient(model):
         assert grads[None][lo:hi].abs().sum().item() > 0
 
 
+def test_c3_unchunked_pass_equals_chunked_gradient(model):
+    """The bench's exact execution: C3 (64 envs x 256 steps = 16 384 rows) in ONE pass per tower (~140 GB of one tower's saved
+    activations resident, env_chunk=None) against the same minibatch accumulated over two env-chunks of 32, eval mode."""
+    from safevla_amd.engine import PPOLagConfig, PPOLagEngine
+    from safevla_amd.synth_env import SynthSpec, fill_synthetic_rollout
+
+    model.eval()
+    T, B = 256, 64
+    st, nxt, ep = fill_synthetic_rollout(model, SynthSpec(T=T, B=B, L=12, task="PickUp", seed=12), device=DEV)
+    st.compute_returns(nxt["next_value"], nxt["next_c_value"])
+    grads, sums = {}, {}
+    for chunk in (None, 32):
+        eng = PPOLagEngine(model, PPOLagConfig(env_chunk=chunk, cost_limit=2.31964))
+        model.zero_grad()
+        eng._sums.zero_()
+        step = chunk or B
+        for c0 in range(0, B, step):
+            eng._accumulate(st.batch_slice(c0, c0 + step), T * B, 0.2, last=c0 + step >= B)
+        grads[chunk], sums[chunk] = model.arena.flat_g.clone(), eng._sums.clone()
+        del eng
+        torch.cuda.empty_cache()
+    a, b = grads[None].double(), grads[32].double()
+    assert torch.isfinite(a).all() and a.norm().item() > 0
+    assert torch.nn.functional.cosine_similarity(a, b, dim=0).item() > 0.9999
+    assert ((a - b).norm() / a.norm()).item() < 1e-2
+    np.testing.assert_allclose(sums[None].cpu().numpy(), sums[32].cpu().numpy(), rtol=1e-4, atol=1e-6)
+    for lo, hi in model.arena.tower_ranges:
+        assert grads[None][lo:hi].abs().sum().item() > 0
+    model.zero_grad()
+
+
 def test_c3_full_update_lambda_active(model):
     """BASELINE configs[2]: PickUp, 64 envs x 256 steps, cost_limit 2.31964 (README.md:255), env-chunk 32, train mode (dropout on)."""
     from safevla_amd.engine import PPOLagConfig, PPOLagEngine

@@ -53,3 +53,21 @@ def test_lagrange_monotone_and_clamped():
     assert all(b > a for a, b in zip(up, up[1:]))
     down = [lag.update(0.0) for _ in range(400)]
     assert down[-1] == 0.0 and min(down) >= 0.0
+
+
+def test_dropout_hash_statistics():
+    """The counter-based dropout mask (include/svla.h: svla_dropout; oracle.ref_model.hash_keep == csrc/common.h: drop_bits): keep rate and
+    independence of neighbouring elements / sites on 2e6 indices beyond 2^32 (both index words in play)."""
+    import numpy as np
+    from oracle.ref_model import hash_keep
+
+    n = 2_000_000
+    idx = np.arange(n, dtype=np.uint64) + np.uint64(6_000_000_000)
+    sig = (0.9 * 0.1 / n) ** 0.5
+    for seed, stream in [(0x5AFE, 3), (987654321, 40)]:
+        k = hash_keep(seed, stream, 0.1, idx).astype(np.float64)
+        assert abs(k.mean() - (1 - 6554 / 65536)) < 5 * sig
+        for lag in (1, 2, 3, 4, 512, 2048):
+            assert abs(np.corrcoef(k[:-lag], k[lag:])[0, 1]) < 5 / n ** 0.5
+        k2 = hash_keep(seed, stream + 1, 0.1, idx).astype(np.float64)
+        assert abs(np.corrcoef(k, k2)[0, 1]) < 5 / n ** 0.5

@@ -14,6 +14,13 @@ def stats(db, out, title):
     open(out, "w").write("\n".join(o) + "\n")
     print("\n".join(o[:14]))
 
+def _sources_sha():
+    """Same hash as bench.py: kernel_sources_sha() -- bench.py refuses a traffic file measured on other kernel sources."""
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.kernel_sources_sha()
+
 def pmc(fdb, wdb, out):
     def q(path, counter):
         cur = sqlite3.connect(path).cursor()
@@ -23,7 +30,7 @@ def pmc(fdb, wdb, out):
     res = {"_method": "rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2), each with --kernel-trace only, on "
                       "`python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline`; means per launch; counters are KiB; "
                       "gfx950: FETCH_SIZE reports half of a wide (16 B/lane) coalesced stream (MI355X_MICROARCH.md, HBM) => fetch bytes = "
-                      "2*FETCH_SIZE*1024; WRITE_SIZE as is", "kernels": {}}
+                      "2*FETCH_SIZE*1024; WRITE_SIZE as is", "kernel_sources_sha256": _sources_sha(), "kernels": {}}
     for n in sorted(set(f) | set(w)):
         if any(k in n for k in ("gemm", "attn", "norm", "colsum", "adam")):
             fv, fc, fd = f.get(n, (0, 0, 0)); wv, wc, wd = w.get(n, (0, 0, 0))
