@@ -385,17 +385,12 @@ struct Nt256Epi {
             for (int rg = 0; rg < 4; ++rg)
                 bias4[j][rg] = LDS_BIAS ? *(const f32x4*)(bias_lds + n0 + wn * 64 + j * 32 + 8 * rg + 4 * fh)
                                         : (p.bias ? *(const f32x4*)(p.bias + n0 + wn * 64 + j * 32 + 8 * rg + 4 * fh) : f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int mrow0 = m0 + wm * 128 + i * 32;      // wave-uniform
-            const int m = mrow0 + fr;
-            if (LDS_AUX && i + 2 < 4) load_aux(i + 2, auxrm[(i + 2) % 3], m0, n0, lo);
-            if (HAS_BITS && i + 1 < 4) load_bits(i + 1, mbits[(i + 1) & 1], m0, n0, lo);
-            if (LDS_AUX) {
-#pragma unroll
-                for (int it = 0; it < 4; ++it) *(u32x4*)(Es + it_off(it) + e_rd) = auxrm[i % 3][it];
-                __builtin_amdgcn_wave_barrier();
-            }
+        // one slab in three steps: convert(i) -> 8 packed 8-byte pieces (+ sign bits); write them into the staging buffer; read the slab back
+        // row-major and store it.  Without an LDS-staged operand (no residual / mask tensor) the steps of consecutive slabs are software-
+        // pipelined: slab i+1 is converted while slab i's read-back is in flight (LDS operations of one wave execute in order, so the one
+        // 4-KiB buffer is enough) -- the LDS round trip was ~300 exposed cycles per slab.
+        auto convert = [&](const int i, u32x2 (&pk)[8], unsigned (&obw)[2], const bool direct) {
+            const int m = m0 + wm * 128 + i * 32 + fr;
             // dropout: element index e = m * row_mult * N + n, pair index e >> 1 = P + c with P the pair of (this row, the wave's first
             // column + 4 fh) and c = j*16 + rg*4 (+1): x = lo(pair) * C1 ^ hi(pair) * C2 ^ key = (P_lo * C1 + c * C1) ^ (P_hi * C2 [+ C2 on carry]) ^ key
             uint32_t dP_lo = 0, dA1 = 0, dB1 = 0;
@@ -405,7 +400,7 @@ struct Nt256Epi {
                 dA1 = dP_lo * 0x9E3779B1u;
                 dB1 = (uint32_t)(P >> 32) * 0x85EBCA77u;
             }
-            unsigned obw[2] = {0u, 0u};       // sign bits of this lane's 2 x 16 outputs, at their column positions (before the final << 4 fh)
+            obw[0] = obw[1] = 0u;       // sign bits of this lane's 2 x 16 outputs, at their column positions (before the final << 4 fh)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -424,8 +419,7 @@ struct Nt256Epi {
                         for (int h = 0; h < 2; ++h) {
                             const uint32_t c = (uint32_t)(j * 16 + rg * 4 + h);
                             const uint32_t hb = (dP_lo + c < c) ? dB1 + 0x85EBCA77u : dB1;
-                            unsigned x = (dA1 + c * 0x9E3779B1u) ^ hb ^ p.drop.key;
-                            x = drop_mix(x);
+                            const unsigned x = drop_mix((dA1 + c * 0x9E3779B1u) ^ hb ^ p.drop.key);
                             keep |= ((x & 0xffffu) >= p.drop.thr ? 1u : 0u) << (2 * h);
                             keep |= ((x >> 16) >= p.drop.thr ? 2u : 0u) << (2 * h);
                         }
@@ -450,24 +444,33 @@ struct Nt256Epi {
                         const u32x2 rs = *(const u32x2*)(Es + (e_wr ^ (gi << 4)));
                         v[0] += bf_lo(rs[0]); v[1] += bf_hi(rs[0]); v[2] += bf_lo(rs[1]); v[3] += bf_hi(rs[1]);
                     }
-                    u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-                    if (PACKED_RELU) { pk[0] = pk_max_i16(pk[0], 0u); pk[1] = pk_max_i16(pk[1], 0u); }      // negative halves (and -0) -> +0
-                    *(u32x2*)(Es + (e_wr ^ (gi << 4))) = pk;
+                    pk[gi] = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                    if (PACKED_RELU) { pk[gi][0] = pk_max_i16(pk[gi][0], 0u); pk[gi][1] = pk_max_i16(pk[gi][1], 0u); }      // negative halves (and -0) -> +0
+                    if (direct) *(u32x2*)(Es + (e_wr ^ (gi << 4))) = pk[gi];      // unpipelined flavours: straight into the staging buffer (no 16 live registers)
                     if (PACKED_RELU && p.bits_out) {   // outputs are >= +0: min(half, 1) per 16-bit half, bit 16 folded down to bit 1
-                        const unsigned t0 = pk_min_i16(pk[0], 0x00010001u), t1 = pk_min_i16(pk[1], 0x00010001u);
+                        const unsigned t0 = pk_min_i16(pk[gi][0], 0x00010001u), t1 = pk_min_i16(pk[gi][1], 0x00010001u);
                         obw[j] |= (((t0 | (t0 >> 15)) & 3u) | (((t1 | (t1 >> 15)) & 3u) << 2)) << (8 * rg);
                     }
                 }
             }
-            __builtin_amdgcn_wave_barrier();
+        };
+        auto write_slab = [&](u32x2 (&pk)[8]) {
+#pragma unroll
+            for (int gi = 0; gi < 8; ++gi) *(u32x2*)(Es + (e_wr ^ (gi << 4))) = pk[gi];
+        };
+        auto read_slab = [&](u32x4 (&w)[4]) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) w[it] = *(const u32x4*)(Es + it_off(it) + e_rd);
+        };
+        auto store_slab = [&](const int i, u32x4 (&w)[4], unsigned (&obw)[2]) {
+            const int mrow0 = m0 + wm * 128 + i * 32;      // wave-uniform
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const u32x4 w = *(const u32x4*)(Es + it_off(it) + e_rd);
-                const int r0 = mrow0 + it * 8;      // wave-uniform
+                const int r0 = mrow0 + it * 8;
                 char* cb = C + ((size_t)r0 * p.ldc + n0 + wn * 64) * 2;
-                if (p.dbg & 1) { asm volatile("" ::"v"(w)); }
-                else if (r0 + 8 <= p.M) *(u32x4*)(cb + c_loff) = w;
-                else if (r0 + (lo >> 3) < p.M) *(u32x4*)(cb + c_loff) = w;
+                if (p.dbg & 1) { asm volatile("" ::"v"(w[it])); }
+                else if (r0 + 8 <= p.M) *(u32x4*)(cb + c_loff) = w[it];
+                else if (r0 + (lo >> 3) < p.M) *(u32x4*)(cb + c_loff) = w[it];
             }
             if (PACKED_RELU && p.bits_out) {
                 // lanes fr and fr+32 hold the two interleaved nibble sets of row fr: merge, then ONE 8-byte store per row (store
@@ -476,9 +479,49 @@ struct Nt256Epi {
                 const auto s0 = __builtin_amdgcn_permlane32_swap(o0, o0, false, false);
                 const auto s1 = __builtin_amdgcn_permlane32_swap(o1, o1, false, false);
                 const u32x2 ob = {o0 | s0[1], o1 | s1[1]};
+                const int m = mrow0 + fr;
                 if (fh == 0 && m < p.M) *(u32x2*)(p.bits_out + relu_bits_word(m, n0 + wn * 64, p.N)) = ob;
             }
-            __builtin_amdgcn_wave_barrier();
+        };
+        if (!LDS_AUX && ACT != ACT_GELU) {
+            u32x2 pkA[8], pkB[8];
+            unsigned obA[2], obB[2];
+            u32x4 w[4];
+            if (HAS_BITS) load_bits(1, mbits[1], m0, n0, lo);
+            convert(0, pkA, obA, false);
+            write_slab(pkA);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                asm volatile("" ::: "memory");
+                read_slab(w);
+                asm volatile("" ::: "memory");
+                if (i + 1 < 4) {      // under the read-back's latency
+                    if (HAS_BITS && i + 2 < 4) load_bits(i + 2, mbits[i & 1], m0, n0, lo);
+                    if (i & 1) convert(i + 1, pkA, obA, false); else convert(i + 1, pkB, obB, false);
+                }
+                if (i & 1) store_slab(i, w, obB); else store_slab(i, w, obA);
+                asm volatile("" ::: "memory");
+                if (i + 1 < 4) { if (i & 1) write_slab(pkA); else write_slab(pkB); }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (LDS_AUX) {
+                    if (i + 2 < 4) load_aux(i + 2, auxrm[(i + 2) % 3], m0, n0, lo);
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) *(u32x4*)(Es + it_off(it) + e_rd) = auxrm[i % 3][it];
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (HAS_BITS && i + 1 < 4) load_bits(i + 1, mbits[(i + 1) & 1], m0, n0, lo);
+                u32x2 pk[8];
+                unsigned obw[2];
+                u32x4 w[4];
+                convert(i, pk, obw, true);
+                __builtin_amdgcn_wave_barrier();
+                read_slab(w);
+                store_slab(i, w, obw);
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         return (m0 + 256 <= p.M) && !(p.dbg & 3);
     }
@@ -648,23 +691,29 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt8p_bf16_kernel(GemmNt
     if (lw >= n_local) return;
     const int my_tiles = (n_local - lw + lstride - 1) / lstride;
     const int nk = p.K / BK64;
-    auto tile_origin = [&](int ti, int& m0, int& n0) {
-        const int li = lw + ti * lstride;
-        m0 = ((li / ntn) * 8 + xcd) * 256;
-        n0 = (li % ntn) * 256;
+    // tile list of this workgroup: li = lw, lw + lstride, ...; li = mq * ntn + nr -> m-block (mq*8 + xcd), n-tile nr.  Walked without integer
+    // division (a division per tile on each of the two cursors cost ~1.3 k cycles per tile: cycle counters, profiles/r03_nt_ktile_position_cycles.txt)
+    const int step_q = lstride / ntn, step_r = lstride % ntn;
+    struct Cursor { int mq, nr; };
+    auto advance = [&](Cursor& c) {
+        c.mq += step_q;
+        c.nr += step_r;
+        if (c.nr >= ntn) { c.nr -= ntn; ++c.mq; }
     };
+    Cursor c_cur{lw / ntn, lw % ntn}, d_cur = c_cur;
 
     // ---- DMA side.  One wave instruction = 8 half-tile rows x 128 B; wave w fills half-tile rows w*16 + j*8 + (lane>>3), j = 0,1.
     uint32_t offB[2][2], offA[2][2];          // [half][j]: byte offset of this lane's 16-byte chunk from the tile's operand base
     const char* a_base = nullptr;
     const char* b_base = nullptr;
-    auto set_dma_tile = [&](int ti) {
-        int m0d, n0d;
-        tile_origin(ti, m0d, n0d);
-        m0d = __builtin_amdgcn_readfirstlane(m0d);
-        n0d = __builtin_amdgcn_readfirstlane(n0d);
+    bool d_offsets_full = false;      // offA / offB hold the (tile-independent) offsets of a full tile
+    auto set_dma_tile = [&]() {
+        const int m0d = __builtin_amdgcn_readfirstlane((d_cur.mq * 8 + xcd) * 256), n0d = __builtin_amdgcn_readfirstlane(d_cur.nr * 256);
         a_base = (const char*)p.A + (size_t)m0d * p.lda * 2;
         b_base = (const char*)p.B + (size_t)n0d * p.ldb * 2;
+        const bool full = m0d + 256 <= p.M && n0d + 256 <= p.N;
+        if (full && d_offsets_full) return;      // only the M tail / the half last n-tile clamp rows: everything else keeps its lane offsets
+        d_offsets_full = full;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int rho = wid * 16 + (lane >> 3) + 8 * j;
@@ -681,7 +730,7 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt8p_bf16_kernel(GemmNt
     int d_tile = 0, d_kt = 0, d_par = 0;
     bool d_live = true;
     const int wrow_off = __builtin_amdgcn_readfirstlane(wid * 2048);
-    set_dma_tile(0);
+    set_dma_tile();
     // ty: 0 = B0, 1 = B1, 2 = A0, 3 = A1 (compile-time at every call site); ring slot = 4 * (K-tile parity) + ty
     auto issue = [&](const int ty) {
         if (d_live && !(p.dbg & 32)) {      // timing-only: dbg & 32 = no DMA at all, dbg & 8 = always K-tile 0 of the first tile (L2-resident operands)
@@ -699,7 +748,7 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt8p_bf16_kernel(GemmNt
             d_par ^= 1;
             if (++d_kt == nk) {
                 d_kt = 0;
-                if (++d_tile < my_tiles) set_dma_tile(d_tile);
+                if (++d_tile < my_tiles) { advance(d_cur); set_dma_tile(); }
                 else d_live = false;
             }
         }
@@ -744,63 +793,81 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt8p_bf16_kernel(GemmNt
         acc[i_][1] = mfma32(fb1[kk], fa[kk], acc[i_][1]);                                                                \
     }                                                                                                                    \
     asm volatile("s_setprio 0\n\ts_barrier" : "+v"(acc[i_][0]), "+v"(acc[i_][1])::"memory");
+    // first K-tile of an output tile: the first MFMA of each accumulator takes a zero C operand (an inline constant) instead of 128
+    // v_mov per wave clearing the accumulators (~1 k cycles per tile with two waves per SIMD competing for the VALU)
+#define P8_COMPUTE_FIRST(i_)                                                                                             \
+    asm volatile("s_barrier\n\ts_setprio 1" ::: "memory");                                                               \
+    acc[i_][0] = mfma32(fb0[0], fa[0], zero16);                                                                          \
+    acc[i_][1] = mfma32(fb1[0], fa[0], zero16);                                                                          \
+    _Pragma("unroll") for (int kk = 1; kk < 4; ++kk) {                                                                   \
+        acc[i_][0] = mfma32(fb0[kk], fa[kk], acc[i_][0]);                                                                \
+        acc[i_][1] = mfma32(fb1[kk], fa[kk], acc[i_][1]);                                                                \
+    }                                                                                                                    \
+    asm volatile("s_setprio 0\n\ts_barrier" : "+v"(acc[i_][0]), "+v"(acc[i_][1])::"memory");
+    // one K-tile = four phases; CMP = P8_COMPUTE / P8_COMPUTE_FIRST
+#define P8_KTILE(CMP, KT)                                                                                                \
+    {                                                                                                                    \
+        const uint32_t kbase = (uint32_t)c_par * 65536u;                                                                 \
+        c_par ^= 1;                                                                                                      \
+        if (p.dbg & 4096) t_kt = __builtin_readcyclecounter();                                                           \
+        /* ---- phase 0: both B half-tiles + A row block 0 */                                                            \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) fb0[kk] = P8_LDS(kbase + rb[kk]);                               \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) fb1[kk] = P8_LDS(kbase + 16384 + rb[kk]);                       \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) fa[kk] = P8_LDS(kbase + ra[kk]);                                \
+        issue(2);                                                                                                        \
+        CMP(0)                                                                                                           \
+        /* ---- phase 1 */                                                                                               \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) fa[kk] = P8_LDS(kbase + 4096 + ra[kk]);                         \
+        issue(3);                                                                                                        \
+        if (!d_live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       /* tail of this workgroup's stream: nothing is issued any more */ \
+        else if (eb) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");      /* 8 + the epilogue's 16 stores (VM ops retire in order) */ \
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                            \
+        eb = false;                                                                                                      \
+        CMP(1)                                                                                                           \
+        /* ---- phase 2 */                                                                                               \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) fa[kk] = P8_LDS(kbase + 16384 + ra[kk]);                        \
+        issue(0);                                                                                                        \
+        CMP(2)                                                                                                           \
+        /* ---- phase 3 */                                                                                               \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) fa[kk] = P8_LDS(kbase + 16384 + 4096 + ra[kk]);                 \
+        issue(1);                                                                                                        \
+        if (!d_live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                    \
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                            \
+        if ((KT) == nk - 1) epi.prefetch0(m0, n0);      /* behind the counted wait: ordinary loads in front of it would only tighten it */ \
+        CMP(3)                                                                                                           \
+        if ((p.dbg & 4096) && ti > 0) {                                                                                  \
+            _Pragma("unroll") for (int q = 0; q < 8; ++q)                                                                \
+                if (q == ((KT) < 8 ? (KT) : 7)) cyc_kt[q] += __builtin_readcyclecounter() - t_kt;                        \
+        }                                                                                                                \
+    }
 
     long long cyc_main = 0, cyc_epi = 0, t_mark = (p.dbg & 16) ? __builtin_readcyclecounter() : 0;      // timing-only instrumentation (dbg & 16)
+    long long cyc_kt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_kt = 0;      // dbg & 4096: cycles by K-tile position inside a tile (first 8)
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
     for (int ti = 0; ti < my_tiles; ++ti) {
-        int m0, n0;
-        tile_origin(ti, m0, n0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int m0 = (c_cur.mq * 8 + xcd) * 256, n0 = c_cur.nr * 256;
+        advance(c_cur);
+        P8_KTILE(P8_COMPUTE_FIRST, 0)
 #pragma clang loop unroll(disable)
-        for (int kt = 0; kt < nk; ++kt) {
-            const uint32_t kbase = (uint32_t)c_par * 65536u;
-            c_par ^= 1;
-            // ---- phase 0: both B half-tiles + A row block 0
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) fb0[kk] = P8_LDS(kbase + rb[kk]);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) fb1[kk] = P8_LDS(kbase + 16384 + rb[kk]);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) fa[kk] = P8_LDS(kbase + ra[kk]);
-            issue(2);
-            P8_COMPUTE(0)
-            // ---- phase 1
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) fa[kk] = P8_LDS(kbase + 4096 + ra[kk]);
-            issue(3);
-            if (!d_live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tail of this workgroup's stream: nothing is issued any more
-            else if (eb) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");      // 8 + the epilogue's 16 stores (VM ops retire in order)
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            eb = false;
-            P8_COMPUTE(1)
-            // ---- phase 2
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) fa[kk] = P8_LDS(kbase + 16384 + ra[kk]);
-            issue(0);
-            P8_COMPUTE(2)
-            // ---- phase 3
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) fa[kk] = P8_LDS(kbase + 16384 + 4096 + ra[kk]);
-            issue(1);
-            if (!d_live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            if (kt == nk - 1) epi.prefetch0(m0, n0);      // behind the counted wait: ordinary loads in front of it would only tighten it
-            P8_COMPUTE(3)
-        }
+        for (int kt = 1; kt < nk; ++kt) P8_KTILE(P8_COMPUTE, kt)
         if (ti == my_tiles - 1 && wm == 0) __builtin_amdgcn_s_barrier();      // pairs with group 1's last barrier
         if (p.dbg & 16) { const long long t = __builtin_readcyclecounter(); cyc_main += t - t_mark; t_mark = t; }
         epi.Es = smem + ((c_par ^ 1) * 4 + 2) * 16384 + wrow_off;
         eb = epi.run(acc, m0, n0);
         if (p.dbg & 16) { const long long t = __builtin_readcyclecounter(); cyc_epi += t - t_mark; t_mark = t; }
     }
+    if ((p.dbg & 4096) && tid == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ((float*)p.C)[8192 + blockIdx.x * 8 + q] = (float)cyc_kt[q] / (float)(my_tiles > 1 ? my_tiles - 1 : 1);
+    }
     if ((p.dbg & 16) && tid == 0) {      // cycles per K-tile of the main loop, cycles per tile of the epilogue, into the first floats of C
         ((float*)p.C)[blockIdx.x * 2] = (float)cyc_main / (float)(my_tiles * nk);
         ((float*)p.C)[blockIdx.x * 2 + 1] = (float)cyc_epi / (float)my_tiles;
     }
+#undef P8_KTILE
+#undef P8_COMPUTE_FIRST
 #undef P8_LDS
 #undef P8_COMPUTE
 }

@@ -54,6 +54,11 @@ for (n, k, flav) in [(512, 512, "plain"), (512, 512, "res"), (512, 512, "res+dro
             sel(256 + 16 + extra); ops.gemm_nt(A, B, M, n, k, out=out, **kw); torch.cuda.synchronize()
             c = out.view(-1)[:1024].view(torch.float32)[:512].view(256, 2)
             print(f"   8-phase kernel ({tag}): {c[:, 0].mean().item():.0f} shader cycles per K-tile in the main loop (2048 = MFMA-bound), {c[:, 1].mean().item():.0f} per tile in the epilogue", flush=True)
+    if os.environ.get("AB_KT"):
+        for extra, tag in ((0, "full"), (2, "no epilogue"), (1, "no C stores")):
+            sel(256 + 4096 + extra); ops.gemm_nt(A, B, M, n, k, out=out, **kw); torch.cuda.synchronize()
+            c = out.view(-1)[16384:16384 + 4096].view(torch.float32)[:2048].view(256, 8).mean(0)
+            print(f"   cycles by K-tile position after a tile boundary ({tag}): " + " ".join(f"{v:.0f}" for v in c.tolist()), flush=True)
     sel(0)
     print(f"N={n} K={k} {flav}: " + "  ".join(f"v{a}: {min(t):.3f} ms ({2*M*n*k/min(t)/1e9:.0f} TF)" for a, t in res.items()), flush=True)
     del A, B, out, kw
