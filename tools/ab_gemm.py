@@ -30,6 +30,8 @@ sel(0)
 M = int(os.environ.get("AB_ROWS", 16384)) * 181
 for (n, k, flav) in [(512, 512, "plain"), (512, 512, "res"), (512, 512, "res+drop"), (1536, 512, "bias"), (2048, 512, "relu"), (2048, 512, "relu+drop"), (512, 2048, "res"), (512, 2048, "res+drop"), (512, 1536, "res"), (1024, 512, "bias"), (2048, 512, "bits_in")]:
     A = torch.randn(M, k, device="cuda").to(torch.bfloat16); B = (torch.randn(n, k, device="cuda") * 0.05).to(torch.bfloat16)
+    if os.environ.get("AB_CONST"):  # operands with few toggling bits: separates the schedule from the power-limited clock
+        A.fill_(1.0); B.fill_(0.5)
     out = torch.empty(M, n, device="cuda", dtype=torch.bfloat16)
     bias = torch.randn(n, device="cuda")
     kw = {}
