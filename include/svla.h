@@ -134,6 +134,9 @@ int svla_attn_bwd_bf16(const svla_bf16* Q, const svla_bf16* K, const svla_bf16* 
                        int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj, const float* bias,
                        const unsigned char* kvalid, int Sq, long ldq, long lddq, float* D_ws, const svla_dropout* drop,
                        void* stream);
+/* Test / A-B hook: 1 = the two-kernel backward (dQ kernel + dK/dV kernel, 12 head slices of HBM traffic per (row, head))
+ * instead of the single-pass kernel (8 slices) on the unmasked exact-tile shapes. */
+int svla_attn_bwd_two_pass(int on);
 
 /* ---- observation / embedding glue ---------------------------------------------------------------------------- */
 /* (R,C,7,12) fp32 channels-first DINO features -> bf16 tokens [R, ncam, P, C] (input layout of the 1x1-conv compressor,

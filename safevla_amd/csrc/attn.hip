@@ -12,6 +12,9 @@
 // V (and K/Q/dO in the backward) are read as B operands straight from row-major LDS with ds_read_b64_tr_b16.
 #include "common.h"
 
+#ifndef ATT_SWZ_OLD
+#define ATT_SWZ_OLD 0
+#endif
 #define HD 64
 #define LDSROW 64   // LDS row = 128 B (one head slice row), 16-byte chunks XOR-swizzled: 48 KiB for two [192, 64] operands,
                     // so THREE workgroups fit a CU's 160 KiB (the kernels are latency-bound: 1 -> 2 workgroups/CU = 1.74x)
@@ -47,9 +50,21 @@ __device__ __forceinline__ bool att_keep1(const DropCfg& c, unsigned long long e
     return ((e & 1) ? (x >> 16) : (x & 0xffffu)) >= c.thr;
 }
 
-// physical 16-byte chunk of logical chunk c in row r: c ^ ((r >> 1) & 7).  16 consecutive rows x one logical chunk hit 16
-// distinct 16-byte bank slots (conflict-free ds_read_b128); a transposed 64-lane read (16 rows x 32 B) takes its 2 cycles.
-__device__ __forceinline__ int att_swz(int row) { return (row >> 1) & 7; }
+// physical 16-byte chunk of logical chunk c in row r: c ^ f(x), x = (r >> 1) & 7 (64 banks x 4 B; a row is 32 banks, so the row
+// parity picks the bank half and f only has to spread the eight values of x over the eight 16-byte slots of a half).  Three
+// access patterns constrain f:
+//  * ds_read_b128 row fragments (row = lane & 15, logical chunk = lane >> 4): the hardware serves lanes {0-3,12-15,20-27},
+//    {4-11,16-19,28-31}, ... as groups, i.e. rows with x in {0,1,6,7} on chunk c together with rows with x in {2,3,4,5} on
+//    chunk c ^ 1: conflict-free iff f is a permutation and f({2,3,4,5}) is a union of two chunk pairs {2k, 2k+1};
+//  * ds_read_b64_tr_b16 (32 lanes per pass = 8 rows x 32 B = one chunk PAIR per row): f >> 1 must be distinct over
+//    x = 0..3 and over x = 4..7.  (f = x, the first layout, put rows 2,3 on the chunk pair of rows 0,1: every transposed
+//    read was a 2-way conflict.)
+//  * staging stores (8 lanes = one row): any f.
+// f = 0,2,4,6,5,7,1,3 satisfies all three.
+__device__ __forceinline__ int att_swz(int row) {
+    const int x = (row >> 1) & 7;
+    return ATT_SWZ_OLD ? x : ((((x + ((x >> 2) << 1)) & 3) << 1) | (x >> 2));
+}
 
 // Lane bases of the two access patterns (tile rows are multiples of 16, so the swizzle term depends on the lane only and the
 // tile offset stays a compile-time immediate of the ds_read):
@@ -829,6 +844,264 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_dkv_e
     }
 }
 
+// ------------------------------------------------------------------------------------------------ single-pass backward
+// The two exact-tile kernels above in one workgroup, so that Q, K, V, dO and O leave HBM once (8 instead of 12 [S,64] head slices
+// of traffic per (row, head)).  LDS still holds only two operands at a time:
+//   stage Q, dO (+ D = rowsum(dO * O) from the staging registers)  ->  dK, dV with this wave's K/V tiles streamed as fragments
+//   ->  this wave's Q / dO query-tile fragments move LDS -> registers  ->  K, V re-staged over Q, dO (L2 hits: this workgroup
+//   read them microseconds ago)  ->  dQ.
+// VALU is the busiest unit of these kernels (PMC: 38 % VALU, 17 % MFMA, 23 % LDS, not overlapping), so the softmax algebra is
+// two packed FMAs per element pair (-lse*log2e and -D*scale are what LDS holds) and the dropout hash is evaluated incrementally:
+// the element-pair index P = P0 + q*(S4/2) + (key >> 1) is linear in (q, key), so lo(P)*C1 = lane constant + wave-uniform term.
+__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+
+struct AttDrop {               // per (row, head): hash of pair index P0 + delta, delta < 2^16
+    unsigned a0;               // lo(P0) * C1
+    unsigned hb;               // (hi(P0) * C2) ^ key
+    bool wrap;                 // lo(P0) + delta may carry into hi(P): take the generic path (never for < 2^33 probabilities per tensor)
+    unsigned long long p0;
+};
+__device__ __forceinline__ AttDrop att_drop_head(const AttnArgs& p, int r, int h) {
+    AttDrop d;
+    d.p0 = att_drop_row(p, r, h, 0) >> 1;
+    d.a0 = (unsigned)d.p0 * 0x9E3779B1u;
+    d.hb = ((unsigned)(d.p0 >> 32) * 0x85EBCA77u) ^ p.drop.key;
+    d.wrap = (unsigned)d.p0 > 0xFFFF0000u;
+    return d;
+}
+
+template <int NKT, bool DROP>
+__global__ void __launch_bounds__(ATT_THREADS, 2) attn_bwd_fused_exact_kernel(AttnArgs p) {
+    if (DROP) p.drop = drop_resolve(p.drop);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SP = NKT * 16, MAXT = (NKT + 3) / 4, IT = SP * 8 / ATT_THREADS;
+    bf16_t* As = (bf16_t*)smem;          // Q, then K
+    bf16_t* Bs = As + SP * LDSROW;       // dO, then V
+    float* nl_s = (float*)(Bs + SP * LDSROW);   // -lse * log2(e)   (-inf for padded queries: P = 0)
+    float* nd_s = nl_s + SP;                    // -D * scale
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const size_t tok0 = (size_t)r * p.S, qtok0 = (size_t)r * p.Sq;
+    const int S = p.S, Sq = p.Sq;
+    const int ql = lane & 15, g = lane >> 4;
+    bf16x8 kvbuf[2][4];
+    auto load_kv = [&](int t, bf16x8 (&dst)[4]) {
+        const int keyl = (wid + 4 * t) * 16 + ql;
+        const bool kok = keyl < S;
+        const bf16_t* kp = p.K + (tok0 + (kok ? keyl : 0)) * p.ld + h * HD + 8 * g;
+        const bf16_t* vp = p.V + (tok0 + (kok ? keyl : 0)) * p.ld + h * HD + 8 * g;
+        dst[0] = gld8(kp, kok); dst[1] = gld8(kp + 32, kok);
+        dst[2] = gld8(vp, kok); dst[3] = gld8(vp + 32, kok);
+    };
+    load_kv(0, kvbuf[0]);
+    stage_head<SP>(As, p.Q + qtok0 * p.ldq + h * HD, p.ldq, Sq, tid);
+    {   // dO -> LDS, and D[row] = sum over the row's eight 16-byte chunks of dO . O (eight consecutive lanes hold one row)
+        u32x4 w[IT];
+        float part[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int q = tid + i * ATT_THREADS, row = q >> 3, c = q & 7;
+            const bool ok = row < Sq;
+            const bf16x8 gv = gld8(p.dO + (qtok0 + (ok ? row : 0)) * p.lddo + h * HD + c * 8, ok);
+            const bf16x8 ov = gld8(p.O + (qtok0 + (ok ? row : 0)) * p.ldo + h * HD + c * 8, ok);
+            w[i] = __builtin_bit_cast(u32x4, gv);
+            part[i] = dot8(gv, ov);
+        }
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int q = tid + i * ATT_THREADS, row = q >> 3;
+            *(u32x4*)(Bs + row * LDSROW + (((q & 7) ^ att_swz(row)) << 3)) = w[i];
+            float d = part[i];
+            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+            if ((q & 7) == 0) nd_s[row] = -d * p.scale;
+        }
+    }
+    for (int i = tid; i < SP; i += ATT_THREADS)
+        nl_s[i] = i < Sq ? -p.LSE[((size_t)r * p.H + h) * Sq + i] * LOG2E : -INFINITY;
+    __syncthreads();
+    const float sl2 = p.scale * LOG2E;
+    const float dsc = DROP ? p.drop.scale : 1.f, scd = p.scale * dsc;
+    const f32x4 sl4 = {sl2, sl2, sl2, sl2}, scd4 = {scd, scd, scd, scd}, dsc4 = {dsc, dsc, dsc, dsc};
+    const RowBase Arow = att_row_base(As, lane), Brow = att_row_base(Bs, lane);
+    const TrBase Atr = att_tr_base(As, lane), Btr = att_tr_base(Bs, lane);
+    const int S4 = (S + 3) & ~3, hS = S4 >> 1;
+    AttDrop dh{};
+    if (DROP) dh = att_drop_head(p, r, h);
+    const unsigned thr = p.drop.thr;
+    // ---- dK, dV: waves own key tiles; As = Q, Bs = dO
+    {
+        const int nw = (Sq + 31) / 32;                        // query-tile pairs holding any real query
+        // dropout, this layout: a lane holds 4 consecutive QUERIES (4g + e) of one key (kt*16 + ql); the lanes ql, ql ^ 1 share their
+        // RNG words (keys 2k, 2k+1 of one query), so the even lane hashes queries e = 0,1, the odd lane e = 2,3 and they swap halves
+        const int odd = ql & 1;
+        const unsigned dl_a = (unsigned)((4 * g + 2 * odd) * hS + (ql >> 1));   // lane part of delta for this lane's own two words
+        const unsigned al_a = dh.a0 + dl_a * 0x9E3779B1u;
+        const unsigned hSC = (unsigned)hS * 0x9E3779B1u;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            const int kt = wid + 4 * t;
+            if (kt < NKT) {
+                const int keyl = kt * 16 + ql;
+                const bool kok = keyl < S;
+                if (t + 1 < MAXT && kt + 4 < NKT) load_kv(t + 1, kvbuf[(t + 1) & 1]);
+                const bf16x8 kf0 = kvbuf[t & 1][0], kf1 = kvbuf[t & 1][1], vf0 = kvbuf[t & 1][2], vf1 = kvbuf[t & 1][3];
+                f32x4 dk[4], dv[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 2
+                for (int w = 0; w < nw; ++w) {
+                    const int off = w * 32 * LDSROW;
+                    float pv[8], dsv[8];
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        const int o2 = off + e2 * 16 * LDSROW;
+                        f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                        sv = mfma16(*(const bf16x8*)(Arow.lo + o2), kf0, sv);
+                        sv = mfma16(*(const bf16x8*)(Arow.hi + o2), kf1, sv);
+                        dp = mfma16(*(const bf16x8*)(Brow.lo + o2), vf0, dp);
+                        dp = mfma16(*(const bf16x8*)(Brow.hi + o2), vf1, dp);
+                        // sv[e]: query (2w+e2)*16 + 4g + e, key keyl
+                        const f32x4 nl4 = *(const f32x4*)(nl_s + w * 32 + e2 * 16 + 4 * g), nd4 = *(const f32x4*)(nd_s + w * 32 + e2 * 16 + 4 * g);
+                        const f32x4 x = fma4(sv, sl4, nl4);
+                        f32x4 pr;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pr[e] = __builtin_amdgcn_exp2f(x[e]);
+                        f32x4 pd = pr, tt = fma4(dp, scd4, nd4);      // tt = scale * (dP - D), dP = keep/(1-p) * (dO V^T)
+                        if (DROP) {
+                            pd = pr * dsc4;
+                            unsigned keep;       // bit e: probability (query 4g + e, key keyl) kept
+                            if (!dh.wrap) {
+                                const int qb = w * 32 + e2 * 16;
+                                const unsigned ua = (unsigned)(qb * hS + kt * 8) * 0x9E3779B1u;         // wave-uniform
+                                const unsigned x0 = drop_mix((al_a + ua) ^ dh.hb), x1 = drop_mix((al_a + ua + hSC) ^ dh.hb);
+                                // own half of my two words, and the partner's half of them
+                                const unsigned mine = odd ? ((x0 >> 16) | (x1 & 0xffff0000u)) : ((x0 & 0xffffu) | (x1 << 16));
+                                const unsigned give = odd ? ((x0 & 0xffffu) | (x1 << 16)) : ((x0 >> 16) | (x1 & 0xffff0000u));
+                                const unsigned got = (unsigned)__builtin_amdgcn_mov_dpp((int)give, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+                                const unsigned q01 = odd ? got : mine, q23 = odd ? mine : got;      // 16-bit randoms of queries e = 0,1 | 2,3
+                                keep = ((q01 & 0xffffu) >= thr ? 1u : 0u) | ((q01 >> 16) >= thr ? 2u : 0u) | ((q23 & 0xffffu) >= thr ? 4u : 0u) | ((q23 >> 16) >= thr ? 8u : 0u);
+                            } else {
+                                keep = 0;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const int q = w * 32 + e2 * 16 + 4 * g + e;
+                                    keep |= att_keep1(p.drop, (dh.p0 << 1) + (unsigned)(q * S4 + keyl)) ? (1u << e) : 0u;
+                                }
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const bool kp = (keep >> e) & 1u;
+                                pd[e] = kp ? pd[e] : 0.f;             // dropped-out probabilities feed dV
+                                tt[e] = kp ? tt[e] : nd4[e];
+                            }
+                        }
+                        const f32x4 ds = pr * tt;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { pv[e2 * 4 + e] = pd[e]; dsv[e2 * 4 + e] = ds[e]; }
+                    }
+                    const bf16x8 pa = pack8(pv), da = pack8(dsv);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        dv[dt] = mfma16(lds_tr8i(Btr.d[dt] + off, 0, 16), pa, dv[dt]);   // dV^T / dK^T: rows = head dims, cols = keys
+                        dk[dt] = mfma16(lds_tr8i(Atr.d[dt] + off, 0, 16), da, dk[dt]);
+                    }
+                }
+                if (kok) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const u32x2 wk = {pack_bf2(dk[dt][0], dk[dt][1]), pack_bf2(dk[dt][2], dk[dt][3])};
+                        const u32x2 wv = {pack_bf2(dv[dt][0], dv[dt][1]), pack_bf2(dv[dt][2], dv[dt][3])};
+                        *(u32x2*)(p.dK + (tok0 + keyl) * p.ldd + h * HD + dt * 16 + 4 * g) = wk;
+                        *(u32x2*)(p.dV + (tok0 + keyl) * p.ldd + h * HD + dt * 16 + 4 * g) = wv;
+                    }
+                }
+            }
+        }
+    }
+    // ---- this wave's query tiles: Q / dO row fragments, -lse and -D*scale move to registers before K, V replace Q, dO in LDS
+    bf16x8 qall[MAXT][4];
+    float dall[MAXT], lall[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int qt = wid + 4 * t;
+        if (qt < NKT) {
+            const int o = qt * 16 * LDSROW;
+            qall[t][0] = *(const bf16x8*)(Arow.lo + o); qall[t][1] = *(const bf16x8*)(Arow.hi + o);
+            qall[t][2] = *(const bf16x8*)(Brow.lo + o); qall[t][3] = *(const bf16x8*)(Brow.hi + o);
+            lall[t] = nl_s[qt * 16 + ql]; dall[t] = nd_s[qt * 16 + ql];
+        }
+    }
+    __syncthreads();
+    stage_head<SP>(As, p.K + tok0 * p.ld + h * HD, p.ld, S, tid);
+    stage_head<SP>(Bs, p.V + tok0 * p.ld + h * HD, p.ld, S, tid);
+    __syncthreads();
+    // ---- dQ: waves own query tiles; As = K, Bs = V
+    {
+        const int ntile = (Sq + 15) / 16;
+        // dropout, this layout: a lane holds 4 consecutive KEYS (tile*16 + 4g + e) of one query: two RNG words
+        const unsigned dl_b = (unsigned)(ql * hS + 2 * g);
+        const unsigned al_b = dh.a0 + dl_b * 0x9E3779B1u;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            const int qt = wid + 4 * t;
+            if (qt < ntile) {                                   // wave-uniform
+                const int q = qt * 16 + ql;
+                const bool qok = q < Sq;
+                const f32x4 nl4 = {lall[t], lall[t], lall[t], lall[t]}, nd4 = {dall[t], dall[t], dall[t], dall[t]};
+                f32x4 dq[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // padded keys need no mask: their K rows are zero, so their dS never reaches dQ
+#pragma unroll 2
+                for (int u = 0; u < NKT / 2; ++u) {
+                    const int off = u * 32 * LDSROW;
+                    float dsv[8];
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        const int o2 = off + e2 * 16 * LDSROW;
+                        f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                        sv = mfma16(*(const bf16x8*)(Arow.lo + o2), qall[t][0], sv);
+                        sv = mfma16(*(const bf16x8*)(Arow.hi + o2), qall[t][1], sv);
+                        dp = mfma16(*(const bf16x8*)(Brow.lo + o2), qall[t][2], dp);
+                        dp = mfma16(*(const bf16x8*)(Brow.hi + o2), qall[t][3], dp);
+                        const f32x4 x = fma4(sv, sl4, nl4);
+                        f32x4 pr;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pr[e] = __builtin_amdgcn_exp2f(x[e]);
+                        f32x4 tt = fma4(dp, scd4, nd4);
+                        if (DROP) {            // dP = keep/(1-p) * (dO V^T), the forward's keep-mask regenerated
+                            unsigned keep;
+                            if (!dh.wrap) {
+                                const unsigned ub = (unsigned)(qt * 16 * hS + (2 * u + e2) * 8) * 0x9E3779B1u;   // wave-uniform
+                                const unsigned r0 = drop_mix((al_b + ub) ^ dh.hb), r1 = drop_mix((al_b + ub + 0x9E3779B1u) ^ dh.hb);
+                                keep = ((r0 & 0xffffu) >= thr ? 1u : 0u) | ((r0 >> 16) >= thr ? 2u : 0u) | ((r1 & 0xffffu) >= thr ? 4u : 0u) | ((r1 >> 16) >= thr ? 8u : 0u);
+                            } else {
+                                keep = drop_keep4(p.drop, (dh.p0 << 1) + (unsigned long long)(qok ? q : 0) * S4 + (2 * u + e2) * 16 + 4 * g);
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) tt[e] = ((keep >> e) & 1u) ? tt[e] : nd4[e];
+                        }
+                        const f32x4 ds = pr * tt;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dsv[e2 * 4 + e] = ds[e];
+                    }
+                    const bf16x8 da = pack8(dsv);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        dq[dt] = mfma16(lds_tr8i(Atr.d[dt] + off, 0, 16), da, dq[dt]);   // dQ^T: rows = head dims, cols = queries
+                }
+                if (qok) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const u32x2 w = {pack_bf2(dq[dt][0], dq[dt][1]), pack_bf2(dq[dt][2], dq[dt][3])};
+                        *(u32x2*)(p.dQ + (qtok0 + q) * p.lddq + h * HD + dt * 16 + 4 * g) = w;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int NKT>
 static int launch_fwd(const AttnArgs& p, int rows, hipStream_t st) {
     const size_t lds = (size_t)2 * NKT * 16 * LDSROW * sizeof(bf16_t) + NKT * 16 * (sizeof(int) + 1);
@@ -860,6 +1133,9 @@ static int launch_fwd(const AttnArgs& p, int rows, hipStream_t st) {
     else hipLaunchKernelGGL((attn_fwd_kernel<NKT, false>), dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
     return svla_launch_status();
 }
+static int g_attn_bwd_two_pass = 0;   // svla_attn_bwd_two_pass(1): the dQ + dK/dV kernel pair instead of the single-pass kernel (A/B, tests)
+extern "C" int svla_attn_bwd_two_pass(int on) { g_attn_bwd_two_pass = on; return 0; }
+
 template <int NKT>
 static int launch_bwd(const AttnArgs& p, int rows, hipStream_t st) {
     const size_t lds_q = (size_t)2 * NKT * 16 * LDSROW * sizeof(bf16_t) + NKT * 16 * (sizeof(int) + 1);
@@ -875,17 +1151,24 @@ static int launch_bwd(const AttnArgs& p, int rows, hipStream_t st) {
     const bool generic = p.mask_mode != MASK_NONE || p.bias || p.kvalid;
     // exact-tile backward: correct for any S <= NKT*16 (padded keys have zero K / V rows, padded queries lse = +inf); used where at most
     // three of the NKT key tiles are padding
-    if constexpr (NKT <= 16) if (!generic && p.Dws && p.S > (NKT - 3) * 16) {
+    if constexpr (NKT <= 16) if (!generic && (p.Dws || !g_attn_bwd_two_pass) && p.S > (NKT - 3) * 16) {
         const size_t le_q = (size_t)2 * NKT * 16 * LDSROW * sizeof(bf16_t);
         const size_t le_kv = le_q + NKT * 16 * 2 * sizeof(float);
         static bool attr_e = false;
         if (!attr_e) {
             HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_dq_exact_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)le_q));
             HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_dkv_exact_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)le_kv));
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_fused_exact_kernel<NKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)le_kv));
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_fused_exact_kernel<NKT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)le_kv));
             attr_e = true;
         }
-        hipLaunchKernelGGL((attn_bwd_dq_exact_kernel<NKT>), dim3(rows * p.H), dim3(ATT_THREADS), le_q, st, p);
-        hipLaunchKernelGGL((attn_bwd_dkv_exact_kernel<NKT>), dim3(rows * p.H), dim3(ATT_THREADS), le_kv, st, p);
+        if (g_attn_bwd_two_pass) {
+            hipLaunchKernelGGL((attn_bwd_dq_exact_kernel<NKT>), dim3(rows * p.H), dim3(ATT_THREADS), le_q, st, p);
+            hipLaunchKernelGGL((attn_bwd_dkv_exact_kernel<NKT>), dim3(rows * p.H), dim3(ATT_THREADS), le_kv, st, p);
+        } else {
+            if (p.drop.thr) hipLaunchKernelGGL((attn_bwd_fused_exact_kernel<NKT, true>), dim3(rows * p.H), dim3(ATT_THREADS), le_kv, st, p);
+            else hipLaunchKernelGGL((attn_bwd_fused_exact_kernel<NKT, false>), dim3(rows * p.H), dim3(ATT_THREADS), le_kv, st, p);
+        }
         return svla_launch_status();
     }
     if (generic) {

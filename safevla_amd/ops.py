@@ -269,6 +269,11 @@ def gemm_force_small_tile(on):
     lib().call("svla_gemm_force_small_tile", int(on))
 
 
+def attn_bwd_two_pass(on) -> None:
+    """True: the dQ + dK/dV kernel pair instead of the single-pass attention backward (A/B and tests)."""
+    lib().call("svla_attn_bwd_two_pass", int(bool(on)))
+
+
 def gemm_tn_acc(dY, X, dW, M, N, K, ldy=None, ldx=None, ldw=None, db=None):
     """dW[N,K] (fp32) += dY[M,N]^T @ X[M,K];  optional fused bias gradient db[N] += dY.sum(0)."""
     if dY.dtype == F32:
