@@ -848,8 +848,7 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_dkv_e
 // The two exact-tile kernels above in one workgroup, so that Q, K, V, dO and O leave HBM once (8 instead of 12 [S,64] head slices
 // of traffic per (row, head)).  LDS still holds only two operands at a time:
 //   stage Q, dO (+ D = rowsum(dO * O) from the staging registers)  ->  dK, dV with this wave's K/V tiles streamed as fragments
-//   ->  this wave's Q / dO query-tile fragments move LDS -> registers  ->  K, V re-staged over Q, dO (L2 hits: this workgroup
-//   read them microseconds ago)  ->  dQ.
+//   ->  this wave's Q / dO query-tile fragments move LDS -> registers  ->  the K, V fragments are written over Q, dO  ->  dQ.
 // VALU is the busiest unit of these kernels (PMC: 38 % VALU, 17 % MFMA, 23 % LDS, not overlapping), so the softmax algebra is
 // two packed FMAs per element pair (-lse*log2e and -D*scale are what LDS holds) and the dropout hash is evaluated incrementally:
 // the element-pair index P = P0 + q*(S4/2) + (key >> 1) is linear in (q, key), so lo(P)*C1 = lane constant + wave-uniform term.
@@ -871,10 +870,12 @@ __device__ __forceinline__ AttDrop att_drop_head(const AttnArgs& p, int r, int h
 }
 
 template <int NKT, bool DROP>
-__global__ void __launch_bounds__(ATT_THREADS, 2) attn_bwd_fused_exact_kernel(AttnArgs p) {
+__global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_fused_exact_kernel(AttnArgs p) {
     if (DROP) p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16, MAXT = (NKT + 3) / 4, IT = SP * 8 / ATT_THREADS;
+    constexpr bool KEEP_KV = NKT <= 12;   // K/V fragments of all of this wave's key tiles stay in registers and are written to LDS for
+                                          // the dQ phase (no second read); NKT = 16 has no registers for that and re-reads K, V
     bf16_t* As = (bf16_t*)smem;          // Q, then K
     bf16_t* Bs = As + SP * LDSROW;       // dO, then V
     float* nl_s = (float*)(Bs + SP * LDSROW);   // -lse * log2(e)   (-inf for padded queries: P = 0)
@@ -884,7 +885,8 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_bwd_fused_exact_kernel(At
     const size_t tok0 = (size_t)r * p.S, qtok0 = (size_t)r * p.Sq;
     const int S = p.S, Sq = p.Sq;
     const int ql = lane & 15, g = lane >> 4;
-    bf16x8 kvbuf[2][4];
+    constexpr int NBUF = KEEP_KV ? MAXT : 2;
+    bf16x8 kvbuf[NBUF][4];
     auto load_kv = [&](int t, bf16x8 (&dst)[4]) {
         const int keyl = (wid + 4 * t) * 16 + ql;
         const bool kok = keyl < S;
@@ -894,6 +896,10 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_bwd_fused_exact_kernel(At
         dst[2] = gld8(vp, kok); dst[3] = gld8(vp + 32, kok);
     };
     load_kv(0, kvbuf[0]);
+    if (KEEP_KV) {
+#pragma unroll
+        for (int t = 1; t < MAXT; ++t) if (wid + 4 * t < NKT) load_kv(t, kvbuf[t]);
+    }
     stage_head<SP>(As, p.Q + qtok0 * p.ldq + h * HD, p.ldq, Sq, tid);
     {   // dO -> LDS, and D[row] = sum over the row's eight 16-byte chunks of dO . O (eight consecutive lanes hold one row)
         u32x4 w[IT];
@@ -940,11 +946,12 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_bwd_fused_exact_kernel(At
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
             const int kt = wid + 4 * t;
+            __builtin_amdgcn_sched_barrier(0);     // keep the unrolled key tiles apart (their loads would otherwise all be hoisted)
             if (kt < NKT) {
                 const int keyl = kt * 16 + ql;
                 const bool kok = keyl < S;
-                if (t + 1 < MAXT && kt + 4 < NKT) load_kv(t + 1, kvbuf[(t + 1) & 1]);
-                const bf16x8 kf0 = kvbuf[t & 1][0], kf1 = kvbuf[t & 1][1], vf0 = kvbuf[t & 1][2], vf1 = kvbuf[t & 1][3];
+                if (!KEEP_KV && t + 1 < MAXT && kt + 4 < NKT) load_kv(t + 1, kvbuf[(t + 1) % NBUF]);
+                const bf16x8 kf0 = kvbuf[t % NBUF][0], kf1 = kvbuf[t % NBUF][1], vf0 = kvbuf[t % NBUF][2], vf1 = kvbuf[t % NBUF][3];
                 f32x4 dk[4], dv[4];
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -1019,6 +1026,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_bwd_fused_exact_kernel(At
         }
     }
     // ---- this wave's query tiles: Q / dO row fragments, -lse and -D*scale move to registers before K, V replace Q, dO in LDS
+    __builtin_amdgcn_sched_barrier(0);
     bf16x8 qall[MAXT][4];
     float dall[MAXT], lall[MAXT];
 #pragma unroll
@@ -1032,8 +1040,23 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_bwd_fused_exact_kernel(At
         }
     }
     __syncthreads();
-    stage_head<SP>(As, p.K + tok0 * p.ld + h * HD, p.ld, S, tid);
-    stage_head<SP>(Bs, p.V + tok0 * p.ld + h * HD, p.ld, S, tid);
+    if (KEEP_KV) {
+        // row fragment (key row kt*16 + ql, logical chunks g and g + 4) back to its swizzled LDS place; padded keys hold zeros
+        const int f = att_swz(ql);
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            const int kt = wid + 4 * t;
+            if (kt < NKT) {
+                bf16_t* ka = As + (kt * 16 + ql) * LDSROW;
+                bf16_t* va = Bs + (kt * 16 + ql) * LDSROW;
+                *(bf16x8*)(ka + ((g ^ f) << 3)) = kvbuf[t % NBUF][0]; *(bf16x8*)(ka + (((g + 4) ^ f) << 3)) = kvbuf[t % NBUF][1];
+                *(bf16x8*)(va + ((g ^ f) << 3)) = kvbuf[t % NBUF][2]; *(bf16x8*)(va + (((g + 4) ^ f) << 3)) = kvbuf[t % NBUF][3];
+            }
+        }
+    } else {
+        stage_head<SP>(As, p.K + tok0 * p.ld + h * HD, p.ld, S, tid);
+        stage_head<SP>(Bs, p.V + tok0 * p.ld + h * HD, p.ld, S, tid);
+    }
     __syncthreads();
     // ---- dQ: waves own query tiles; As = K, Bs = V
     {
@@ -1044,6 +1067,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_bwd_fused_exact_kernel(At
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
             const int qt = wid + 4 * t;
+            __builtin_amdgcn_sched_barrier(0);
             if (qt < ntile) {                                   // wave-uniform
                 const int q = qt * 16 + ql;
                 const bool qok = q < Sq;

@@ -557,6 +557,36 @@ def test_attn_dropout_fwd_bwd_vs_hash_reference(ops, S, mask_mode):
         close(dqkv[:, i * H * 64:(i + 1) * H * 64].float().view(rows, S, H, 64), w, 2e-2, 2e-2 * w.abs().max().item() + 1e-3, f"{n} drop S={S}")
 
 
+@pytest.mark.parametrize("S,p", [(50, 0.0), (181, 0.0), (181, 0.1), (233, 0.1)])
+def test_attn_bwd_two_pass_pair_still_matches_reference(ops, S, p):
+    """The dQ + dK/dV kernel pair (kept behind svla_attn_bwd_two_pass for A/B) against torch, and against the default single-pass
+    kernel on the same inputs: identical dropout masks, gradients equal up to bf16 rounding of differently ordered fp32 sums."""
+    ops.attn_bwd_two_pass(True)
+    try:
+        if p > 0:
+            test_attn_dropout_fwd_bwd_vs_hash_reference(ops, S, 0)
+        else:
+            _attn_case(ops, 3, S, 8)
+    finally:
+        ops.attn_bwd_two_pass(False)
+    rows, H = 5, 8
+    qkv = bf(rnd(rows * S, 3 * H * 64, seed=31)).to(DEV).bfloat16()
+    kw = dict(drop=ops.Dropout(seed=5, stream=2, p=p)) if p > 0 else {}
+    out, lse = ops.attn_fwd(qkv, qkv[:, 512:], qkv[:, 1024:], 1536, rows, S, H, 0.125, **kw)
+    do = bf(rnd(rows * S, H * 64, seed=32)).to(DEV).bfloat16()
+    res = []
+    for two in (True, False):
+        ops.attn_bwd_two_pass(two)
+        try:
+            d = torch.zeros_like(qkv)
+            ops.attn_bwd(qkv, qkv[:, 512:], qkv[:, 1024:], 1536, out, 512, lse, do, 512, d, d[:, 512:], d[:, 1024:], 1536, rows, S, H, 0.125, **kw)
+            res.append(d.float())
+        finally:
+            ops.attn_bwd_two_pass(False)
+    assert (res[0] - res[1]).abs().max().item() <= 2 ** -7 * res[0].abs().max().item()
+    assert torch.nn.functional.cosine_similarity(res[0].flatten(), res[1].flatten(), dim=0).item() > 0.99999
+
+
 @pytest.mark.parametrize("M,force_small,row_mult", [(700, True, 1), (256 * 300 + 77, False, 1), (256 * 300, False, 3)])
 def test_gemm_nt_epilogue_dropout(ops, M, force_small, row_mult):
     """Dropout in the NT-GEMM epilogue (after the activation, before the residual add), 128- and 256-tile kernels, row_mult > 1
