@@ -70,9 +70,9 @@ __global__ void norm_fwd_kernel(const T* __restrict__ x, RowMap xmap, const floa
     float g[VPL], b[VPL];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) { g[i] = gamma[lane * VPL + i]; b[i] = (beta && !rms) ? beta[lane * VPL + i] : 0.f; }
-    for (int m = wave; m < rows; m += nw) {
-        float v[VPL];
-        load_row<VPL>(x + map_row(xmap, m) * D + lane * VPL, v);
+    // two rows per trip, both loads issued before the first reduction: one 1-KiB load per wave in flight does not cover the HBM
+    // latency-bandwidth product (3.9 TB/s with one row per trip, 4.6 with two, 3.9 again with four: fewer waves per SIMD)
+    auto finish = [&](int m, float (&v)[VPL]) {
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) s += v[i];
@@ -91,6 +91,14 @@ __global__ void norm_fwd_kernel(const T* __restrict__ x, RowMap xmap, const floa
             v[i] = o;
         }
         store_row<VPL>(y + map_row(ymap, m) * D + lane * VPL, v);
+    };
+    constexpr int RPT = 2;
+    for (int m = RPT * wave; m < rows; m += RPT * nw) {
+        float v[RPT][VPL];
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) if (m + j < rows) load_row<VPL>(x + map_row(xmap, m + j) * D + lane * VPL, v[j]);
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) if (m + j < rows) finish(m + j, v[j]);
     }
 }
 
@@ -115,11 +123,7 @@ __global__ void norm_bwd_kernel(const T* __restrict__ dy, RowMap dymap, const T*
         g[i] = gamma[lane * VPL + i]; b[i] = (beta && !rms) ? beta[lane * VPL + i] : 0.f;
         ag[i] = ab[i] = at0[i] = at1[i] = 0.f;
     }
-    for (int m = wave; m < rows; m += nw) {
-        float xv[VPL], dv[VPL];
-        load_row<VPL>(x + map_row(xmap, m) * D + lane * VPL, xv);
-        load_row<VPL>(dy + map_row(dymap, m) * D + lane * VPL, dv);
-        const float mu = rms ? 0.f : mean[m], rs = rstd_in[m];
+    auto finish = [&](int m, float (&xv)[VPL], float (&dv)[VPL], float mu, float rs) {
         if (dtok) {
             const int k = (dymap.G > 0 ? (m % dymap.G) : m) / tok_group;
 #pragma unroll
@@ -157,6 +161,21 @@ __global__ void norm_bwd_kernel(const T* __restrict__ dy, RowMap dymap, const T*
             }
             store_row<VPL>(dx_drop + (size_t)m * D + lane * VPL, xv);
         }
+    };
+    // two rows per trip, all four row loads issued before the first reduction (see norm_fwd_kernel)
+    for (int m = 2 * wave; m < rows; m += 2 * nw) {
+        float x0[VPL], d0[VPL], x1[VPL], d1[VPL];
+        const bool two = m + 1 < rows;
+        load_row<VPL>(x + map_row(xmap, m) * D + lane * VPL, x0);
+        load_row<VPL>(dy + map_row(dymap, m) * D + lane * VPL, d0);
+        if (two) {
+            load_row<VPL>(x + map_row(xmap, m + 1) * D + lane * VPL, x1);
+            load_row<VPL>(dy + map_row(dymap, m + 1) * D + lane * VPL, d1);
+        }
+        const float mu0 = rms ? 0.f : mean[m], rs0 = rstd_in[m];
+        const float mu1 = (rms || !two) ? 0.f : mean[m + 1], rs1 = two ? rstd_in[m + 1] : 0.f;
+        finish(m, x0, d0, mu0, rs0);
+        if (two) finish(m + 1, x1, d1, mu1, rs1);
     }
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
@@ -175,7 +194,7 @@ __global__ void norm_bwd_kernel(const T* __restrict__ dy, RowMap dymap, const T*
 }
 
 static inline int norm_grid(int rows) {
-    int blocks = (rows + 3) / 4;
+    int blocks = (rows + 7) / 8;      // 4 waves x 2 rows per trip
     return blocks > 2048 ? 2048 : (blocks < 1 ? 1 : blocks);
 }
 
@@ -206,7 +225,7 @@ static int norm_bwd_launch(const T* dy, int dyG, int dyGS, int dyOFF, const T* x
     if (dtok && tok_group <= 0) return SVLA_EINVAL;
     RowMap dym{dyG, dyGS, dyOFF}, xm{xG, xGS, xOFF}, dxm{dxG, dxGS, dxOFF};
     int blocks = norm_grid(rows);
-    if (blocks > 512) blocks = 512;  // fewer, fatter blocks: each ends with 4*D atomics
+    if (blocks > 1024) blocks = 1024;  // 4 workgroups per CU (<= 128 VGPRs); each ends with up to 4*D atomics
     hipLaunchKernelGGL((norm_bwd_kernel<T, 512>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, dym, x, xm, gamma, beta, mean,
                        rstd, rows, rms, relu, tok_group > 0 ? tok_group : 1, dres, dx, dxm, dgamma, dbeta, dtok, dx_drop, drop_cfg(drop));
     return svla_launch_status();
