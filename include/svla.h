@@ -138,6 +138,25 @@ int svla_attn_bwd_bf16(const svla_bf16* Q, const svla_bf16* K, const svla_bf16* 
  * instead of the single-pass kernel (8 slices) on the unmasked exact-tile shapes. */
 int svla_attn_bwd_two_pass(int on);
 
+/* ---- fp8 attention (BASELINE config 5: "fp8 MFMA attention") ---------------------------------------------------------------
+ * The unmasked fusion-encoder attention (same reference op as svla_attn_fwd_bf16: nn.MultiheadAttention inside the post-LN
+ * nn.TransformerEncoderLayer, allenact_dino_transformer.py:545-552,702-708) on v_mfma_f32_16x16x32_{fp8,bf8}: Q, K, V and the
+ * probabilities in OCP e4m3, dO and dS in OCP e5m2, fp32 accumulation / softmax, bf16 O, dQ, dK, dV.  S <= 256, head_dim 64.
+ * SP = S rounded up to 64 / 128 / 192 / 256.
+ *   svla_attn_fp8_quant : qkv bf16 [rows*S, ld >= 3*H*64] (Q | K | V column blocks) -> ws (rows*H*6*SP*64 bytes: per (row, head)
+ *                         Q8 | Q8T | K8 | K8T | V8 | V8T) and scales [rows*H*3] (dequantisation multiplier of each [S,64] slice)
+ *   svla_attn_fp8_fwd   : ws, scales -> O [rows*S, ldo], LSE [rows,H,S] (natural log, like the bf16 kernel)
+ *   svla_attn_fp8_bwd   : + O, LSE, dO -> dQ, dK, dV (row stride ldd); gws (rows*H*2*SP*64 bytes), gscale [rows*H] and
+ *                         D [rows*H*SP] are scratch the call fills itself (e5m2 copies of dO, their scales, rowsum(dO * O))
+ * drop: dropout on the probabilities, the same counter-based masks as the bf16 kernels. */
+int svla_attn_fp8_quant(const svla_bf16* qkv, long ld, int rows, int S, int H, int head_dim, unsigned char* ws, float* scales,
+                        void* stream);
+int svla_attn_fp8_fwd(const unsigned char* ws, const float* scales, svla_bf16* O, long ldo, float* LSE, int rows, int S, int H,
+                      int head_dim, float scale, const svla_dropout* drop, void* stream);
+int svla_attn_fp8_bwd(const unsigned char* ws, const float* scales, const svla_bf16* O, long ldo, const float* LSE, const svla_bf16* dO,
+                      long lddo, unsigned char* gws, float* gscale, float* D, svla_bf16* dQ, svla_bf16* dK, svla_bf16* dV, long ldd,
+                      int rows, int S, int H, int head_dim, float scale, const svla_dropout* drop, void* stream);
+
 /* ---- observation / embedding glue ---------------------------------------------------------------------------- */
 /* (R,C,7,12) fp32 channels-first DINO features -> bf16 tokens [R, ncam, P, C] (input layout of the 1x1-conv compressor,
  * allenact_dino_transformer.py:663-667; tensor layout per architecture/allenact_preprocessors/dino_preprocessors.py:31-35). */

@@ -1,0 +1,524 @@
+// fp8 attention for the fusion encoder (BASELINE config 5: "fp8 MFMA attention"), gfx950, OCP formats:
+// Q, K, V and the probabilities in e4m3, the gradients dO and dS in e5m2, fp32 accumulation and softmax.
+// v_mfma_f32_16x16x32_{fp8,bf8}_{fp8,bf8}: lane l holds A[l&15][8*(l>>4)+0..7] / B[8*(l>>4)+0..7][l&15] as 8 bytes,
+// D[reg]: col = l&15, row = 4*(l>>4) + reg -- the bf16 16x16x32 layout with bytes for halves.
+// Reference op: nn.MultiheadAttention inside the post-LN nn.TransformerEncoderLayer of the fusion encoder (no mask;
+// allenact_dino_transformer.py:545-552,702-708); the bf16 kernels of attn.hip are the default, this file is the C5 variant.
+//
+// Design: every operand an MFMA needs with the REDUCTION index contiguous is prepared once, in global memory, by two
+// HBM-bound preparation kernels, so the attention kernels read nothing but plain 8-byte row fragments from LDS
+// (no transposed LDS reads, no in-kernel transposes):
+//   quant   : qkv (bf16) -> per (row, head): Q8 | Q8T | K8 | K8T | V8 | V8T  (e4m3, one fp32 scale per [S,64] slice each)
+//   bwd prep: dO, O      -> per (row, head): G8 | G8T (e5m2, one scale per slice), D = rowsum(dO * O)
+// X8 is [SP][64] (token-major), X8T is [64][SP] with the token index permuted inside each block of 32 so that the 8 bytes
+// at block offset 8g are tokens {4g..4g+3, 16+4g..16+4g+3}: exactly the 8 reduction slots in which a lane group g holds two
+// consecutive 16x16 score tiles (its probabilities / dS), which therefore feed the next MFMA without any data movement.
+// Static power-of-two scales keep P (x256, in [0, 284]) and dS (raw units x 2^-13) inside e4m3 / e5m2 range.
+#include "common.h"
+
+typedef unsigned char u8;
+#define HD 64
+#define F8_THREADS 256
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+#define E4M3_MAX 448.f
+#define E5M2_TARGET 16384.f        // dO slices are scaled to amax = 2^14 (e5m2 max is 57344; its 2 mantissa bits do not care)
+#define P_SCALE 256.f
+#define DS_SHIFT 0.0001220703125f  // 2^-13
+#define DS_UNSHIFT 8192.f
+
+struct Fp8Args {
+    const u8* ws;          // [rows*H][6][SP*64]: Q8 Q8T K8 K8T V8 V8T
+    const float* sc;       // [rows*H][3] dequantisation multipliers (amax / 448) of the Q, K, V slices
+    const u8* gws;         // [rows*H][2][SP*64]: G8 G8T (backward)
+    const float* sg;       // [rows*H]
+    const float* D;        // [rows*H][SP]
+    bf16_t* O; long ldo;
+    float* LSE;            // [rows, H, S]
+    bf16_t *dQ, *dK, *dV; long ldd;
+    int S, H;
+    float scale;
+    DropCfg drop;
+};
+
+__device__ __forceinline__ unsigned long long att_drop_row8(int S, int H, int r, int h, int q) {
+    return ((unsigned long long)((size_t)r * H + h) * S + q) * (unsigned long long)((S + 3) & ~3);
+}
+__device__ __forceinline__ bool att_keep1_8(const DropCfg& c, unsigned long long e) {
+    const unsigned x = drop_bits(c.key, e >> 1);
+    return ((e & 1) ? (x >> 16) : (x & 0xffffu)) >= c.thr;
+}
+
+__device__ __forceinline__ f32x4 mfma_ff(long a, long b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma_bf(long a, long b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma_fb(long a, long b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ long pack8_fp8(const float (&v)[8]) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false); hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+    return (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ long pack8_bf8(const float (&v)[8]) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], lo, false); lo = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_bf8_f32(v[4], v[5], hi, false); hi = __builtin_amdgcn_cvt_pk_bf8_f32(v[6], v[7], hi, true);
+    return (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+// position of token i (0..31) inside its block of 32 in a transposed slice
+__host__ __device__ __forceinline__ int f8_perm(int i) { return 8 * ((i & 15) >> 2) + (i & 3) + 4 * (i >> 4); }
+
+// ---- LDS images ------------------------------------------------------------------------------------------------------
+// token-major [SP][64 B]: 8-byte chunk c of row r at r*64 + ((c ^ f(r)) * 8), f = 2 * ((r >> 2) & 3): the 32 lanes of one
+// ds_read_b64 pass (16 rows x chunks {g, g+1 pass-wise}) hit 32 distinct 8-byte bank slots.  The swizzle keeps chunk pairs
+// together, so the image is filled with 16-byte stores.
+__device__ __forceinline__ int f8_rswz(int row) { return ((row >> 2) & 3) << 1; }
+// reduction-major [64][SP + 16]: the 16 pad bytes rotate consecutive rows by two 8-byte slots (conflict-free b64 reads of
+// 16 rows at one block offset).
+template <int SP>
+__device__ __forceinline__ void stage_rows8(u8* dst, const u8* src, int tid) {          // [SP][64] contiguous in global
+    constexpr int IT = SP * 4 / F8_THREADS;     // 16-byte chunks per thread
+    u32x4 w[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) w[i] = *(const u32x4*)(src + (size_t)(tid + i * F8_THREADS) * 16);
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int q = tid + i * F8_THREADS, row = q >> 2, c16 = q & 3;
+        *(u32x4*)(dst + row * 64 + (((2 * c16) ^ f8_rswz(row)) << 3)) = w[i];
+    }
+}
+template <int SP>
+__device__ __forceinline__ void stage_tr8(u8* dst, const u8* src, int tid) {            // [64][SP] contiguous in global
+    constexpr int IT = SP * 4 / F8_THREADS, CPR = SP / 16;
+    u32x4 w[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) w[i] = *(const u32x4*)(src + (size_t)(tid + i * F8_THREADS) * 16);
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int q = tid + i * F8_THREADS, row = q / CPR, cc = q % CPR;
+        *(u32x4*)(dst + row * (SP + 16) + cc * 16) = w[i];
+    }
+}
+// lane offsets: row fragment (row = tile*16 + (lane & 15), bytes 8g.. / 32+8g..) and transposed fragment (row = dt*16 + (lane & 15), byte 8g)
+struct F8Row { int lo, hi; };
+__device__ __forceinline__ F8Row f8_row_off(int lane) {
+    const int r = lane & 15, g = lane >> 4, f = f8_rswz(r);
+    return F8Row{r * 64 + ((g ^ f) << 3), r * 64 + (((g + 4) ^ f) << 3)};
+}
+#define LDS8(base, off) (*(const long*)((base) + (off)))
+
+// ============================================================================================== preparation kernels
+// one workgroup per (row, head, which in {Q,K,V}): amax -> scale -> e4m3, token-major and reduction-major copies
+template <int SP, bool GRAD>
+__device__ __forceinline__ void quant_slice(const bf16_t* src, long ld, int S, u8* dst_rows, u8* dst_tr, float* scale_out,
+                                            const bf16_t* osrc, long ldo, float* D_out, u8* tbuf, float* red) {
+    constexpr int IT = SP / 32;          // (row, 16-byte chunk) items per thread: row = tid/8 + 32 i, chunk = tid & 7
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float v[IT][8];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int row = (tid >> 3) + 32 * i, c = tid & 7;
+        const bool ok = row < S;
+        u32x4 w = {0, 0, 0, 0};
+        if (ok) w = *(const u32x4*)(src + (size_t)row * ld + c * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[i][2 * j] = bf_lo(w[j]); v[i][2 * j + 1] = bf_hi(w[j]); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[i][j]));
+        if (GRAD) {      // D[row] = sum_d dO * O
+            u32x4 o = {0, 0, 0, 0};
+            if (ok) o = *(const u32x4*)(osrc + (size_t)row * ldo + c * 8);
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d += v[i][2 * j] * bf_lo(o[j]) + v[i][2 * j + 1] * bf_hi(o[j]);
+            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+            if (c == 0) D_out[row] = d;
+        }
+    }
+    amax = wave_max(amax);
+    if (lane == 0) red[wid] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float target = GRAD ? E5M2_TARGET : E4M3_MAX;
+    const float inv = amax > 0.f ? target / amax : 0.f;
+    if (tid == 0) *scale_out = amax > 0.f ? amax / target : 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int row = (tid >> 3) + 32 * i, c = tid & 7;
+        float s8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s8[j] = v[i][j] * inv;
+        const long pk = GRAD ? pack8_bf8(s8) : pack8_fp8(s8);
+        *(long*)(dst_rows + (size_t)row * 64 + c * 8) = pk;
+        // reduction-major copy through LDS: byte (d = 8c + j, token position perm(row))
+        const int pos = (row & ~31) + f8_perm(row & 31);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tbuf[(8 * c + j) * (SP + 4) + pos] = (u8)((unsigned long long)pk >> (8 * j));
+    }
+    __syncthreads();
+    for (int q = tid; q < 64 * (SP / 4); q += F8_THREADS) {
+        const int d = q / (SP / 4), cc = q % (SP / 4);
+        *(uint32_t*)(dst_tr + (size_t)d * SP + cc * 4) = *(const uint32_t*)(tbuf + d * (SP + 4) + cc * 4);
+    }
+}
+
+template <int SP>
+__global__ void __launch_bounds__(F8_THREADS) attn_fp8_quant_kernel(const bf16_t* qkv, long ld, int S, int H, u8* ws, float* sc) {
+    __shared__ __attribute__((aligned(16))) u8 tbuf[64 * (SP + 4)];
+    __shared__ float red[4];
+    const int item = blockIdx.x, which = item % 3, rh = item / 3, r = rh / H, h = rh % H;
+    const bf16_t* src = qkv + (size_t)r * S * ld + which * (H * HD) + h * HD;
+    u8* base = ws + ((size_t)rh * 6 + 2 * which) * (SP * 64);
+    quant_slice<SP, false>(src, ld, S, base, base + SP * 64, sc + (size_t)rh * 3 + which, nullptr, 0, nullptr, tbuf, red);
+}
+template <int SP>
+__global__ void __launch_bounds__(F8_THREADS) attn_fp8_bwd_prep_kernel(const bf16_t* dO, long lddo, const bf16_t* O, long ldo, int S, int H,
+                                                                      u8* gws, float* sg, float* D) {
+    __shared__ __attribute__((aligned(16))) u8 tbuf[64 * (SP + 4)];
+    __shared__ float red[4];
+    const int rh = blockIdx.x, r = rh / H, h = rh % H;
+    u8* base = gws + (size_t)rh * 2 * (SP * 64);
+    quant_slice<SP, true>(dO + (size_t)r * S * lddo + h * HD, lddo, S, base, base + SP * 64, sg + rh, O + (size_t)r * S * ldo + h * HD, ldo,
+                          D + (size_t)rh * SP, tbuf, red);
+}
+
+// ============================================================================================== forward
+// one workgroup per (row, head); waves own query tiles ("swapped" S^T = K Q^T: a query's whole score row is lane-local)
+template <int NKT, bool DROP>
+__global__ void __launch_bounds__(F8_THREADS, 2) attn_fp8_fwd_kernel(Fp8Args p) {
+    if (DROP) p.drop = drop_resolve(p.drop);
+    extern __shared__ __attribute__((aligned(16))) u8 smem8[];
+    constexpr int SP = NKT * 16, MAXT = NKT / 4;
+    u8* Ks = smem8;                   // K8  [SP][64]
+    u8* Vt = Ks + SP * 64;            // V8T [64][SP+16]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int rh = blockIdx.x, r = rh / p.H, h = rh % p.H;
+    const int S = p.S, ql = lane & 15, g = lane >> 4;
+    const u8* wsh = p.ws + (size_t)rh * 6 * (SP * 64);
+    stage_rows8<SP>(Ks, wsh + 2 * (SP * 64), tid);
+    stage_tr8<SP>(Vt, wsh + 5 * (SP * 64), tid);
+    long qf[MAXT][2];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const u8* qp = wsh + (size_t)((wid + 4 * t) * 16 + ql) * 64 + 8 * g;
+        qf[t][0] = *(const long*)qp; qf[t][1] = *(const long*)(qp + 32);
+    }
+    const float sq = p.sc[rh * 3 + 0], sk = p.sc[rh * 3 + 1], sv = p.sc[rh * 3 + 2];
+    const float c1 = sq * sk * p.scale * LOG2E;
+    __syncthreads();
+    const F8Row kr = f8_row_off(lane);
+    const int vt_off = ql * (SP + 16) + 8 * g;
+    const float dsc = DROP ? p.drop.scale : 1.f;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int qt = wid + 4 * t, q = qt * 16 + ql;
+        const bool qok = q < S;
+        if (qt * 16 < S) {                                   // wave-uniform
+            f32x4 s[NKT];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                a = mfma_ff(LDS8(Ks, kr.lo + kt * 1024), qf[t][0], a);
+                a = mfma_ff(LDS8(Ks, kr.hi + kt * 1024), qf[t][1], a);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[e] = (kt * 16 + 4 * g + e < S) ? a[e] * c1 : -INFINITY;      // padded keys
+                    mx = fmaxf(mx, a[e]);
+                }
+                s[kt] = a;
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[kt][e] = __builtin_amdgcn_exp2f(s[kt][e] - mx); sum += s[kt][e]; }
+            sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+            if (p.LSE && g == 0 && qok) p.LSE[(size_t)rh * S + q] = (mx + __builtin_amdgcn_logf(sum)) * LN2;
+            f32x4 o[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const unsigned long long drow = DROP ? att_drop_row8(S, p.H, r, h, qok ? q : 0) : 0ull;
+#pragma unroll
+            for (int u = 0; u < NKT / 2; ++u) {
+                float pv[8];
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    unsigned keep = 0xfu;
+                    if (DROP) keep = drop_keep4(p.drop, drow + (2 * u + e2) * 16 + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pv[e2 * 4 + e] = ((keep >> e) & 1u) ? s[2 * u + e2][e] * (P_SCALE * dsc) : 0.f;
+                }
+                const long p8 = pack8_fp8(pv);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt] = mfma_ff(LDS8(Vt, vt_off + dt * 16 * (SP + 16) + u * 32), p8, o[dt]);
+            }
+            if (qok) {
+                const float on = sv / (P_SCALE * sum);
+                bf16_t* op = p.O + ((size_t)r * S + q) * p.ldo + h * HD + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const u32x2 w = {pack_bf2(o[dt][0] * on, o[dt][1] * on), pack_bf2(o[dt][2] * on, o[dt][3] * on)};
+                    *(u32x2*)(op + dt * 16) = w;
+                }
+            }
+        }
+    }
+}
+
+// ============================================================================================== backward
+// phase A: waves own key tiles (LDS: Q8, G8 token-major; Q8T, G8T reduction-major) -> dK, dV
+// phase B: waves own query tiles (LDS: K8, V8 token-major; K8T) -> dQ
+template <int NKT, bool DROP>
+__global__ void __launch_bounds__(F8_THREADS, 2) attn_fp8_bwd_kernel(Fp8Args p) {
+    if (DROP) p.drop = drop_resolve(p.drop);
+    extern __shared__ __attribute__((aligned(16))) u8 smem8[];
+    constexpr int SP = NKT * 16, MAXT = NKT / 4, TR = 64 * (SP + 16);
+    u8* A0 = smem8;               // phase A: Q8      phase B: K8
+    u8* A1 = A0 + SP * 64;        //          G8               V8
+    u8* T0 = A1 + SP * 64;        //          Q8T              K8T
+    u8* T1 = T0 + TR;             //          G8T
+    float* nl_s = (float*)(T1 + TR);     // -lse * log2(e)  (-inf: padded query)
+    float* nd_s = nl_s + SP;             // -D / (sG * sV): rowsum(dO * O) in the raw units of G8 . V8
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int rh = blockIdx.x, r = rh / p.H, h = rh % p.H;
+    const int S = p.S, ql = lane & 15, g = lane >> 4;
+    const u8* wsh = p.ws + (size_t)rh * 6 * (SP * 64);
+    const u8* gsh = p.gws + (size_t)rh * 2 * (SP * 64);
+    const float sq = p.sc[rh * 3 + 0], sk = p.sc[rh * 3 + 1], sv = p.sc[rh * 3 + 2], sg = p.sg[rh];
+    const float c1 = sq * sk * p.scale * LOG2E;
+    const float gv = sg * sv, inv_gv = gv > 0.f ? 1.f / gv : 0.f;
+    const float dsc = DROP ? p.drop.scale : 1.f;
+    stage_rows8<SP>(A0, wsh + 0 * (SP * 64), tid);
+    stage_rows8<SP>(A1, gsh, tid);
+    stage_tr8<SP>(T0, wsh + 1 * (SP * 64), tid);
+    stage_tr8<SP>(T1, gsh + SP * 64, tid);
+    for (int i = tid; i < SP; i += F8_THREADS) {
+        nl_s[i] = i < S ? -p.LSE[(size_t)rh * S + i] * LOG2E : -INFINITY;
+        nd_s[i] = i < S ? -p.D[(size_t)rh * SP + i] * inv_gv : 0.f;
+    }
+    long kf[MAXT][2], vf[MAXT][2];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const size_t ro = (size_t)((wid + 4 * t) * 16 + ql) * 64 + 8 * g;
+        kf[t][0] = *(const long*)(wsh + 2 * (SP * 64) + ro); kf[t][1] = *(const long*)(wsh + 2 * (SP * 64) + ro + 32);
+        vf[t][0] = *(const long*)(wsh + 4 * (SP * 64) + ro); vf[t][1] = *(const long*)(wsh + 4 * (SP * 64) + ro + 32);
+    }
+    __syncthreads();
+    const F8Row rr = f8_row_off(lane);
+    const int tr_off = ql * (SP + 16) + 8 * g;
+    const f32x4 c14 = {c1, c1, c1, c1};
+    const unsigned long long drow0 = DROP ? att_drop_row8(S, p.H, r, h, 0) : 0ull;
+    const int S4 = (S + 3) & ~3;
+    // ---- phase A
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int kt = wid + 4 * t, keyl = kt * 16 + ql;
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt * 16 < S) {                                   // wave-uniform
+            f32x4 dk[4], dv[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 2
+            for (int w = 0; w < NKT / 2; ++w) {
+                float pv[8], dsv[8];
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const int qo = (2 * w + e2) * 1024;
+                    f32x4 sc_ = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    sc_ = mfma_ff(LDS8(A0, rr.lo + qo), kf[t][0], sc_);
+                    sc_ = mfma_ff(LDS8(A0, rr.hi + qo), kf[t][1], sc_);
+                    dp = mfma_bf(LDS8(A1, rr.lo + qo), vf[t][0], dp);
+                    dp = mfma_bf(LDS8(A1, rr.hi + qo), vf[t][1], dp);
+                    // element e: query (2w+e2)*16 + 4g + e, key keyl
+                    const f32x4 nl4 = *(const f32x4*)(nl_s + (2 * w + e2) * 16 + 4 * g), nd4 = *(const f32x4*)(nd_s + (2 * w + e2) * 16 + 4 * g);
+                    const f32x4 x = __builtin_elementwise_fma(sc_, c14, nl4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pr = __builtin_amdgcn_exp2f(x[e]);
+                        bool kp = true;
+                        if (DROP) {
+                            const int q = (2 * w + e2) * 16 + 4 * g + e;
+                            kp = att_keep1_8(p.drop, drow0 + (unsigned)((q < S ? q : 0) * S4 + keyl));
+                        }
+                        const float tt = kp ? dp[e] * dsc + nd4[e] : nd4[e];
+                        pv[e2 * 4 + e] = kp ? pr * (P_SCALE * dsc) : 0.f;
+                        dsv[e2 * 4 + e] = fminf(fmaxf(pr * tt * DS_SHIFT, -49152.f), 49152.f);
+                    }
+                }
+                const long p8 = pack8_fp8(pv), d8 = pack8_bf8(dsv);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dv[dt] = mfma_bf(LDS8(T1, tr_off + dt * 16 * (SP + 16) + w * 32), p8, dv[dt]);    // dV^T: G8T (e5m2) x P (e4m3)
+                    dk[dt] = mfma_fb(LDS8(T0, tr_off + dt * 16 * (SP + 16) + w * 32), d8, dk[dt]);    // dK^T: Q8T (e4m3) x dS (e5m2)
+                }
+            }
+            if (keyl < S) {
+                const float vn = sg * (1.f / P_SCALE), kn = sq * gv * p.scale * DS_UNSHIFT;
+                bf16_t* kp_ = p.dK + ((size_t)r * S + keyl) * p.ldd + h * HD + 4 * g;
+                bf16_t* vp_ = p.dV + ((size_t)r * S + keyl) * p.ldd + h * HD + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const u32x2 wk = {pack_bf2(dk[dt][0] * kn, dk[dt][1] * kn), pack_bf2(dk[dt][2] * kn, dk[dt][3] * kn)};
+                    const u32x2 wv = {pack_bf2(dv[dt][0] * vn, dv[dt][1] * vn), pack_bf2(dv[dt][2] * vn, dv[dt][3] * vn)};
+                    *(u32x2*)(kp_ + dt * 16) = wk;
+                    *(u32x2*)(vp_ + dt * 16) = wv;
+                }
+            }
+        }
+    }
+    // ---- phase B operands
+    __builtin_amdgcn_sched_barrier(0);
+    long qf[MAXT][2], gf[MAXT][2];
+    float lq[MAXT], dq_[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int qt = wid + 4 * t;
+        qf[t][0] = LDS8(A0, rr.lo + qt * 1024); qf[t][1] = LDS8(A0, rr.hi + qt * 1024);
+        gf[t][0] = LDS8(A1, rr.lo + qt * 1024); gf[t][1] = LDS8(A1, rr.hi + qt * 1024);
+        lq[t] = nl_s[qt * 16 + ql]; dq_[t] = nd_s[qt * 16 + ql];
+    }
+    __syncthreads();
+    stage_rows8<SP>(A0, wsh + 2 * (SP * 64), tid);
+    stage_rows8<SP>(A1, wsh + 4 * (SP * 64), tid);
+    stage_tr8<SP>(T0, wsh + 3 * (SP * 64), tid);
+    __syncthreads();
+    // ---- phase B
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int qt = wid + 4 * t, q = qt * 16 + ql;
+        __builtin_amdgcn_sched_barrier(0);
+        if (qt * 16 < S) {
+            const bool qok = q < S;
+            const f32x4 nl4 = {lq[t], lq[t], lq[t], lq[t]};
+            const float nd = dq_[t];
+            const unsigned long long drow = DROP ? drow0 + (unsigned long long)(qok ? q : 0) * S4 : 0ull;
+            f32x4 dq[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+            for (int u = 0; u < NKT / 2; ++u) {
+                float dsv[8];
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const int ko = (2 * u + e2) * 1024;
+                    f32x4 sc_ = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    sc_ = mfma_ff(LDS8(A0, rr.lo + ko), qf[t][0], sc_);
+                    sc_ = mfma_ff(LDS8(A0, rr.hi + ko), qf[t][1], sc_);
+                    dp = mfma_fb(LDS8(A1, rr.lo + ko), gf[t][0], dp);                 // V8 (e4m3) x G8 (e5m2)
+                    dp = mfma_fb(LDS8(A1, rr.hi + ko), gf[t][1], dp);
+                    const f32x4 x = __builtin_elementwise_fma(sc_, c14, nl4);
+                    unsigned keep = 0xfu;
+                    if (DROP) keep = drop_keep4(p.drop, drow + (2 * u + e2) * 16 + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pr = __builtin_amdgcn_exp2f(x[e]);
+                        const float tt = ((keep >> e) & 1u) ? dp[e] * dsc + nd : nd;
+                        dsv[e2 * 4 + e] = fminf(fmaxf(pr * tt * DS_SHIFT, -49152.f), 49152.f);
+                    }
+                }
+                const long d8 = pack8_bf8(dsv);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    dq[dt] = mfma_fb(LDS8(T0, tr_off + dt * 16 * (SP + 16) + u * 32), d8, dq[dt]);    // dQ^T: K8T (e4m3) x dS^T (e5m2)
+            }
+            if (qok) {
+                const float qn = sk * gv * p.scale * DS_UNSHIFT;
+                bf16_t* qp_ = p.dQ + ((size_t)r * S + q) * p.ldd + h * HD + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const u32x2 w = {pack_bf2(dq[dt][0] * qn, dq[dt][1] * qn), pack_bf2(dq[dt][2] * qn, dq[dt][3] * qn)};
+                    *(u32x2*)(qp_ + dt * 16) = w;
+                }
+            }
+        }
+    }
+}
+
+// ============================================================================================== C ABI
+static inline int f8_nkt(int S) { return S <= 64 ? 4 : S <= 128 ? 8 : S <= 192 ? 12 : 16; }
+
+extern "C" int svla_attn_fp8_quant(const bf16_t* qkv, long ld, int rows, int S, int H, int head_dim, unsigned char* ws, float* scales,
+                                   void* stream) {
+    if (head_dim != HD || rows <= 0 || S <= 0 || S > 256 || H <= 0 || (ld % 8) || ld < 3L * H * HD) return SVLA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(rows * H * 3), block(F8_THREADS);
+    switch (f8_nkt(S)) {
+        case 4: hipLaunchKernelGGL((attn_fp8_quant_kernel<64>), grid, block, 0, st, qkv, ld, S, H, ws, scales); break;
+        case 8: hipLaunchKernelGGL((attn_fp8_quant_kernel<128>), grid, block, 0, st, qkv, ld, S, H, ws, scales); break;
+        case 12: hipLaunchKernelGGL((attn_fp8_quant_kernel<192>), grid, block, 0, st, qkv, ld, S, H, ws, scales); break;
+        default: hipLaunchKernelGGL((attn_fp8_quant_kernel<256>), grid, block, 0, st, qkv, ld, S, H, ws, scales); break;
+    }
+    return svla_launch_status();
+}
+
+template <int NKT>
+static int f8_launch_fwd(const Fp8Args& p, int rows, hipStream_t st) {
+    constexpr int SP = NKT * 16;
+    const size_t lds = SP * 64 + 64 * (SP + 16);
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fp8_fwd_kernel<NKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fp8_fwd_kernel<NKT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    if (p.drop.thr) hipLaunchKernelGGL((attn_fp8_fwd_kernel<NKT, true>), dim3(rows * p.H), dim3(F8_THREADS), lds, st, p);
+    else hipLaunchKernelGGL((attn_fp8_fwd_kernel<NKT, false>), dim3(rows * p.H), dim3(F8_THREADS), lds, st, p);
+    return svla_launch_status();
+}
+template <int NKT>
+static int f8_launch_bwd(const Fp8Args& p, int rows, hipStream_t st) {
+    constexpr int SP = NKT * 16;
+    const size_t lds = 2 * SP * 64 + 2 * 64 * (SP + 16) + 2 * SP * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fp8_bwd_kernel<NKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fp8_bwd_kernel<NKT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    if (p.drop.thr) hipLaunchKernelGGL((attn_fp8_bwd_kernel<NKT, true>), dim3(rows * p.H), dim3(F8_THREADS), lds, st, p);
+    else hipLaunchKernelGGL((attn_fp8_bwd_kernel<NKT, false>), dim3(rows * p.H), dim3(F8_THREADS), lds, st, p);
+    return svla_launch_status();
+}
+
+extern "C" int svla_attn_fp8_fwd(const unsigned char* ws, const float* scales, bf16_t* O, long ldo, float* LSE, int rows, int S, int H,
+                                 int head_dim, float scale, const svla_dropout* drop, void* stream) {
+    if (head_dim != HD || rows <= 0 || S <= 0 || S > 256 || H <= 0 || (ldo % 4)) return SVLA_EINVAL;
+    Fp8Args p{};
+    p.ws = ws; p.sc = scales; p.O = O; p.ldo = ldo; p.LSE = LSE; p.S = S; p.H = H; p.scale = scale; p.drop = drop_cfg(drop);
+    hipStream_t st = (hipStream_t)stream;
+    switch (f8_nkt(S)) {
+        case 4: return f8_launch_fwd<4>(p, rows, st);
+        case 8: return f8_launch_fwd<8>(p, rows, st);
+        case 12: return f8_launch_fwd<12>(p, rows, st);
+        default: return f8_launch_fwd<16>(p, rows, st);
+    }
+}
+
+extern "C" int svla_attn_fp8_bwd(const unsigned char* ws, const float* scales, const bf16_t* O, long ldo, const float* LSE, const bf16_t* dO,
+                                 long lddo, unsigned char* gws, float* gscale, float* D, bf16_t* dQ, bf16_t* dK, bf16_t* dV, long ldd,
+                                 int rows, int S, int H, int head_dim, float scale, const svla_dropout* drop, void* stream) {
+    if (head_dim != HD || rows <= 0 || S <= 0 || S > 256 || H <= 0 || (ldo % 8) || (lddo % 8) || (ldd % 4)) return SVLA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(rows * H), block(F8_THREADS);
+    switch (f8_nkt(S)) {
+        case 4: hipLaunchKernelGGL((attn_fp8_bwd_prep_kernel<64>), grid, block, 0, st, dO, lddo, O, ldo, S, H, gws, gscale, D); break;
+        case 8: hipLaunchKernelGGL((attn_fp8_bwd_prep_kernel<128>), grid, block, 0, st, dO, lddo, O, ldo, S, H, gws, gscale, D); break;
+        case 12: hipLaunchKernelGGL((attn_fp8_bwd_prep_kernel<192>), grid, block, 0, st, dO, lddo, O, ldo, S, H, gws, gscale, D); break;
+        default: hipLaunchKernelGGL((attn_fp8_bwd_prep_kernel<256>), grid, block, 0, st, dO, lddo, O, ldo, S, H, gws, gscale, D); break;
+    }
+    int rc = svla_launch_status();
+    if (rc) return rc;
+    Fp8Args p{};
+    p.ws = ws; p.sc = scales; p.gws = gws; p.sg = gscale; p.D = D; p.LSE = (float*)LSE; p.dQ = dQ; p.dK = dK; p.dV = dV; p.ldd = ldd;
+    p.S = S; p.H = H; p.scale = scale; p.drop = drop_cfg(drop);
+    switch (f8_nkt(S)) {
+        case 4: return f8_launch_bwd<4>(p, rows, st);
+        case 8: return f8_launch_bwd<8>(p, rows, st);
+        case 12: return f8_launch_bwd<12>(p, rows, st);
+        default: return f8_launch_bwd<16>(p, rows, st);
+    }
+}

@@ -323,6 +323,46 @@ def attn_bwd(q, k, v, ld, o, ldo, lse, do, lddo, dq, dk, dv, ldd, rows, S, H, sc
                rows, S, H, 64, float(scale), mask_mode, _p(traj), _p(bias), _p(kvalid), int(Sq), int(ldq), int(lddq), _p(d_ws), _d(drop), _stream())
 
 
+# ---- fp8 attention (BASELINE config 5) ---------------------------------------------------------------------------------------
+def _fp8_sp(S: int) -> int:
+    return 64 if S <= 64 else 128 if S <= 128 else 192 if S <= 192 else 256
+
+
+class Fp8QKV:
+    """e4m3 copies of one layer's Q, K, V head slices (token-major and reduction-major) + their scales (svla_attn_fp8_quant)."""
+    __slots__ = ("ws", "scales", "rows", "S", "H")
+
+    def __init__(self, ws, scales, rows, S, H):
+        self.ws, self.scales, self.rows, self.S, self.H = ws, scales, rows, S, H
+
+
+def attn_fp8_quant(qkv, ld, rows, S, H) -> Fp8QKV:
+    _chk(qkv, BF16, "qkv")
+    ws = torch.empty(rows * H * 6 * _fp8_sp(S) * 64, device=qkv.device, dtype=torch.uint8)
+    scales = torch.empty(rows * H * 3, device=qkv.device, dtype=F32)
+    lib().call("svla_attn_fp8_quant", _p(qkv), ld, rows, S, H, 64, _p(ws), _p(scales), _stream())
+    return Fp8QKV(ws, scales, rows, S, H)
+
+
+def attn_fp8_fwd(f8: Fp8QKV, scale, out=None, save_lse=True, drop=None):
+    rows, S, H = f8.rows, f8.S, f8.H
+    if out is None:
+        out = torch.empty(rows * S, H * 64, device=f8.ws.device, dtype=BF16)
+    lse = torch.empty(rows, H, S, device=f8.ws.device, dtype=F32) if save_lse else None
+    lib().call("svla_attn_fp8_fwd", _p(f8.ws), _p(f8.scales), _p(out), out.stride(-2), _p(lse), rows, S, H, 64, float(scale), _d(drop), _stream())
+    return out, lse
+
+
+def attn_fp8_bwd(f8: Fp8QKV, o, lse, do, dq, dk, dv, ldd, scale, drop=None):
+    rows, S, H = f8.rows, f8.S, f8.H
+    sp = _fp8_sp(S)
+    gws = torch.empty(rows * H * 2 * sp * 64, device=o.device, dtype=torch.uint8)
+    gscale = torch.empty(rows * H, device=o.device, dtype=F32)
+    dws = torch.empty(rows * H * sp, device=o.device, dtype=F32)
+    lib().call("svla_attn_fp8_bwd", _p(f8.ws), _p(f8.scales), _p(o), o.stride(-2), _p(lse), _p(do), do.stride(-2), _p(gws), _p(gscale), _p(dws),
+               _p(dq), _p(dk), _p(dv), ldd, rows, S, H, 64, float(scale), _d(drop), _stream())
+
+
 # ------------------------------------------------------------------------------------------------ glue
 def feat_to_tokens(feat, out, cam, ncam=2):
     """feat (R,C,7,12) or (R,C,P) fp32 -> out bf16 [R, ncam, P, C] slot ``cam``."""

@@ -31,3 +31,17 @@ for (R, S, drop) in [(int(os.environ.get("AB_ROWS", 8192)), 181, None), (4096, 2
     err = (a - b).abs().max().item(); ref = a.abs().max().item()
     cos = torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
     print(f"R={R} S={S} drop={'yes' if drop else 'no'}: two-pass {res[1][0]:.3f} ms, single-pass {res[0][0]:.3f} ms; max |diff| {err:.3e} (max |grad| {ref:.3e}), cosine {cos:.7f}")
+
+# fp8 variant (BASELINE config 5) next to the bf16 kernels, S = 233
+for (R, S) in [(4096, 233), (8192, 181)]:
+    qkv = (torch.randn(R * S, 1536, device="cuda") * 0.5).to(torch.bfloat16)
+    out, lse = ops.attn_fwd(qkv, qkv[:, 512:], qkv[:, 1024:], 1536, R, S, 8, 0.125)
+    do = torch.randn_like(out); dqkv = torch.zeros_like(qkv)
+    fb = t_ms(lambda: ops.attn_fwd(qkv, qkv[:, 512:], qkv[:, 1024:], 1536, R, S, 8, 0.125, out=out))
+    bb = t_ms(lambda: ops.attn_bwd(qkv, qkv[:, 512:], qkv[:, 1024:], 1536, out, 512, lse, do, 512, dqkv, dqkv[:, 512:], dqkv[:, 1024:], 1536, R, S, 8, 0.125))
+    f8 = ops.attn_fp8_quant(qkv, 1536, R, S, 8)
+    tq = t_ms(lambda: ops.attn_fp8_quant(qkv, 1536, R, S, 8))
+    o8, l8 = ops.attn_fp8_fwd(f8, 0.125)
+    f8f = t_ms(lambda: ops.attn_fp8_fwd(f8, 0.125, out=o8))
+    f8b = t_ms(lambda: ops.attn_fp8_bwd(f8, o8, l8, do, dqkv, dqkv[:, 512:], dqkv[:, 1024:], 1536, 0.125))
+    print(f"R={R} S={S}: bf16 fwd {fb:.3f} ms bwd {bb:.3f} ms | fp8 quant {tq:.3f} ms fwd {f8f:.3f} ms bwd (prep + kernel) {f8b:.3f} ms")
