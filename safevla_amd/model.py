@@ -144,6 +144,9 @@ class Tower(nn.Module):
         self.max_steps = max_steps
         self.time_step_counter = 0
         self.prune_last = True      # dead-output elimination in the last fusion layer (exact; see run_forward)
+        # BASELINE config 5 ("fp8 MFMA attention"): the full-sequence fusion-encoder attention layers run on the e4m3 / e5m2 kernels
+        # (svla_attn_fp8_*); the pruned last layer (one query per row) and the decoder keep the bf16 kernels.  bf16 precision only.
+        self.fp8_attention = False
         # The reference leaves the policy in train() mode (allenact_dino_transformer.py:193): nn.TransformerEncoderLayer's
         # dropout 0.1 is active in rollouts and updates.  Same here: ``.eval()`` turns it off (parity fixtures are eval-mode).
         self.dropout_p = 0.1
@@ -341,7 +344,13 @@ class Tower(nn.Module):
                 xf, xf_stride = xo, D
                 continue
             qkv = ops.gemm_nt(xf, w[f"f{i}.in"], M, 3 * D, D, bias=l.self_attn.in_proj_bias)
-            ao, lse = ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, R, S, 8, 0.125, save_lse=need_grad, drop=site(i, 0))
+            f8 = None
+            if self.fp8_attention and self.adt == BF16 and S <= 256:
+                f8 = ops.attn_fp8_quant(qkv, 3 * D, R, S, 8)
+                ao, lse = ops.attn_fp8_fwd(f8, 0.125, save_lse=need_grad, drop=site(i, 0))
+                qkv = None                       # the backward reads the e4m3 copies
+            else:
+                ao, lse = ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, R, S, 8, 0.125, save_lse=need_grad, drop=site(i, 0))
             h1 = ops.gemm_nt(ao, w[f"f{i}.out"], M, D, D, bias=l.self_attn.out_proj.bias, residual=xf, drop=site(i, 1))
             x1, m1, r1 = ops.norm_fwd(h1, l.norm1.weight, l.norm1.bias, 1e-5, M, save_stats=need_grad)
             # the ReLU derivative is kept as 1 bit per element (M x 256 bytes): the input-gradient GEMM then reads 16x fewer mask bytes
@@ -350,7 +359,7 @@ class Tower(nn.Module):
             h2 = ops.gemm_nt(f1, w[f"f{i}.l2"], M, D, 2048, bias=l.linear2.bias, residual=x1, drop=site(i, 3))
             xo, m2, r2 = ops.norm_fwd(h2, l.norm2.weight, l.norm2.bias, 1e-5, M, save_stats=need_grad)
             if need_grad:
-                fl.append(dict(pruned=False, x=xf, qkv=qkv, ao=ao, lse=lse, h1=h1, x1=x1, n1=(m1, r1), f1=f1, f1b=f1b, h2=h2, n2=(m2, r2)))
+                fl.append(dict(pruned=False, x=xf, qkv=qkv, f8=f8, ao=ao, lse=lse, h1=h1, x1=x1, n1=(m1, r1), f1=f1, f1b=f1b, h2=h2, n2=(m2, r2)))
             xf = xo
         c["fusion"] = fl
         # decoder over the rollout time axis, rows (b*T + t)
@@ -576,8 +585,11 @@ class Tower(nn.Module):
             dao = ops.gemm_nt(da, wt[f"f{i}.out"], M, D, D)
             dqkv = torch.empty(M, 3 * D, device=dev, dtype=self.adt)
             q = a["qkv"]
-            ops.attn_bwd(q, q[:, D:], q[:, 2 * D:], 3 * D, a["ao"], D, a["lse"], dao, D, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D,
-                         R, S, 8, 0.125, drop=site(i, 0))
+            if a.get("f8") is not None:
+                ops.attn_fp8_bwd(a["f8"], a["ao"], a["lse"], dao, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D, 0.125, drop=site(i, 0))
+            else:
+                ops.attn_bwd(q, q[:, D:], q[:, 2 * D:], 3 * D, a["ao"], D, a["lse"], dao, D, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D,
+                             R, S, 8, 0.125, drop=site(i, 0))
             ops.gemm_tn_acc(dqkv, a["x"], dw[f"f{i}.in"], M, 3 * D, D, db=g(l.self_attn.in_proj_bias))
             dyf = ops.gemm_nt(dqkv, wt[f"f{i}.in"], M, D, 3 * D, residual=dh1)
             c["fusion"][i] = None
@@ -795,6 +807,13 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
             # T5Frozen.sync() REPLACES the encoder's runtime tensors: recorded acting steps (and the engine's recorded env-chunks, through
             # the hook below) hold the old ones alive and would keep acting on the previous encoder while updates use the new one
             self.invalidate_recorded()
+
+    def set_fp8_attention(self, on: bool) -> None:
+        """BASELINE config 5: run the full-sequence fusion-encoder attention of all three towers (acting and update passes) on the
+        e4m3 / e5m2 kernels.  Recorded acting steps are dropped: they hold the other kernels' launches."""
+        for t in self.towers:
+            t.fp8_attention = bool(on)
+        self.invalidate_recorded()
 
     def invalidate_recorded(self):
         """Drop every recorded launch sequence / captured graph that may reference replaced tensors."""
