@@ -394,6 +394,8 @@ def main():
                     help="weak (default): every GPU runs --envs-per-gpu envs; strong: --global-envs envs (BASELINE configs[3]: Fetch, 256) are sharded "
                          "over the ranks with parallel.shard_envs, the reference's evenly_distribute_count_into_bins (training/online/base.py:208-224)")
     ap.add_argument("--global-envs", type=int, default=256)
+    ap.add_argument("--deterministic", action="store_true", help="bitwise-repeatable gradients (64-bit fixed-point accumulation, PPOLagConfig.deterministic); "
+                    "the default bench line is measured with the fp32 atomics")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -429,7 +431,7 @@ def main():
         if B <= 0:
             raise SystemExit(f"bench.py --scaling strong: {args.global_envs} envs cannot feed {world} ranks")
     chunk = args.env_chunk if 0 < args.env_chunk < B else None
-    cfg = PPOLagConfig(env_chunk=chunk, cost_limit=args.cost_limit)
+    cfg = PPOLagConfig(env_chunk=chunk, cost_limit=args.cost_limit, deterministic=args.deterministic)
     eng = PPOLagEngine(model, cfg)
     st, nxt, ep = fill_synthetic_rollout(model, SynthSpec(T=T, B=B, L=args.L, task=args.task, seed=1234 + rank), device=dev)
 
@@ -443,7 +445,7 @@ def main():
         del eng
         torch.cuda.empty_cache()
         chunk = 32 if B > 32 else max(1, B // 2)
-        cfg = PPOLagConfig(env_chunk=chunk, cost_limit=args.cost_limit)
+        cfg = PPOLagConfig(env_chunk=chunk, cost_limit=args.cost_limit, deterministic=args.deterministic)
         eng = PPOLagEngine(model, cfg)
         ms, info, step = timed_updates(eng, st, nxt, ep, args.steps, args.warmup, world, dev)
     env_steps = T * (args.global_envs if args.scaling == "strong" else B * world)
@@ -547,7 +549,7 @@ def main():
                                       f"{'' if chunk is None else f' in {B // chunk} env-chunks of {chunk}'}, Adam+clip",
                           "global_envs": args.global_envs if args.scaling == "strong" else B * world, "rollout_steps": T, "rows_per_gpu": R, "parallelism": f"dp{world}", "env_chunk": chunk,
                           "stage_losses": list(cfg.stage_losses), "weights": "random-init, reference geometry (168.9 M params)",
-                          "dropout": 0.0 if args.eval_mode else 0.1},
+                          "dropout": 0.0 if args.eval_mode else 0.1, "deterministic_accumulation": bool(args.deterministic)},
                "reference_equivalent_tflop_per_update": round(algo / 1e12, 1),
                "note": "reference_equivalent counts SURVEY 8(d) FLOPs of the reference's schedule; the engine executes fewer (last fusion "
                        "layer only for the consumed token, T5 once per unique goal) -- see roofline.executed_mfma_*",

@@ -138,6 +138,17 @@ int svla_attn_bwd_bf16(const svla_bf16* Q, const svla_bf16* K, const svla_bf16* 
  * instead of the single-pass kernel (8 slices) on the unmasked exact-tile shapes. */
 int svla_attn_bwd_two_pass(int on);
 
+/* ---- deterministic gradient accumulation --------------------------------------------------------------------------------------
+ * Every weight / bias / LayerNorm / embedding gradient of the backward (autograd of the layers cited above) is accumulated across
+ * workgroups with fp32 atomics, so its last bits depend on arrival order.  svla_det_config(slot, f32_base, i64_shadow, n) registers
+ * an int64 shadow (zero-initialised, n elements) of the fp32 range [f32_base, f32_base + n): from then on every such accumulation
+ * whose target lies in a registered range is added to the shadow as 64-bit fixed point (2^-40 resolution; integer adds commute, so the
+ * sum is bitwise repeatable and exact) instead.  svla_det_finalize adds shadow * 2^-40 into the fp32 buffer and clears the shadow.
+ * slot 0 / 1: two independent ranges (the flat gradient buffer; a scratch range for accumulated intermediates).  NULL, NULL, 0
+ * unregisters.  bf16 product path only (the fp32 verification kernels keep their atomics). */
+int svla_det_config(int slot, float* f32_base, long long* i64_shadow, long n);
+int svla_det_finalize(float* f32, long long* i64_shadow, long n, void* stream);
+
 /* ---- fp8 attention (BASELINE config 5: "fp8 MFMA attention") ---------------------------------------------------------------
  * The unmasked fusion-encoder attention (same reference op as svla_attn_fwd_bf16: nn.MultiheadAttention inside the post-LN
  * nn.TransformerEncoderLayer, allenact_dino_transformer.py:545-552,702-708) on v_mfma_f32_16x16x32_{fp8,bf8}: Q, K, V and the

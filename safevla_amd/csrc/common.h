@@ -103,3 +103,24 @@ __device__ __forceinline__ unsigned drop_keep4(const DropCfg& c, unsigned long l
     return ((r0 & 0xffffu) >= c.thr ? 1u : 0u) | ((r0 >> 16) >= c.thr ? 2u : 0u) | ((r1 & 0xffffu) >= c.thr ? 4u : 0u) | ((r1 >> 16) >= c.thr ? 8u : 0u);
 }
 
+
+// ---- deterministic gradient accumulation (svla_det_config) -------------------------------------------------------------------
+// fp32 atomicAdd makes every accumulated gradient depend on the arrival order of the workgroups.  With a registered shadow buffer the
+// same partial sums are added as 64-bit FIXED-POINT integers (2^-40 resolution, +-8.4e6 range): integer addition is associative, so
+// the result is bitwise repeatable -- and exact, where the fp32 atomic rounds at every step.  svla_det_finalize folds the shadow back
+// into the fp32 buffer.  Up to two registered ranges: the flat gradient buffer, and a scratch range for accumulated intermediates.
+struct DetCfg { float* f32[2]; long long* i64[2]; long n[2]; };
+extern DetCfg g_svla_det;                 // host-side current configuration (misc.hip); all-null = plain fp32 atomics
+#define DET_SCALE 1099511627776.f         // 2^40
+#define DET_UNSCALE 9.094947017729282e-13 // 2^-40
+__device__ __forceinline__ unsigned long long det_fixed(float v) { return (unsigned long long)__float2ll_rn(v * DET_SCALE); }
+__device__ __forceinline__ void grad_add(const DetCfg& d, float* p, float v) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (d.i64[k]) {
+            const long off = p - d.f32[k];
+            if (off >= 0 && off < d.n[k]) { atomicAdd((unsigned long long*)(d.i64[k] + off), det_fixed(v)); return; }
+        }
+    }
+    atomicAdd(p, v);
+}

@@ -987,6 +987,7 @@ struct GemmTnArgs {
     const bf16_t* X; long ldx;    // [M, K]
     float* dW; long ldw;          // [N, K] fp32, accumulated with atomics
     int M, N, K, chunk_rows;
+    DetCfg det;                   // deterministic mode: fixed-point shadow of dW (common.h)
 };
 
 __device__ __forceinline__ bf16x8 frag_tr(const bf16_t* tile, int step, int col0, int lane) {
@@ -1078,7 +1079,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_tn_bf16_kernel(GemmTnArgs p)
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int k = k0 + wk * 64 + j * 32 + (lane & 31);
-                atomicAdd(p.dW + (size_t)n * p.ldw + k, acc[i][j][r]);
+                grad_add(p.det, p.dW + (size_t)n * p.ldw + k, acc[i][j][r]);
             }
 }
 
@@ -1109,6 +1110,7 @@ struct GemmTn256Args {
     float* db;
     int M, N, K, chunk_rows;
     int dbg;      // timing-only ablations of gemm_tn8p: 64 = DMA stream + barriers alone, 32 = no DMA (fragment reads + MFMAs + barriers), 16 = nt loads
+    DetCfg det;   // deterministic mode: fixed-point shadow of dW / db (common.h)
 };
 
 __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_tn256_bf16_kernel(GemmTn256Args p) {
@@ -1209,12 +1211,12 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_tn256_bf16_kernel(GemmT
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int k = k0 + wk * 64 + j * 32 + (lane & 31);
-                atomicAdd(p.dW + (size_t)n * p.ldw + k, acc[i][j][r]);
+                grad_add(p.det, p.dW + (size_t)n * p.ldw + k, acc[i][j][r]);
             }
     if (do_bias && (lane & 31) == 0) {   // every column of accb holds the same sums: lanes 0 and 32 publish their 16 rows
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            atomicAdd(p.db + n0 + wn * 128 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), accb[r]);
+            grad_add(p.det, p.db + n0 + wn * 128 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), accb[r]);
     }
 }
 
@@ -1365,12 +1367,12 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_tn8p_bf16_kernel(GemmTn
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int k = k0 + wk * 64 + j * 32 + (lane & 31);
-                atomicAdd(p.dW + (size_t)n * p.ldw + k, acc[i][j][r]);
+                grad_add(p.det, p.dW + (size_t)n * p.ldw + k, acc[i][j][r]);
             }
     if (do_bias && (lane & 31) == 0) {   // every column of accb holds the same sums: lanes 0 and 32 publish their 16 rows
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            atomicAdd(p.db + n0 + wn * 128 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), accb[r]);
+            grad_add(p.det, p.db + n0 + wn * 128 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), accb[r]);
     }
 }
 
@@ -1394,7 +1396,7 @@ extern "C" int svla_gemm_tn_f32acc(const bf16_t* dY, long ldy, const bf16_t* X, 
         if (chunks < 1) chunks = 1;
         int chunk_rows = ((M + chunks - 1) / chunks + TN256_ROWS - 1) / TN256_ROWS * TN256_ROWS;
         chunks = (M + chunk_rows - 1) / chunk_rows;
-        GemmTn256Args q{dY, ldy, X, ldx, dW, ldw, db, M, N, K, chunk_rows, g_dbg};
+        GemmTn256Args q{dY, ldy, X, ldx, dW, ldw, db, M, N, K, chunk_rows, g_dbg, g_svla_det};
         const size_t lds256 = (size_t)TN_NS * 2 * TN256_ROWS * 256 * sizeof(bf16_t);   // 128 KiB
         static bool attr256 = false;
         if (!attr256) {
@@ -1423,7 +1425,7 @@ extern "C" int svla_gemm_tn_f32acc(const bf16_t* dY, long ldy, const bf16_t* X, 
     int chunk_rows = ((M + chunks - 1) / chunks + TK - 1) / TK * TK;
     if (chunk_rows < 4 * TK) chunk_rows = 4 * TK;
     chunks = (M + chunk_rows - 1) / chunk_rows;
-    GemmTnArgs p{dY, ldy, X, ldx, dW, ldw, M, N, K, chunk_rows};
+    GemmTnArgs p{dY, ldy, X, ldx, dW, ldw, M, N, K, chunk_rows, g_svla_det};
     const size_t lds = 2 * 2 * TK * 128 * sizeof(bf16_t);  // 64 KiB
     static bool attr_set = false;
     if (!attr_set) {
@@ -1436,7 +1438,7 @@ extern "C" int svla_gemm_tn_f32acc(const bf16_t* dY, long ldy, const bf16_t* X, 
 
 // Column sums (bias gradients): db[n] += sum_m dY[m, n].  HBM-bound single pass, 16-byte loads.
 __global__ void colsum_bf16_kernel(const bf16_t* __restrict__ dY, long ldy, int M, int N, int row_stride_groups,
-                                   float* __restrict__ db) {
+                                   float* __restrict__ db, DetCfg det) {
     // each thread owns 8 consecutive columns; blockDim.x threads cover N columns (N/8 <= blockDim.x) x rows/block
     const int cpr = N / 8;                       // chunks per row
     const int rows_per_pass = blockDim.x / cpr;
@@ -1457,7 +1459,7 @@ __global__ void colsum_bf16_kernel(const bf16_t* __restrict__ dY, long ldy, int 
         const int cc = col >> 3, e = col & 7;
         float t = 0.f;
         for (int r = 0; r < rows_per_pass; ++r) t += red[(r * cpr + cc) * 8 + e];
-        atomicAdd(&db[col], t);
+        grad_add(det, &db[col], t);
     }
 }
 
@@ -1469,6 +1471,6 @@ extern "C" int svla_colsum_bf16(const bf16_t* dY, long ldy, int M, int N, int ro
     int blocks = (M + rpp - 1) / rpp;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3(blocks), dim3(threads), threads * 8 * sizeof(float), (hipStream_t)stream, dY, ldy,
-                       M, N, row_stride > 0 ? row_stride : 1, db);
+                       M, N, row_stride > 0 ? row_stride : 1, db, g_svla_det);
     return svla_launch_status();
 }

@@ -5,6 +5,7 @@
 //   swiglu / _bwd       : llama FeedForward gate
 //   adam / sumsq / cast / transpose : flat-buffer optimiser step (clip by global norm, no host sync)
 #include "common.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------
 // DataAugmentation/DINO preprocessor output is (R, C=384, 7, 12) fp32 (dino_preprocessors.py:31-35); the 1x1-conv
@@ -54,7 +55,7 @@ extern "C" int svla_fusion_fill(const float* fusion_token, const bf16_t* text, c
 // dtext[gid[r], j, :] += dx0[r, text_off + j, :].  Rows are (t*B + b); an env's goal is constant over an episode,
 // so one workgroup walks one env over t and flushes a register accumulator only when the goal id changes.
 __global__ void fusion_text_bwd_kernel(const bf16_t* __restrict__ dx0, const int* __restrict__ gid, int T, int B, int S,
-                                       int L, int text_off, float* __restrict__ dtext) {
+                                       int L, int text_off, float* __restrict__ dtext, DetCfg det) {
     const int b = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int cur = gid[b];
@@ -64,7 +65,7 @@ __global__ void fusion_text_bwd_kernel(const bf16_t* __restrict__ dx0, const int
         if (g != cur) {
             float* d = dtext + ((size_t)cur * L + j) * 512 + lane * 8;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { atomicAdd(d + e, acc[e]); acc[e] = 0.f; }
+            for (int e = 0; e < 8; ++e) { grad_add(det, d + e, acc[e]); acc[e] = 0.f; }
             cur = g;
         }
         const u32x4 w = *(const u32x4*)(dx0 + ((size_t)r * S + text_off + j) * 512 + lane * 8);
@@ -73,13 +74,13 @@ __global__ void fusion_text_bwd_kernel(const bf16_t* __restrict__ dx0, const int
     }
     float* d = dtext + ((size_t)cur * L + j) * 512 + lane * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(d + e, acc[e]);
+    for (int e = 0; e < 8; ++e) grad_add(det, d + e, acc[e]);
 }
 
 extern "C" int svla_fusion_text_bwd(const bf16_t* dx0, const int* gid, int T, int B, int S, int L, int text_off, float* dtext,
                                     void* stream) {
     if (T <= 0 || B <= 0 || L <= 0) return SVLA_EINVAL;
-    hipLaunchKernelGGL(fusion_text_bwd_kernel, dim3(B, L), dim3(64), 0, (hipStream_t)stream, dx0, gid, T, B, S, L, text_off, dtext);
+    hipLaunchKernelGGL(fusion_text_bwd_kernel, dim3(B, L), dim3(64), 0, (hipStream_t)stream, dx0, gid, T, B, S, L, text_off, dtext, g_svla_det);
     return svla_launch_status();
 }
 
@@ -125,16 +126,23 @@ extern "C" int svla_decoder_embed_fwd(const bf16_t* xf, long xf_row_stride, cons
 }
 
 // dxf[(t*B+b) row, :] = dout[b*T+t, :];  d act_tab / d hand_tab accumulated in LDS per block, then flushed.
+// DET: the per-block LDS table is fixed-point too (the four waves of a block reach it in arbitrary order).
+template <bool DET>
 __global__ void decoder_embed_bwd_kernel(const bf16_t* __restrict__ dout, const int64_t* __restrict__ prev_actions,
                                          const float* __restrict__ masks, const int64_t* __restrict__ hand, int T, int B,
                                          int n_actions, bf16_t* __restrict__ dxf, long dxf_row_stride,
-                                         float* __restrict__ d_act_tab, float* __restrict__ d_hand_tab) {
-    extern __shared__ float tab[];  // [(n_actions + 2) + 3][512]
+                                         float* __restrict__ d_act_tab, float* __restrict__ d_hand_tab, DetCfg det) {
+    extern __shared__ __attribute__((aligned(16))) char tab_raw[];  // [(n_actions + 2) + 3][512] float (or 64-bit fixed point)
+    typedef typename std::conditional<DET, unsigned long long, float>::type acc_t;
+    acc_t* tab = (acc_t*)tab_raw;
     const int nrows_tab = n_actions + 2 + 3;
-    for (int i = threadIdx.x; i < nrows_tab * 512; i += blockDim.x) tab[i] = 0.f;
+    for (int i = threadIdx.x; i < nrows_tab * 512; i += blockDim.x) tab[i] = (acc_t)0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int nw = (gridDim.x * blockDim.x) >> 6;
+    auto add = [&](int idx, float v) {
+        if constexpr (DET) atomicAdd(&tab[idx], det_fixed(v)); else atomicAdd(&tab[idx], v);
+    };
     for (int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wave < T * B; wave += nw) {
         const int t = wave / B, b = wave % B;
         const u32x4 w = *(const u32x4*)(dout + ((size_t)b * T + t) * 512 + lane * 8);
@@ -144,18 +152,19 @@ __global__ void decoder_embed_bwd_kernel(const bf16_t* __restrict__ dout, const 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float lo = bf_lo(w[e]), hi = bf_hi(w[e]);
-            atomicAdd(&tab[a * 512 + lane * 8 + 2 * e], lo);
-            atomicAdd(&tab[a * 512 + lane * 8 + 2 * e + 1], hi);
-            atomicAdd(&tab[hh * 512 + lane * 8 + 2 * e], lo);
-            atomicAdd(&tab[hh * 512 + lane * 8 + 2 * e + 1], hi);
+            add(a * 512 + lane * 8 + 2 * e, lo);
+            add(a * 512 + lane * 8 + 2 * e + 1, hi);
+            add(hh * 512 + lane * 8 + 2 * e, lo);
+            add(hh * 512 + lane * 8 + 2 * e + 1, hi);
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nrows_tab * 512; i += blockDim.x) {
-        const float v = tab[i];
+        float v;
+        if constexpr (DET) v = (float)((double)(long long)tab[i] * DET_UNSCALE); else v = tab[i];
         if (v != 0.f) {
-            if (i < (n_actions + 2) * 512) atomicAdd(&d_act_tab[i], v);
-            else atomicAdd(&d_hand_tab[i - (n_actions + 2) * 512], v);
+            if (i < (n_actions + 2) * 512) grad_add(det, &d_act_tab[i], v);
+            else grad_add(det, &d_hand_tab[i - (n_actions + 2) * 512], v);
         }
     }
 }
@@ -164,13 +173,45 @@ extern "C" int svla_decoder_embed_bwd(const bf16_t* dout, const int64_t* prev_ac
                                       int T, int B, int n_actions, bf16_t* dxf, long dxf_row_stride, float* d_act_tab,
                                       float* d_hand_tab, void* stream) {
     if (T <= 0 || B <= 0) return SVLA_EINVAL;
-    const size_t lds = (size_t)(n_actions + 5) * 512 * sizeof(float);
+    const bool det = g_svla_det.i64[0] != nullptr || g_svla_det.i64[1] != nullptr;
+    const size_t lds = (size_t)(n_actions + 5) * 512 * (det ? sizeof(unsigned long long) : sizeof(float));
     int blocks = (T * B + 63) / 64;
     if (blocks > 128) blocks = 128;
     static bool attr = false;
-    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)decoder_embed_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-    hipLaunchKernelGGL(decoder_embed_bwd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, dout, prev_actions, masks, hand,
-                       T, B, n_actions, dxf, dxf_row_stride, d_act_tab, d_hand_tab);
+    if (!attr) {
+        const int cap = (n_actions + 5) * 512 * 8;
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)decoder_embed_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)decoder_embed_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        attr = true;
+    }
+    if (det)
+        hipLaunchKernelGGL(decoder_embed_bwd_kernel<true>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, dout, prev_actions, masks, hand,
+                           T, B, n_actions, dxf, dxf_row_stride, d_act_tab, d_hand_tab, g_svla_det);
+    else
+        hipLaunchKernelGGL(decoder_embed_bwd_kernel<false>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, dout, prev_actions, masks, hand,
+                           T, B, n_actions, dxf, dxf_row_stride, d_act_tab, d_hand_tab, g_svla_det);
+    return svla_launch_status();
+}
+
+// ---- deterministic accumulation: configuration and fold-back (common.h: DetCfg) -------------------------------------------------
+DetCfg g_svla_det = {{nullptr, nullptr}, {nullptr, nullptr}, {0, 0}};
+
+extern "C" int svla_det_config(int slot, float* f32_base, long long* i64_shadow, long n) {
+    if (slot < 0 || slot > 1 || n < 0 || ((f32_base == nullptr) != (i64_shadow == nullptr))) return SVLA_EINVAL;
+    g_svla_det.f32[slot] = f32_base; g_svla_det.i64[slot] = i64_shadow; g_svla_det.n[slot] = f32_base ? n : 0;
+    return SVLA_OK;
+}
+__global__ void det_finalize_kernel(float* __restrict__ f, long long* __restrict__ s, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long long v = s[i];
+        if (v != 0) { f[i] += (float)((double)v * DET_UNSCALE); s[i] = 0; }
+    }
+}
+extern "C" int svla_det_finalize(float* f32, long long* i64_shadow, long n, void* stream) {
+    if (n <= 0 || !f32 || !i64_shadow) return SVLA_EINVAL;
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(det_finalize_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, f32, i64_shadow, n);
     return svla_launch_status();
 }
 

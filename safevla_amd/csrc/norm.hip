@@ -111,7 +111,7 @@ __global__ void norm_bwd_kernel(const T* __restrict__ dy, RowMap dymap, const T*
                                 const float* __restrict__ mean, const float* __restrict__ rstd_in, int rows, int rms,
                                 int relu, int tok_group, const T* __restrict__ dres, T* __restrict__ dx,
                                 RowMap dxmap, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                float* __restrict__ dtok, T* __restrict__ dx_drop, DropCfg drop) {
+                                float* __restrict__ dtok, T* __restrict__ dx_drop, DropCfg drop, DetCfg det) {
     drop = drop_resolve(drop);
     constexpr int VPL = D / 64;
     __shared__ float red[4][4 * D];  // [wave][dgamma | dbeta | dtok0 | dtok1]
@@ -187,9 +187,9 @@ __global__ void norm_bwd_kernel(const T* __restrict__ dy, RowMap dymap, const T*
     for (int c = threadIdx.x; c < 4 * D; c += blockDim.x) {
         float s = 0.f;
         for (int w = 0; w < nwv; ++w) s += red[w][c];
-        if (c < D) { if (dgamma) atomicAdd(&dgamma[c], s); }
-        else if (c < 2 * D) { if (dbeta && !rms) atomicAdd(&dbeta[c - D], s); }
-        else if (dtok) atomicAdd(&dtok[c - 2 * D], s);
+        if (c < D) { if (dgamma) grad_add(det, &dgamma[c], s); }
+        else if (c < 2 * D) { if (dbeta && !rms) grad_add(det, &dbeta[c - D], s); }
+        else if (dtok) grad_add(det, &dtok[c - 2 * D], s);
     }
 }
 
@@ -227,7 +227,7 @@ static int norm_bwd_launch(const T* dy, int dyG, int dyGS, int dyOFF, const T* x
     int blocks = norm_grid(rows);
     if (blocks > 1024) blocks = 1024;  // 4 workgroups per CU (<= 128 VGPRs); each ends with up to 4*D atomics
     hipLaunchKernelGGL((norm_bwd_kernel<T, 512>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, dym, x, xm, gamma, beta, mean,
-                       rstd, rows, rms, relu, tok_group > 0 ? tok_group : 1, dres, dx, dxm, dgamma, dbeta, dtok, dx_drop, drop_cfg(drop));
+                       rstd, rows, rms, relu, tok_group > 0 ? tok_group : 1, dres, dx, dxm, dgamma, dbeta, dtok, dx_drop, drop_cfg(drop), g_svla_det);
     return svla_launch_status();
 }
 

@@ -344,7 +344,7 @@ __global__ void small_linear_fwd_kernel(const float* __restrict__ x, const float
 template <int N_MAX>
 __global__ void small_linear_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                         const float* __restrict__ dout, int rows, int N, int T, int B, int accumulate_dx,
-                                        float* __restrict__ dx, float* __restrict__ dW, float* __restrict__ db) {
+                                        float* __restrict__ dx, float* __restrict__ dW, float* __restrict__ db, DetCfg det) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -383,8 +383,8 @@ __global__ void small_linear_bwd_kernel(const float* __restrict__ x, const float
     for (int n = 0; n < N_MAX; ++n) {
         if (n < N) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) atomicAdd(&dW[(size_t)n * 512 + lane * 8 + k], gw[n][k]);
-            if (lane == 0 && db) atomicAdd(&db[n], gb[n]);
+            for (int k = 0; k < 8; ++k) grad_add(det, &dW[(size_t)n * 512 + lane * 8 + k], gw[n][k]);
+            if (lane == 0 && db) grad_add(det, &db[n], gb[n]);
         }
     }
 }
@@ -406,9 +406,9 @@ extern "C" int svla_small_linear_bwd_f32(const float* x, const float* W, const f
     if (blocks > 256) blocks = 256;
     if (N <= 1)
         hipLaunchKernelGGL(small_linear_bwd_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, W, dout, rows, N,
-                           T, B, accumulate_dx, dx, dW, db);
+                           T, B, accumulate_dx, dx, dW, db, g_svla_det);
     else
         hipLaunchKernelGGL(small_linear_bwd_kernel<20>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, W, dout, rows,
-                           N, T, B, accumulate_dx, dx, dW, db);
+                           N, T, B, accumulate_dx, dx, dW, db, g_svla_det);
     return svla_launch_status();
 }

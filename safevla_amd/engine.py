@@ -55,6 +55,7 @@ class PPOLagConfig:
     record_small_updates: bool = True     # small minibatches: record each env-chunk's launch sequence in the first epoch, replay it in the others
     adam_betas: Tuple[float, float] = (0.9, 0.999)
     adam_eps: float = 1e-8
+    deterministic: bool = False           # bitwise-repeatable gradients: cross-workgroup accumulation in 64-bit fixed point (svla_det_config)
 
 
 class PPOLagEngine:
@@ -69,6 +70,8 @@ class PPOLagEngine:
         self._gnorm_sq = torch.zeros(1, device=dev, dtype=torch.float64)
         self._sums = torch.zeros(5, device=dev, dtype=torch.float64)   # v_sq, action, -entropy, hl-gauss CE (discrete critic), c_v_sq
         self.gemm_flops = 0
+        # deterministic mode: an int64 shadow of the flat gradient buffer (8 B per parameter)
+        self._det_shadow = torch.zeros(model.arena.flat_g.numel(), device=dev, dtype=torch.int64) if cfg.deterministic else None
         if not hasattr(model, "_invalidate_hooks"):
             model._invalidate_hooks = []
         model._invalidate_hooks.append(self._chunk_cache.clear)      # load_state_dict / broadcast replace the frozen encoder's tensors
@@ -126,6 +129,7 @@ class PPOLagEngine:
         discrete = m.critic_type == "discrete"
         small = m.concurrent_towers and R * prep.S <= m.concurrent_tower_tokens
         record = (small and cache_key is not None and cfg.record_small_updates and m.adt == torch.bfloat16 and m.critic_type == "linear"
+                  and not cfg.deterministic        # the accumulation mode is read at launch time, not part of a recorded launch
                   and len(self._chunk_cache) < 4)        # a recorded chunk keeps its three towers' activations alive: bound the footprint
         flat = {k: f(batch[k]) for k in ("actions", "old_action_log_probs", "adv_targ", "c_adv_targ", "c_returns")}     # contiguous once, outside the recorded region
 
@@ -181,18 +185,27 @@ class PPOLagEngine:
             else:
                 blocks[k]()
             if last:
+                if cfg.deterministic:      # fold this tower's fixed-point sums into its fp32 range before anything reads it
+                    a, b = m.arena.tower_ranges[k]
+                    ops.det_finalize(m.arena.flat_g[a:b], self._det_shadow[a:b])
                 self._reduce_tower_async(k)
             return plan
 
-        if small:
-            # small minibatches are bound by the dispatch of ~1000 small dependent kernels: the three towers (independent given the batch)
-            # run on three HIP streams (model.run_towers_concurrently); gradients land in disjoint arena ranges, loss sums are atomics
-            plans = m.run_towers_concurrently(run_block)
-            if record:
-                self._chunk_cache[cache_key] = dict(sig=(R, n_total, lam, tuple(cfg.stage_losses), m.training), plans=plans, keep=(prep, flat, ret_))
-        else:
-            for k, t in enumerate(m.towers):      # update-sized shapes: one tower at a time (only one tower's activations resident)
-                run_block(k, t)
+        if cfg.deterministic:
+            ops.det_config(0, m.arena.flat_g, self._det_shadow)
+        try:
+            if small:
+                # small minibatches are bound by the dispatch of ~1000 small dependent kernels: the three towers (independent given the batch)
+                # run on three HIP streams (model.run_towers_concurrently); gradients land in disjoint arena ranges, loss sums are atomics
+                plans = m.run_towers_concurrently(run_block)
+                if record:
+                    self._chunk_cache[cache_key] = dict(sig=(R, n_total, lam, tuple(cfg.stage_losses), m.training), plans=plans, keep=(prep, flat, ret_))
+            else:
+                for k, t in enumerate(m.towers):      # update-sized shapes: one tower at a time (only one tower's activations resident)
+                    run_block(k, t)
+        finally:
+            if cfg.deterministic:
+                ops.det_config(0, None, None)
 
     def optimizer_step(self, reduced: bool = False):
         """Global-norm clip + Adam over the ranges of the towers that received a gradient.  ``reduced``: the per-tower asynchronous

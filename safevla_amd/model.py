@@ -597,7 +597,16 @@ class Tower(nn.Module):
         ops.colsum_acc(dx0, g(ve.fusion_token), R, D, row_stride=S)
         # text adapter (trainable) -- the T5 encoder is frozen (no_grad in the reference)
         dtf = ops.zeros(U * L, D, device=dev, dtype=F32)
-        ops.fusion_text_bwd(dx0, prep.gid, T, B, S, L, TEXT_OFF, dtf)
+        if ops.det_active():       # deterministic mode: this accumulated intermediate gets its own fixed-point shadow (slot 1)
+            dtf_sh = torch.zeros(U * L * D, device=dev, dtype=torch.int64)
+            ops.det_config(1, dtf, dtf_sh)
+            try:
+                ops.fusion_text_bwd(dx0, prep.gid, T, B, S, L, TEXT_OFF, dtf)
+                ops.det_finalize(dtf, dtf_sh)
+            finally:
+                ops.det_config(1, None, None)
+        else:
+            ops.fusion_text_bwd(dx0, prep.gid, T, B, S, L, TEXT_OFF, dtf)
         dtf_b = torch.empty(U * L, D, device=dev, dtype=self.adt)
         ops.cast_bf16(dtf, dtf_b)
         dta = ops.norm_bwd(dtf_b, c["ta"], ve.text_adapter[1].weight, ve.text_adapter[1].bias, c["ta_stats"][0], c["ta_stats"][1], U * L,

@@ -323,6 +323,30 @@ def attn_bwd(q, k, v, ld, o, ldo, lse, do, lddo, dq, dk, dv, ldd, rows, S, H, sc
                rows, S, H, 64, float(scale), mask_mode, _p(traj), _p(bias), _p(kvalid), int(Sq), int(ldq), int(lddq), _p(d_ws), _d(drop), _stream())
 
 
+# ---- deterministic gradient accumulation ---------------------------------------------------------------------------------------
+_DET_SLOTS = [None, None]
+
+
+def det_config(slot: int, f32: Optional[torch.Tensor], shadow: Optional[torch.Tensor]) -> None:
+    """Register (or with None, None: unregister) an int64 fixed-point shadow of an fp32 accumulation range (svla_det_config)."""
+    if f32 is None:
+        lib().call("svla_det_config", int(slot), None, None, 0)
+        _DET_SLOTS[slot] = None
+        return
+    assert f32.dtype == F32 and shadow.dtype == torch.int64 and shadow.numel() == f32.numel() and f32.is_contiguous()
+    lib().call("svla_det_config", int(slot), f32.data_ptr(), shadow.data_ptr(), f32.numel())
+    _DET_SLOTS[slot] = (f32, shadow)
+
+
+def det_active() -> bool:
+    return _DET_SLOTS[0] is not None
+
+
+def det_finalize(f32: torch.Tensor, shadow: torch.Tensor) -> None:
+    """f32 += shadow * 2^-40; shadow = 0 (svla_det_finalize), on the current stream."""
+    lib().call("svla_det_finalize", _p(f32), _p(shadow), f32.numel(), _stream())
+
+
 # ---- fp8 attention (BASELINE config 5) ---------------------------------------------------------------------------------------
 def _fp8_sp(S: int) -> int:
     return 64 if S <= 64 else 128 if S <= 128 else 192 if S <= 192 else 256
