@@ -874,7 +874,7 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_fused
     if (DROP) p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16, MAXT = (NKT + 3) / 4, IT = SP * 8 / ATT_THREADS;
-    constexpr bool KEEP_KV = NKT <= 12;   // K/V fragments of all of this wave's key tiles stay in registers and are written to LDS for
+    constexpr bool KEEP_KV = true;        // K/V fragments of all of this wave's key tiles stay in registers and are written to LDS for
                                           // the dQ phase (no second read); NKT = 16 has no registers for that and re-reads K, V
     bf16_t* As = (bf16_t*)smem;          // Q, then K
     bf16_t* Bs = As + SP * LDSROW;       // dO, then V
@@ -955,7 +955,7 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_fused
                 f32x4 dk[4], dv[4];
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll 2
+#pragma unroll (NKT <= 12 ? 2 : 1)
                 for (int w = 0; w < nw; ++w) {
                     const int off = w * 32 * LDSROW;
                     float pv[8], dsv[8];
@@ -1076,7 +1076,7 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_fused
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 // padded keys need no mask: their K rows are zero, so their dS never reaches dQ
-#pragma unroll 2
+#pragma unroll (NKT <= 12 ? 2 : 1)
                 for (int u = 0; u < NKT / 2; ++u) {
                     const int off = u * 32 * LDSROW;
                     float dsv[8];
