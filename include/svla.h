@@ -139,7 +139,8 @@ int svla_attn_bwd_bf16(const svla_bf16* Q, const svla_bf16* K, const svla_bf16* 
 int svla_attn_bwd_two_pass(int on);
 
 /* ---- deterministic gradient accumulation --------------------------------------------------------------------------------------
- * Every weight / bias / LayerNorm / embedding gradient of the backward (autograd of the layers cited above) is accumulated across
+ * Every weight / bias / LayerNorm / embedding gradient of the backward (torch autograd of the layers cited above, e.g.
+ * allenact_dino_transformer.py:545-552, feeding the Adam step of training/online/dinov2_vits_tsfm_base.py:331-334) is accumulated across
  * workgroups with fp32 atomics, so its last bits depend on arrival order.  svla_det_config(slot, f32_base, i64_shadow, n) registers
  * an int64 shadow (zero-initialised, n elements) of the fp32 range [f32_base, f32_base + n): from then on every such accumulation
  * whose target lies in a registered range is added to the shadow as 64-bit fixed point (2^-40 resolution; integer adds commute, so the
