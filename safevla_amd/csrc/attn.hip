@@ -15,6 +15,9 @@
 #ifndef ATT_SWZ_OLD
 #define ATT_SWZ_OLD 0
 #endif
+#ifndef ATT_EARLY_TR
+#define ATT_EARLY_TR 0      // measured: no gain at 3 workgroups per CU (other waves hide the LDS latency), spills with dropout
+#endif
 #define HD 64
 #define LDSROW 64   // LDS row = 128 B (one head slice row), 16-byte chunks XOR-swizzled: 48 KiB for two [192, 64] operands,
                     // so THREE workgroups fit a CU's 160 KiB (the kernels are latency-bound: 1 -> 2 workgroups/CU = 1.74x)
@@ -874,6 +877,7 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_fused
     if (DROP) p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16, MAXT = (NKT + 3) / 4, IT = SP * 8 / ATT_THREADS;
+    constexpr bool EARLY_TR = ATT_EARLY_TR && NKT <= 12;
     constexpr bool KEEP_KV = true;        // K/V fragments of all of this wave's key tiles stay in registers and are written to LDS for
                                           // the dQ phase (no second read); NKT = 16 has no registers for that and re-reads K, V
     bf16_t* As = (bf16_t*)smem;          // Q, then K
@@ -955,10 +959,15 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_fused
                 f32x4 dk[4], dv[4];
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll (NKT <= 12 ? 2 : 1)
+#pragma unroll (NKT <= 12 ? 2 : 1)       // full unroll (address bumps become immediates): measured 4 % slower
                 for (int w = 0; w < nw; ++w) {
                     const int off = w * 32 * LDSROW;
                     float pv[8], dsv[8];
+                    bf16x8 gfr[4], qfr[4];       // dO^T / Q^T fragments of this query pair: read first, their latency sits under the softmax block
+                    if (EARLY_TR) {
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) { gfr[dt] = lds_tr8i(Btr.d[dt] + off, 0, 16); qfr[dt] = lds_tr8i(Atr.d[dt] + off, 0, 16); }
+                    }
 #pragma unroll
                     for (int e2 = 0; e2 < 2; ++e2) {
                         const int o2 = off + e2 * 16 * LDSROW;
@@ -1009,8 +1018,9 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_fused
                     const bf16x8 pa = pack8(pv), da = pack8(dsv);
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt) {
-                        dv[dt] = mfma16(lds_tr8i(Btr.d[dt] + off, 0, 16), pa, dv[dt]);   // dV^T / dK^T: rows = head dims, cols = keys
-                        dk[dt] = mfma16(lds_tr8i(Atr.d[dt] + off, 0, 16), da, dk[dt]);
+                        if (!EARLY_TR) { gfr[dt] = lds_tr8i(Btr.d[dt] + off, 0, 16); qfr[dt] = lds_tr8i(Atr.d[dt] + off, 0, 16); }
+                        dv[dt] = mfma16(gfr[dt], pa, dv[dt]);   // dV^T / dK^T: rows = head dims, cols = keys
+                        dk[dt] = mfma16(qfr[dt], da, dk[dt]);
                     }
                 }
                 if (kok) {
