@@ -60,7 +60,19 @@ __device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) {
     typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
     return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// exact (erf) GELU of nn.GELU / timm's Mlp, branch-free: 1 + erf(x / sqrt 2) through Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 on erf, and no
+// cancellation in the negative tail: for x < 0 the quantity q = 1 - erf(|z|) IS the factor).  17 VALU ops (2 transcendental) where ocml's erff
+// is ~45 with branches -- the GELU epilogue was a third of the ViT's GEMM time.
+__device__ __forceinline__ float gelu_f(float x) {
+    const float az = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.f));
+    float q = fmaf(t, 1.061405429f, -1.453152027f);
+    q = fmaf(q, t, 1.421413741f);
+    q = fmaf(q, t, -0.284496736f);
+    q = fmaf(q, t, 0.254829592f);
+    q = q * t * __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);      // exp(-x^2 / 2)
+    return 0.5f * x * (x >= 0.f ? 2.f - q : q);
+}
 
 __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p) {
     p.drop = drop_resolve(p.drop);
@@ -483,7 +495,7 @@ struct Nt256Epi {
                 if (fh == 0 && m < p.M) *(u32x2*)(p.bits_out + relu_bits_word(m, n0 + wn * 64, p.N)) = ob;
             }
         };
-        if (!LDS_AUX && ACT != ACT_GELU) {
+        if (!LDS_AUX) {
             u32x2 pkA[8], pkB[8];
             unsigned obA[2], obB[2];
             u32x4 w[4];
