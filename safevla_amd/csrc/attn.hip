@@ -107,20 +107,20 @@ __device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
 
 // stage an [S, 64] head slice into LDS rows (zero-filled up to SP rows): all global loads are issued before the first LDS
 // store so the HBM/L2 latency is paid once, not once per loop trip
-template <int SP>
+template <int SP, int THREADS = ATT_THREADS>
 __device__ __forceinline__ void stage_head(bf16_t* dst, const bf16_t* src, long ld, int S, int tid) {
-    constexpr int IT = SP * 8 / ATT_THREADS;   // SP is a multiple of 32
+    constexpr int IT = SP * 8 / THREADS;       // SP is a multiple of 32 (of 64 with 512 threads)
     u32x4 w[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-        const int q = tid + i * ATT_THREADS;
+        const int q = tid + i * THREADS;
         const int row = q >> 3, c = q & 7;
         w[i] = u32x4{0, 0, 0, 0};
         if (row < S) w[i] = *(const u32x4*)(src + (size_t)row * ld + c * 8);
     }
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-        const int q = tid + i * ATT_THREADS;
+        const int q = tid + i * THREADS;
         *(u32x4*)(dst + (q >> 3) * LDSROW + (((q & 7) ^ att_swz(q >> 3)) << 3)) = w[i];
     }
 }
@@ -135,8 +135,10 @@ __device__ __forceinline__ bool masked(const AttnArgs& p, int q, int key, const 
 // ================================================================================================ forward
 // GENERIC = false: no bias / traj / padding mask (the fusion encoder, >99 % of the attention work): only the ragged tail
 // of the last key tile is masked and the softmax runs in the exp2 domain with the scale folded in.
-template <int NKT, bool GENERIC>
-__global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
+// NW = waves per workgroup.  The long-sequence shapes (S > 256: the ViT's 433 tokens) need > 80 KiB of LDS for K and V, i.e. ONE workgroup
+// per CU: eight waves instead of four share that K/V image (2 waves per SIMD hide each other's latency; measured 1.5x on S = 433).
+template <int NKT, bool GENERIC, int NW = 4>
+__global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs p) {
     p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16;
@@ -148,9 +150,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
     const int r = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const size_t tok0 = (size_t)r * p.kv_rows, mtok0 = (size_t)r * p.S;
     const int S = p.S;
-    stage_head<SP>(Ks, p.K + tok0 * p.ld + h * HD, p.ld, S, tid);
-    stage_head<SP>(Vs, p.V + tok0 * p.ld + h * HD, p.ld, S, tid);
-    for (int i = tid; i < SP; i += ATT_THREADS) {
+    stage_head<SP, NW * 64>(Ks, p.K + tok0 * p.ld + h * HD, p.ld, S, tid);
+    stage_head<SP, NW * 64>(Vs, p.V + tok0 * p.ld + h * HD, p.ld, S, tid);
+    for (int i = tid; i < SP; i += NW * 64) {
         traj_s[i] = (p.traj && i < S) ? p.traj[mtok0 + i] : -1;
         kv_s[i] = (p.kvalid && i < S) ? p.kvalid[mtok0 + i] : 1;
     }
@@ -158,13 +160,13 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
     const int Sq = p.Sq;
     const size_t qtok0 = (size_t)r * Sq;
     const int nqt = (Sq + 15) / 16;
-    // Q fragments of all of this wave's query tiles (qt = wid, wid+4, ...): issued before the barrier so their latency
+    // Q fragments of all of this wave's query tiles (qt = wid, wid+NW, ...): issued before the barrier so their latency
     // overlaps the K/V staging instead of stalling every tile
-    constexpr int MAXQT = (NKT + 3) / 4;
+    constexpr int MAXQT = (NKT + NW - 1) / NW;
     bf16x8 qall[MAXQT][2];
 #pragma unroll
     for (int t = 0; t < MAXQT; ++t) {
-        const int q = (wid + 4 * t) * 16 + ql;
+        const int q = (wid + NW * t) * 16 + ql;
         const bool ok = q < Sq;
         const bf16_t* qp = p.Q + (qtok0 + (ok ? q : 0)) * p.ldq + h * HD + 8 * g;
         qall[t][0] = ok ? *(const bf16x8*)qp : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -176,7 +178,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
     const TrBase Vtr = att_tr_base(Vs, lane);
 #pragma unroll
     for (int t = 0; t < MAXQT; ++t) {
-        const int qt = wid + 4 * t;
+        const int qt = wid + NW * t;
         if (qt >= nqt) break;
         const int q = qt * 16 + ql;
         const bf16x8 qf[2] = {qall[t][0], qall[t][1]};
@@ -1160,6 +1162,14 @@ static int launch_fwd(const AttnArgs& p, int rows, hipStream_t st) {
             }
             const int nitems = rows * p.H;
             hipLaunchKernelGGL((attn_fwd_persist_kernel<NKT>), dim3(nitems < slots ? nitems : slots), dim3(ATT_THREADS), ldsp, st, p, nitems);
+            return svla_launch_status();
+        }
+    }
+    if constexpr (NKT >= 28) {           // one workgroup per CU (K + V > 80 KiB): eight waves share the LDS image
+        if (!generic) {
+            static bool attr8 = false;
+            if (!attr8) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr8 = true; }
+            hipLaunchKernelGGL((attn_fwd_kernel<NKT, false, 8>), dim3(rows * p.H), dim3(512), lds, st, p);
             return svla_launch_status();
         }
     }
