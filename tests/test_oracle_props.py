@@ -71,3 +71,25 @@ def test_dropout_hash_statistics():
             assert abs(np.corrcoef(k[:-lag], k[lag:])[0, 1]) < 5 / n ** 0.5
         k2 = hash_keep(seed, stream + 1, 0.1, idx).astype(np.float64)
         assert abs(np.corrcoef(k, k2)[0, 1]) < 5 / n ** 0.5
+
+
+def test_branch_free_gelu_of_the_gemm_epilogue_is_the_erf_gelu():
+    """csrc/gemm.hip gelu_f (the ViT MLP epilogue) evaluates nn.GELU's exact erf form through Abramowitz-Stegun 7.1.26 without a branch;
+    this is its arithmetic restated in float32 numpy: absolute error <= 3e-7 (+ one float32 ulp of the value) everywhere, relative error below one bf16 ulp (the epilogue's
+    output precision) wherever the value is representable at all."""
+    import numpy as np
+    import torch
+
+    x = np.linspace(-12.0, 12.0, 400001, dtype=np.float32)
+    az = np.abs(x) * np.float32(0.70710678118654752)
+    t = np.float32(1.0) / (np.float32(0.3275911) * az + np.float32(1.0))
+    q = t * np.float32(1.061405429) + np.float32(-1.453152027)
+    q = q * t + np.float32(1.421413741)
+    q = q * t + np.float32(-0.284496736)
+    q = q * t + np.float32(0.254829592)
+    q = q * t * np.exp2(x * x * np.float32(-0.72134752044448170))
+    got = np.float32(0.5) * x * np.where(x >= 0, np.float32(2.0) - q, q)
+    want = torch.nn.functional.gelu(torch.from_numpy(x).double()).numpy()
+    assert (np.abs(got - want) <= 3e-7 + 1.2e-7 * np.abs(want)).all()          # 2e-7 of the formula + float32 rounding of the result
+    big = np.abs(want) > 1e-6
+    assert (np.abs(got - want)[big] / np.abs(want)[big]).max() < 2.0 ** -8
