@@ -1315,57 +1315,69 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_tn8p_bf16_kernel(GemmTn
 
 #pragma unroll
     for (int s = 0; s < TNP_L; ++s) issue();
-    if (nph > TNP_L) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    // steps 0 and 1 landed (4 younger steps = 8 instructions may stay in flight) and published
+    if (nph > TNP_L) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (wn == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind
     const long long t_begin = (p.dbg & 4) ? __builtin_readcyclecounter() : 0;
-#pragma clang loop unroll(disable)
-    for (int ph = 0; ph < nph; ++ph) {
-        const uint32_t sb = (uint32_t)(ph & 7) * 16384u;
-        // Transposed fragment gathers from inline asm: behind the builtin, hipcc cannot tell the reads from the LDS-DMA writes still in
-        // flight and drains the whole DMA queue (s_waitcnt vmcnt(0)) in front of the first one.  Rows r0 and r0 + 4 (+ 4 * 512 B).
-        bf16x4 ylo[4], yhi[4], xlo[2], xhi[2];
-        if (p.dbg & 64) {
-            issue();
-            if (dq <= nph) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_barrier\n\ts_barrier" ::: "memory");
-            continue;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048" : "=&v"(ylo[u]), "=&v"(yhi[u]) : "v"(sb + ay[u]) : "memory");
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048" : "=&v"(xlo[u]), "=&v"(xhi[u]) : "v"(sb + ax[u]) : "memory");
-        issue();
-        if (dq <= nph) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // steady state: steps ph+2 .. ph+6 may stay in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // tail of the chunk
-        const bool bt = do_bias && bturn == 0;
-        if (do_bias) bturn = (bturn + 1 == ntk) ? 0 : bturn + 1;
-        // barrier, then the fragment reads retire; the asm "modifies" fragments and accumulators, which pins the MFMAs behind it
-        asm volatile("s_barrier\n\ts_setprio 1\n\ts_waitcnt lgkmcnt(0)"
-                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(accb),
-                       "+v"(ylo[0]), "+v"(yhi[0]), "+v"(ylo[1]), "+v"(yhi[1]), "+v"(ylo[2]), "+v"(yhi[2]), "+v"(ylo[3]), "+v"(yhi[3]),
-                       "+v"(xlo[0]), "+v"(xhi[0]), "+v"(xlo[1]), "+v"(xhi[1])::"memory");
-        bf16x8 fy[4], fx[2];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) fy[u] = bf16x8{ylo[u][0], ylo[u][1], ylo[u][2], ylo[u][3], yhi[u][0], yhi[u][1], yhi[u][2], yhi[u][3]};
-#pragma unroll
-        for (int u = 0; u < 2; ++u) fx[u] = bf16x8{xlo[u][0], xlo[u][1], xlo[u][2], xlo[u][3], xhi[u][0], xhi[u][1], xhi[u][2], xhi[u][3]};
-        if (bt) {      // wave-uniform; this wave's 32 bias columns are fragment u = wk
-            const bf16x8 fsel = wk == 0 ? fy[0] : wk == 1 ? fy[1] : wk == 2 ? fy[2] : fy[3];
-            accb = mfma32(fsel, ones, accb);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fy[i], fx[j], acc[i][j]);
-        asm volatile("s_setprio 0\n\ts_barrier"
-                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(accb)::"memory");
+    // Transposed fragment gathers from inline asm: behind the builtin, hipcc cannot tell the reads from the LDS-DMA writes still in
+    // flight and drains the whole DMA queue (s_waitcnt vmcnt(0)) in front of the first one.  Rows r0 and r0 + 4 (+ 4 * 512 B).
+    // ONE barrier per phase, two fragment register sets: phase P = [step P's fragments retire] [gather step P+1 (its slot was published
+    // by the previous barrier)] [8 MFMAs of step P] [DMA issue of step P+6] [wait: step P+2 landed] barrier.  The two waves of a SIMD
+    // interleave their MFMAs and gathers freely.  (The two-barrier ping-pong of the NT kernel, gathering step P in its own load segment,
+    // ran at 837 cycles per phase without any DMA and 1 098 with it; MFMA-bound is 512.)
+    bf16x4 ylo[2][4], yhi[2][4], xlo[2][2], xhi[2][2];
+#define TNP_READS(SET_, SB_)                                                                                                                  \
+    {                                                                                                                                         \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                                                         \
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048" : "=&v"(ylo[SET_][u]), "=&v"(yhi[SET_][u]) : "v"((SB_) + ay[u]) : "memory"); \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                                                         \
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048" : "=&v"(xlo[SET_][u]), "=&v"(xhi[SET_][u]) : "v"((SB_) + ax[u]) : "memory"); \
     }
-    if (wn == 0) __builtin_amdgcn_s_barrier();      // pairs with group 1's last barrier
+#define TNP_PHASE(CUR_, NXT_)                                                                                                                 \
+    {                                                                                                                                         \
+        const bool bt = do_bias && bturn == 0;                                                                                                \
+        if (do_bias) bturn = (bturn + 1 == ntk) ? 0 : bturn + 1;                                                                              \
+        /* this step's fragment reads (issued one phase ago) retire; the asm "modifies" fragments and accumulators, which pins the MFMAs */   \
+        asm volatile("s_waitcnt lgkmcnt(0)"                                                                                                   \
+                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(accb), \
+                       "+v"(ylo[CUR_][0]), "+v"(yhi[CUR_][0]), "+v"(ylo[CUR_][1]), "+v"(yhi[CUR_][1]), "+v"(ylo[CUR_][2]), "+v"(yhi[CUR_][2]), "+v"(ylo[CUR_][3]), "+v"(yhi[CUR_][3]), \
+                       "+v"(xlo[CUR_][0]), "+v"(xhi[CUR_][0]), "+v"(xlo[CUR_][1]), "+v"(xhi[CUR_][1])::"memory");                               \
+        if (ph + 1 < nph) TNP_READS(NXT_, (uint32_t)((ph + 1) & 7) * 16384u)                                                                  \
+        bf16x8 fy[4], fx[2];                                                                                                                  \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) fy[u] = bf16x8{ylo[CUR_][u][0], ylo[CUR_][u][1], ylo[CUR_][u][2], ylo[CUR_][u][3], yhi[CUR_][u][0], yhi[CUR_][u][1], yhi[CUR_][u][2], yhi[CUR_][u][3]}; \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) fx[u] = bf16x8{xlo[CUR_][u][0], xlo[CUR_][u][1], xlo[CUR_][u][2], xlo[CUR_][u][3], xhi[CUR_][u][0], xhi[CUR_][u][1], xhi[CUR_][u][2], xhi[CUR_][u][3]}; \
+        if (bt) {      /* wave-uniform; this wave's 32 bias columns are fragment u = wk */                                                    \
+            const bf16x8 fsel = wk == 0 ? fy[0] : wk == 1 ? fy[1] : wk == 2 ? fy[2] : fy[3];                                                  \
+            accb = mfma32(fsel, ones, accb);                                                                                                  \
+        }                                                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                         \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fy[i], fx[j], acc[i][j]);                                        \
+        issue();                                                                                                                              \
+        if (dq <= nph) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      /* steady state: steps ph+3 .. ph+6 may stay in flight */        \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                /* tail of the chunk */                                          \
+        asm volatile("s_barrier"                                                                                                              \
+                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(accb)::"memory"); \
+    }
+    if (p.dbg & 64) {        // timing-only: DMA stream + barriers alone
+        for (int ph = 0; ph < nph; ++ph) {
+            issue();
+            if (dq <= nph) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+        }
+    } else {
+        TNP_READS(0, 0u)         // step 0 (published by the barrier above)
+#pragma clang loop unroll(disable)
+        for (int ph = 0; ph < nph; ph += 2) {      // nph is a multiple of 4 (64-row chunks)
+            TNP_PHASE(0, 1)
+            ++ph;
+            TNP_PHASE(1, 0)
+            --ph;
+        }
+    }
+#undef TNP_PHASE
+#undef TNP_READS
     if (p.dbg & 4) {      // timing-only: shader cycles per phase of this workgroup instead of the gradient
         if (tid == 0) p.dW[blockIdx.x] = (float)(__builtin_readcyclecounter() - t_begin) / (float)nph;
         return;
