@@ -9,6 +9,9 @@
 // adapter LayerNorm write straight into (and its backward read straight out of) the token slice of the
 // fusion-transformer input [R, S, D] without a concat/split copy.
 #include "common.h"
+#ifndef NORM_NT
+#define NORM_NT 1
+#endif
 
 struct RowMap { int G, GS, OFF; };
 __device__ __forceinline__ size_t map_row(const RowMap& rm, int m) {
@@ -18,7 +21,7 @@ __device__ __forceinline__ size_t map_row(const RowMap& rm, int m) {
 template <int VPL>
 __device__ __forceinline__ void load_row_bf16(const bf16_t* p, float (&v)[VPL]) {
     if constexpr (VPL == 8) {
-        const u32x4 w = *(const u32x4*)p;
+        const u32x4 w = NORM_NT ? __builtin_nontemporal_load((const u32x4*)p) : *(const u32x4*)p;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[2 * i] = bf_lo(w[i]); v[2 * i + 1] = bf_hi(w[i]); }
     } else {
@@ -33,7 +36,7 @@ __device__ __forceinline__ void store_row_bf16(bf16_t* p, const float (&v)[VPL])
         u32x4 w;
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
-        *(u32x4*)p = w;
+        if (NORM_NT) __builtin_nontemporal_store(w, (u32x4*)p); else *(u32x4*)p = w;
     } else {
         uint32_t* q = (uint32_t*)p;
 #pragma unroll
