@@ -496,7 +496,8 @@ def main():
                 "executed_mfma_frac_of_peak": round(executed / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                 # the other roof: this GEMM family is d = 512 wide (<= 256 FLOP/B at N = K = 512, below the 312 FLOP/B ridge of 2.5 PF / 8 TB/s),
                 # so the HBM roof binds before the MFMA one; counter traffic per launch / live launch duration
-                "hbm_view": None if traffic is None else {"achieved_TBps": round(traffic / (g["avg_ms"] * 1e-3) / 1e12, 3), "peak_TBps": PEAK_HBM_TBPS,
+                # (tiny configurations launch none of the 256-tile kernels: no launch duration to divide by, and the profiled traffic is not theirs)
+                "hbm_view": None if (traffic is None or g["avg_ms"] <= 0) else {"achieved_TBps": round(traffic / (g["avg_ms"] * 1e-3) / 1e12, 3), "peak_TBps": PEAK_HBM_TBPS,
                                                           "frac": round(traffic / (g["avg_ms"] * 1e-3) / 1e12 / PEAK_HBM_TBPS, 4)}}
     cpu = None
     acting = None

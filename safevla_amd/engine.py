@@ -25,6 +25,8 @@ moments freeze and its per-parameter step count does not advance.  Here: per-tow
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import weakref
+
 import torch
 
 from . import ops, parallel
@@ -74,7 +76,13 @@ class PPOLagEngine:
         self._det_shadow = torch.zeros(model.arena.flat_g.numel(), device=dev, dtype=torch.int64) if cfg.deterministic else None
         if not hasattr(model, "_invalidate_hooks"):
             model._invalidate_hooks = []
-        model._invalidate_hooks.append(self._chunk_cache.clear)      # load_state_dict / broadcast replace the frozen encoder's tensors
+        # load_state_dict / broadcast replace the frozen encoder's tensors: recorded env-chunks must go.  The hook holds the engine weakly --
+        # a strong reference to the cache would keep a discarded engine's recorded chunks (and their towers' activations) alive
+        ref = weakref.ref(self)
+        model._invalidate_hooks[:] = [h for h in model._invalidate_hooks if getattr(h, "_alive", lambda: True)()]
+        hook = lambda: (ref() is not None and ref()._chunk_cache.clear())
+        hook._alive = lambda: ref() is not None
+        model._invalidate_hooks.append(hook)
         if parallel.is_dist():      # independent dropout noise per rank (every rank holds different environments)
             for t in model.towers:
                 t.drop_seed_base += 7919 * torch.distributed.get_rank()
