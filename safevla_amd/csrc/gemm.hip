@@ -1414,7 +1414,8 @@ extern "C" int svla_gemm_tn_f32acc(const bf16_t* dY, long ldy, const bf16_t* X, 
         g_force_small_tile = 2;
         return rc;
     }
-    if ((N % 256) == 0 && (K % 256) == 0 && (M % TN256_ROWS) == 0 && (M >= 32768 || g_force_small_tile == 2) && g_force_small_tile != 1) {   // (59.6 k-row minibatches: 256 rows x 233 tokens)
+    if ((N % 256) == 0 && (K % 256) == 0 && (M % TN256_ROWS) == 0 && (M >= 16384 || (M >= 8192 && (long)N * K >= 1024L * 512) || g_force_small_tile == 2) && g_force_small_tile != 1) {
+        // measured (r03): at 16 k rows the 256-tile kernel is 1.0x (512 x 512) to 2.0x (1536 x 512) the 128-tile one, at 8 k rows 0.7x / 1.2-1.9x
         const int ntile256 = (N / 256) * (K / 256);
         int chunks = 256 / ntile256;                                  // <= one workgroup per CU (no second dispatch wave)
         if (chunks < 1) chunks = 1;
