@@ -962,7 +962,7 @@ extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, lon
     GemmNtArgs p{A, lda, B, ldb, bias, residual, ldr, relu_mask, ldm, C, ldc, M, N, K, act, out_f32, alpha, relu_bits_out, relu_bits, drop_cfg(drop), g_dbg};
     // N % 256 == 128 with N >= 384 (the ViT-S widths 384 and 1152): the last n-tile is a half tile (75 % / 90 % of the MFMA work useful) --
     // still well ahead of the 128-tile kernel
-    if (!out_f32 && ((N % 256) == 0 || ((N % 128) == 0 && N >= 384)) && (K % BK64) == 0 && K >= 2 * BK64 && ((long)((M + 255) / 256) * ((N + 255) / 256) >= 256 || g_force_small_tile == 2) && g_force_small_tile != 1) {
+    if (!out_f32 && ((N % 256) == 0 || ((N % 128) == 0 && N >= 384)) && (K % BK64) == 0 && K >= 2 * BK64 && ((long)((M + 255) / 256) * ((N + 255) / 256) >= 160 || g_force_small_tile == 2) && g_force_small_tile != 1) {
         static int n_cu = 0;
         if (!n_cu) {
             int dev = 0;
