@@ -138,6 +138,17 @@ int svla_attn_bwd_bf16(const svla_bf16* Q, const svla_bf16* K, const svla_bf16* 
  * instead of the single-pass kernel (8 slices) on the unmasked exact-tile shapes. */
 int svla_attn_bwd_two_pass(int on);
 
+/* ---- recorded launch sequences --------------------------------------------------------------------------------------------------
+ * The single-step acting forward (the reference's rollout collection calls DinoLLAMATxNavActorCritic.forward once per env step,
+ * allenact_dino_transformer.py:326-475) and small minibatches are ~100 small dependent kernels per tower: bound by the issue of the
+ * launches, not by the kernels.  svla_replay_calls re-issues a recorded sequence of calls to the entry points of THIS header from one
+ * C loop (one FFI crossing per sequence instead of one per launch): call i is entry point fn_ids[i] (index in declaration order of
+ * this header, this function excluded) with its arguments args[arg_offsets[i] ...] as 64-bit words in declaration order -- pointers and
+ * integers by value, float / double by bit pattern.  The dispatcher is generated from this header at build time
+ * (safevla_amd/build.py), so the header stays the single source of truth.  Returns 0, or the first non-zero status with
+ * *failed_at = the index of the failing call. */
+int svla_replay_calls(int n, const int* fn_ids, const int* arg_offsets, const unsigned long long* args, int* failed_at);
+
 /* ---- deterministic gradient accumulation --------------------------------------------------------------------------------------
  * Every weight / bias / LayerNorm / embedding gradient of the backward (torch autograd of the layers cited above, e.g.
  * allenact_dino_transformer.py:545-552, feeding the Adam step of training/online/dinov2_vits_tsfm_base.py:331-334) is accumulated across

@@ -52,6 +52,9 @@ class _Lib:
 
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.decls = parse_header()
+        # ids of the entry points in svla_replay_calls: declaration order of the header, the replay entry itself excluded (build.py generates
+        # the dispatcher from the same header in the same order)
+        self.fn_ids = {n: i for i, n in enumerate(k for k in self.decls if k != "svla_replay_calls")}
         for name, args in self.decls.items():
             fn = getattr(self.cdll, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = ctypes.c_int

@@ -1,6 +1,7 @@
 """Stream-aware Python bindings of the C-ABI kernels (include/svla.h).  torch is plumbing only: device memory
 and the current HIP stream.  Every function launches on ``torch.cuda.current_stream()`` and raises on failure."""
 import ctypes
+import struct
 from typing import Optional, Tuple
 
 import torch
@@ -37,7 +38,45 @@ class LaunchPlan:
         _REC = None
         lib().recorder = None
 
+    def compile(self):
+        """Flatten the recorded calls for svla_replay_calls (include/svla.h): one FFI crossing per replay instead of one per launch.
+        Arguments become 64-bit words -- pointers / integers by value, float / double by bit pattern, per the header's declaration."""
+        L = lib()
+        ids, offs, words = [], [], []
+        for fn, a in self.calls:
+            name = fn.__name__
+            decl = L.decls[name]
+            assert len(decl) == len(a), name
+            ids.append(L.fn_ids[name])
+            offs.append(len(words))
+            for (_, ct), v in zip(decl, a):
+                if ct is ctypes.c_float:
+                    words.append(struct.unpack("<I", struct.pack("<f", float(v)))[0])
+                elif ct is ctypes.c_double:
+                    words.append(struct.unpack("<Q", struct.pack("<d", float(v)))[0])
+                elif v is None:
+                    words.append(0)
+                elif isinstance(v, ctypes.c_void_p):
+                    words.append(int(v.value or 0))
+                else:
+                    words.append(int(v) & 0xFFFFFFFFFFFFFFFF)
+        self._n = len(ids)
+        self._ids = (ctypes.c_int * max(1, len(ids)))(*ids)
+        self._offs = (ctypes.c_int * max(1, len(offs)))(*offs)
+        self._words = (ctypes.c_ulonglong * max(1, len(words)))(*words)
+        self._failed = ctypes.c_int(-1)
+        self._replay_fn = L.cdll.svla_replay_calls
+        return self
+
     def replay(self):
+        if getattr(self, "_n", None) != len(self.calls):
+            self.compile()
+        rc = self._replay_fn(self._n, self._ids, self._offs, self._words, ctypes.byref(self._failed))
+        if rc != 0:
+            raise RuntimeError(f"replayed {self.calls[self._failed.value][0].__name__} (call {self._failed.value}) failed with status {rc}")
+
+    def replay_python(self):
+        """The same sequence issued call by call from Python (the pre-round-3 path; kept for A/B: tools/replay_probe.py)."""
         for fn, a in self.calls:
             rc = fn(*a)
             if rc != 0:

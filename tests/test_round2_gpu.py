@@ -608,3 +608,28 @@ def test_t5_dropout_per_row_switch(ops):
     _, e1 = text_feats(True, False)                      # eval: the switch is inert (de-duplicated) and features agree
     assert torch.equal(e0, e1)
     m.t5_dropout_per_row = False
+
+
+def test_launch_plan_single_call_replay_equals_call_by_call(ops):
+    """ops.LaunchPlan.replay() re-issues a recorded sequence through ONE foreign call (svla_replay_calls, whose dispatcher is generated
+    from include/svla.h): pointers / ints by value, floats and doubles by bit pattern, NULLs, the dropout descriptor.  Same results as the
+    call-by-call replay and as the recorded execution itself."""
+    torch.manual_seed(3)
+    M, N, K = 300, 512, 256
+    A = torch.randn(M, K, device=DEV).bfloat16(); W = (torch.randn(N, K, device=DEV) * 0.1).bfloat16(); bias = torch.randn(N, device=DEV)
+    res = torch.randn(M, N, device=DEV).bfloat16(); g = torch.rand(N, device=DEV) + 0.5; b = torch.randn(N, device=DEV)
+    y = torch.empty(M, N, device=DEV, dtype=torch.bfloat16); z = torch.empty_like(y)
+    drop = ops.Dropout(seed=11, stream=4, p=0.1)
+    plan = ops.LaunchPlan()
+    with plan:
+        ops.gemm_nt(A, W, M, N, K, bias=bias, residual=res, out=y, alpha=0.37, drop=drop)
+        ops.norm_fwd(y, g, b, 1e-5, M, y=z)
+        ops.dropout_(z, ops.Dropout(seed=5, stream=1, p=0.25))
+    torch.cuda.synchronize()
+    want = z.clone()
+    assert len(plan.calls) == 3
+    for replay in (plan.replay, plan.replay_python, plan.replay):
+        y.zero_(); z.zero_()
+        replay()
+        torch.cuda.synchronize()
+        assert torch.equal(z, want)
