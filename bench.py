@@ -57,7 +57,8 @@ class GemmTimer:
             k2 = key
             if key == "gemm_nt":   # same dispatch rule as svla_gemm_nt_bf16: big row-streaming shapes run the persistent 256x256 kernel
                 M, N, K = a[2], a[3], a[4]
-                if not kw.get("out_f32") and N % 256 == 0 and K % 64 == 0 and K >= 128 and ((M + 255) // 256) * (N // 256) >= 256:
+                if (not kw.get("out_f32") and (N % 256 == 0 or (N % 128 == 0 and N >= 384)) and K % 64 == 0 and K >= 128
+                        and ((M + 255) // 256) * ((N + 255) // 256) >= 160):
                     k2 = "gemm_nt256"
             self.rec[k2].append((e0, e1, flops(*a, **kw)))
             return out
