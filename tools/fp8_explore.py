@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""fp8 attention kernels vs exact fp32 attention and vs the bf16 kernels on the same inputs: relative Frobenius errors and cosines of O, dQ, dK, dV
+(the numbers quoted in DESIGN.md section 5 and in tests/test_fp8_attention_gpu.py)."""
 import sys; sys.path.insert(0, "/root/repo")
 import torch
 from safevla_amd import ops
