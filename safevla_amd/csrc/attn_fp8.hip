@@ -49,6 +49,21 @@ __device__ __forceinline__ bool att_keep1_8(const DropCfg& c, unsigned long long
     return ((e & 1) ? (x >> 16) : (x & 0xffffu)) >= c.thr;
 }
 
+// Incremental dropout hash (the bf16 kernels' scheme, attn.hip): the element-pair index P = P0 + q*(S4/2) + (key >> 1) is linear in (query, key),
+// so lo(P) * C1 = lane constant + wave-uniform term; hi(P) is constant unless lo(P0) is within 2^16 of wrapping (then: the generic hash).
+struct F8Drop { unsigned a0, hb; bool wrap; unsigned long long p0; };
+__device__ __forceinline__ F8Drop f8_drop_head(const DropCfg& c, int S, int H, int r, int h) {
+    F8Drop d;
+    d.p0 = att_drop_row8(S, H, r, h, 0) >> 1;
+    d.a0 = (unsigned)d.p0 * 0x9E3779B1u;
+    d.hb = ((unsigned)(d.p0 >> 32) * 0x85EBCA77u) ^ c.key;
+    d.wrap = (unsigned)d.p0 > 0xFFFF0000u;
+    return d;
+}
+__device__ __forceinline__ unsigned f8_keep_bits(unsigned r0, unsigned r1, unsigned thr) {      // 4 consecutive elements = the halves of two words
+    return ((r0 & 0xffffu) >= thr ? 1u : 0u) | ((r0 >> 16) >= thr ? 2u : 0u) | ((r1 & 0xffffu) >= thr ? 4u : 0u) | ((r1 >> 16) >= thr ? 8u : 0u);
+}
+
 __device__ __forceinline__ f32x4 mfma_ff(long a, long b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma_bf(long a, long b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma_fb(long a, long b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(a, b, c, 0, 0, 0); }
@@ -211,6 +226,9 @@ __global__ void __launch_bounds__(F8_THREADS, 2) attn_fp8_fwd_kernel(Fp8Args p) 
     const F8Row kr = f8_row_off(lane);
     const int vt_off = ql * (SP + 16) + 8 * g;
     const float dsc = DROP ? p.drop.scale : 1.f;
+    const int hS = ((S + 3) & ~3) >> 1;
+    F8Drop dh{};
+    if (DROP) dh = f8_drop_head(p.drop, S, p.H, r, h);
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
         const int qt = wid + 4 * t, q = qt * 16 + ql;
@@ -242,13 +260,19 @@ __global__ void __launch_bounds__(F8_THREADS, 2) attn_fp8_fwd_kernel(Fp8Args p) 
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
             const unsigned long long drow = DROP ? att_drop_row8(S, p.H, r, h, qok ? q : 0) : 0ull;
+            const unsigned al_q = DROP ? dh.a0 + (unsigned)((qok ? q : 0) * hS + 2 * g) * 0x9E3779B1u : 0u;      // lane part: query row + first key pair of its 4 keys
 #pragma unroll
             for (int u = 0; u < NKT / 2; ++u) {
                 float pv[8];
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {
                     unsigned keep = 0xfu;
-                    if (DROP) keep = drop_keep4(p.drop, drow + (2 * u + e2) * 16 + 4 * g);
+                    if (DROP) {
+                        if (!dh.wrap) {
+                            const unsigned ub = (unsigned)((2 * u + e2) * 8) * 0x9E3779B1u;       // compile-time
+                            keep = f8_keep_bits(drop_mix((al_q + ub) ^ dh.hb), drop_mix((al_q + ub + 0x9E3779B1u) ^ dh.hb), p.drop.thr);
+                        } else keep = drop_keep4(p.drop, drow + (2 * u + e2) * 16 + 4 * g);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) pv[e2 * 4 + e] = ((keep >> e) & 1u) ? s[2 * u + e2][e] * (P_SCALE * dsc) : 0.f;
                 }
@@ -312,7 +336,15 @@ __global__ void __launch_bounds__(F8_THREADS, 2) attn_fp8_bwd_kernel(Fp8Args p) 
     const int tr_off = ql * (SP + 16) + 8 * g;
     const f32x4 c14 = {c1, c1, c1, c1};
     const unsigned long long drow0 = DROP ? att_drop_row8(S, p.H, r, h, 0) : 0ull;
-    const int S4 = (S + 3) & ~3;
+    const int S4 = (S + 3) & ~3, hS = S4 >> 1;
+    F8Drop dh{};
+    if (DROP) dh = f8_drop_head(p.drop, S, p.H, r, h);
+    const unsigned thr = p.drop.thr;
+    // phase A layout: a lane holds 4 consecutive QUERIES (4g + e) of one key; the lanes ql, ql ^ 1 share their RNG words (keys 2k, 2k+1 of a query):
+    // the even lane hashes queries e = 0,1, the odd lane e = 2,3, and they swap the halves they need (DPP quad_perm [1,0,3,2])
+    const int odd = ql & 1;
+    const unsigned al_a = dh.a0 + (unsigned)((4 * g + 2 * odd) * hS + (ql >> 1)) * 0x9E3779B1u;
+    const unsigned hSC = (unsigned)hS * 0x9E3779B1u;
     // ---- phase A
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
@@ -336,14 +368,29 @@ __global__ void __launch_bounds__(F8_THREADS, 2) attn_fp8_bwd_kernel(Fp8Args p) 
                     // element e: query (2w+e2)*16 + 4g + e, key keyl
                     const f32x4 nl4 = *(const f32x4*)(nl_s + (2 * w + e2) * 16 + 4 * g), nd4 = *(const f32x4*)(nd_s + (2 * w + e2) * 16 + 4 * g);
                     const f32x4 x = __builtin_elementwise_fma(sc_, c14, nl4);
+                    unsigned keep = 0xfu;
+                    if (DROP) {
+                        if (!dh.wrap) {
+                            const unsigned ua = (unsigned)((2 * w + e2) * 16 * hS + kt * 8) * 0x9E3779B1u;     // wave-uniform
+                            const unsigned x0 = drop_mix((al_a + ua) ^ dh.hb), x1 = drop_mix((al_a + ua + hSC) ^ dh.hb);
+                            const unsigned mine = odd ? ((x0 >> 16) | (x1 & 0xffff0000u)) : ((x0 & 0xffffu) | (x1 << 16));
+                            const unsigned give = odd ? ((x0 & 0xffffu) | (x1 << 16)) : ((x0 >> 16) | (x1 & 0xffff0000u));
+                            const unsigned got = (unsigned)__builtin_amdgcn_mov_dpp((int)give, 0xB1, 0xf, 0xf, true);
+                            const unsigned q01 = odd ? got : mine, q23 = odd ? mine : got;
+                            keep = f8_keep_bits(q01, q23, thr);
+                        } else {
+                            keep = 0;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int q = (2 * w + e2) * 16 + 4 * g + e;
+                                keep |= att_keep1_8(p.drop, drow0 + (unsigned)((q < S ? q : 0) * S4 + keyl)) ? (1u << e) : 0u;
+                            }
+                        }
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float pr = __builtin_amdgcn_exp2f(x[e]);
-                        bool kp = true;
-                        if (DROP) {
-                            const int q = (2 * w + e2) * 16 + 4 * g + e;
-                            kp = att_keep1_8(p.drop, drow0 + (unsigned)((q < S ? q : 0) * S4 + keyl));
-                        }
+                        const bool kp = (keep >> e) & 1u;
                         const float tt = kp ? dp[e] * dsc + nd4[e] : nd4[e];
                         pv[e2 * 4 + e] = kp ? pr * (P_SCALE * dsc) : 0.f;
                         dsv[e2 * 4 + e] = fminf(fmaxf(pr * tt * DS_SHIFT, -49152.f), 49152.f);
@@ -396,6 +443,7 @@ __global__ void __launch_bounds__(F8_THREADS, 2) attn_fp8_bwd_kernel(Fp8Args p) 
             const f32x4 nl4 = {lq[t], lq[t], lq[t], lq[t]};
             const float nd = dq_[t];
             const unsigned long long drow = DROP ? drow0 + (unsigned long long)(qok ? q : 0) * S4 : 0ull;
+            const unsigned al_b = DROP ? dh.a0 + (unsigned)((qok ? q : 0) * hS + 2 * g) * 0x9E3779B1u : 0u;
             f32x4 dq[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -412,7 +460,12 @@ __global__ void __launch_bounds__(F8_THREADS, 2) attn_fp8_bwd_kernel(Fp8Args p) 
                     dp = mfma_fb(LDS8(A1, rr.hi + ko), gf[t][1], dp);
                     const f32x4 x = __builtin_elementwise_fma(sc_, c14, nl4);
                     unsigned keep = 0xfu;
-                    if (DROP) keep = drop_keep4(p.drop, drow + (2 * u + e2) * 16 + 4 * g);
+                    if (DROP) {
+                        if (!dh.wrap) {
+                            const unsigned ub = (unsigned)((2 * u + e2) * 8) * 0x9E3779B1u;
+                            keep = f8_keep_bits(drop_mix((al_b + ub) ^ dh.hb), drop_mix((al_b + ub + 0x9E3779B1u) ^ dh.hb), thr);
+                        } else keep = drop_keep4(p.drop, drow + (2 * u + e2) * 16 + 4 * g);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float pr = __builtin_amdgcn_exp2f(x[e]);
