@@ -1,0 +1,583 @@
+"""Generator of the A-stationary NT GEMM kernels for gfx950 (C[M,N] = epi(A[M,512] . W[N,512]^T), M % 256 == 0, N % 128 == 0).
+
+Replaces, for the K = 512 linears of the fusion encoder (reference: nn.TransformerEncoder layers of
+architecture/models/allenact_transformer_models/allenact_dino_transformer.py:545-552,702-708 -- in_proj, out_proj, linear1, and the
+input-gradient GEMM through linear2), the 256x256-tile kernel of csrc/gemm.hip.  Structure:
+
+  * one workgroup of FOUR waves per CU (one wave per SIMD, 256 arch VGPRs + 256 AGPRs each), persistent over 256-row panels of A;
+  * wave w keeps ITS 64 rows x 512 k of A in the 256 AGPRs for the whole sweep over N (MFMA B operands read straight from the
+    accumulator file): A is fetched from HBM exactly once and never touches LDS;
+  * W streams L2 -> LDS by LDS-DMA, one 64-column x 512-k tile (64 KiB, rows XOR-swizzled on the DMA source address) per "n-step",
+    two buffers, ONE workgroup barrier per n-step (4096 MFMA cycles);
+  * per n-step a wave issues 128 v_mfma_f32_32x32x16_bf16 (2 n-blocks x 2 m-blocks x 32 k-steps) against 64 ds_read_b128: 0.5 LDS
+    fragment reads per MFMA;
+  * TWO accumulator sets (2 x 64 VGPRs): while n-step j accumulates into one, the epilogue of n-step j-1 (bias is the accumulator's
+    initial value, activation / dropout / mask / residual, bf16 rounding, transposition through a wave-private 4-KiB LDS buffer, eight
+    full-line stores) is interleaved, instruction by instruction, into the gaps between the MFMAs of step j -- the C stores leave the CU
+    as a continuous trickle instead of a burst at the end of a 256x256 tile;
+  * every s_waitcnt is counted by this generator from a model of the in-order VM / LGKM queues; amdasm.Emu checks the result.
+
+The instruction stream is emitted by a list scheduler: each MFMA is followed by up to CAP "filler" instructions taken from fixed slots
+(W fragment reads) and from ordered streams (LDS-DMA of the next W tile, epilogue of the previous step, panel switch).
+"""
+from .amdasm import EXEC, M0, Prog, Reg, a, s, v
+
+KS = 32                    # k-steps of 16 (K = 512)
+LDS_W = (0, 65536)
+LDS_STG = 131072           # + wave * 4096
+LDS_BIAS = 147456          # fp32 bias[N], N <= 4096 (the bias table doubles as the accumulator initialiser)
+LDS_BYTES = 163840
+
+# ---- kernel arguments (byte offsets in the kernarg segment)
+KARG = dict(A=0, lda=8, B=16, ldb=24, bias=32, res=40, ldr=48, C=56, ldc=64, M=72, N=76, alpha=80, npanels=84, bits=88,
+            key=96, thr=100, scale=104, row_mult=108, seed_dev=112, stream_key=120, grid=124)
+KARG_BYTES = 128
+
+# ---- SGPRs
+S_A, S_LDA, S_B, S_LDB, S_BIAS, S_RES, S_LDR, S_C = s(4, 2), s(6, 2), s(8, 2), s(10, 2), s(12, 2), s(14, 2), s(16, 2), s(18, 2)
+S_LDC, S_M, S_N, S_ALPHA, S_NPANELS, S_BITS = s(20, 2), s(22), s(23), s(24), s(25), s(26, 2)
+S_KEY, S_THR, S_SCALE, S_ROWMULT, S_SEEDDEV, S_STREAMKEY, S_GRID = s(28), s(29), s(30), s(31), s(32, 2), s(34), s(35)
+S_WID = s(36)
+S_LDA2, S_LDC2, S_LDR2 = s(37), s(38), s(39)
+SRD_X, SRD_C, SRD_R, SRD_T = s(40, 4), s(48, 4), s(52, 4), s(56, 4)
+S_P, S_PN = s(60), s(61)             # panel being accumulated; panel whose A is being fetched
+S_LOOP = s(62)
+S_WBASE_HI, S_LDB2, S_LDB2X48, S_WBASE = s(63), s(64), s(65), s(66)      # S_WBASE(_HI): B + w * 16 * ldb2
+S_WPTR = s(90, 2)                     # address of the next W row this wave fetches
+S_M0BASE = s(67)
+S_NE2 = s(68)                         # 2 * n0 of the step whose epilogue is running
+S_N0 = s(69)                          # n0 of the step being accumulated
+S_CROW = [s(70 + i) for i in range(8)]   # store row offsets (w*64 + mb*32 + 8 it) * ldc2
+S_XROW = s(78)                        # w * 64 * lda2
+S_NB4 = s(79)                         # 4 * n0 of the next step (bias table offset)
+S_STMASK = s(80, 2)                   # exec mask of the epilogue stores (0 until the first n-step of the launch has been computed)
+S_T = [s(82 + i) for i in range(8)]   # scratch
+S_RROW = [s(92 + i) for i in range(8)]   # residual row offsets (w*64 + mb*32 + 8 it) * ldr2
+N_SGPR = 100
+
+# ---- VGPRs
+def ACC(st, nb, mb):
+    return v(st * 64 + (nb * 2 + mb) * 16, 16)
+
+
+def BIASR(nb):
+    return v(128 + nb * 16, 16)
+
+
+def WFRAG(ks, nb):
+    return v(160 + ((ks % 4) * 2 + nb) * 4, 4)
+
+
+V_WRD = [v(192 + j) for j in range(8)]
+V_LANE16, V_DMATMP = v(200), v(201)
+V_COFF, V_CSTEP, V_STW, V_STRD, V_BIASRD, V_BIASSTEP = v(202), v(203), v(204), v(205), v(206), v(207)
+V_XOFF = [v(208), v(209)]
+V_STWX = v(210)                       # staging write address of the current 8-byte piece
+V_PK = [v(212 + 2 * i, 2) for i in range(8)]       # converted pieces
+V_RB = [v(228 + 4 * i, 4) for i in range(4)]       # read-back (row-major) pieces = store data
+V_TMP = [v(244 + i) for i in range(12)]
+
+
+def XFRAG(mb, ks):
+    return a((mb * KS + ks) * 4, 4)
+
+
+class QModel:
+    """In-order completion queue (VM or LGKM) as the generator sees it: tags of the operations issued and not yet known retired."""
+
+    def __init__(self, maxcnt):
+        self.q = []
+        self.maxcnt = maxcnt
+
+    def issue(self, tag):
+        self.q.append(tag)
+
+    def need(self, tags):
+        """largest count n such that waiting for 'at most n outstanding' retires every tag in tags; None if none of them is in the queue"""
+        idx = [i for i, t in enumerate(self.q) if t in tags]
+        if not idx:
+            return None
+        return min(len(self.q) - 1 - max(idx), self.maxcnt)
+
+    def wait(self, n):
+        self.q = self.q[len(self.q) - n:] if n > 0 else []
+
+
+class NtAsGen:
+    CAP = 3            # fillers per MFMA gap taken from the streams (fixed-slot instructions come on top)
+
+    def __init__(self, name="svla_nt_as_f0", act=0, aux=0, drop=False, bits_out=False, alpha=False, cap=None):
+        self.name = name
+        self.act, self.aux, self.drop, self.bits_out, self.alpha = act, aux, drop, bits_out, alpha
+        if cap is not None:
+            self.CAP = cap
+        self.p = Prog(name)
+        self.vm = QModel(63)
+        self.lg = QModel(15)
+        self.uid = 0
+        self.stats = {}
+
+    # ------------------------------------------------------------------ helpers
+    def tag(self, base):
+        self.uid += 1
+        return f"{base}#{self.uid}"
+
+    def wait_for(self, vm_tags=(), lg_tags=()):
+        nv = self.vm.need(set(vm_tags)) if vm_tags else None
+        nl = self.lg.need(set(lg_tags)) if lg_tags else None
+        if nv is None and nl is None:
+            return
+        self.p.s_waitcnt(vmcnt=nv, lgkmcnt=nl)
+        if nv is not None:
+            self.vm.wait(nv)
+        if nl is not None:
+            self.lg.wait(nl)
+
+    def lg_room(self):
+        # the LGKM counter has 4 bits: never let the model's queue pass 15 (LDS operations retire in order within ~100 cycles, so in
+        # steady state this wait finds its operations long retired)
+        if len(self.lg.q) >= 15:
+            self.p.s_waitcnt(lgkmcnt=11)
+            self.lg.wait(11)
+
+    def ds_read(self, d, addr, off, tag):
+        self.lg_room()
+        self.p.ds_read(d, addr, off)
+        self.lg.issue(tag)
+
+    def ds_write(self, addr, src, off=0):
+        self.lg_room()
+        self.p.ds_write(addr, src, off)
+        self.lg.issue(self.tag("dsw"))
+
+    # ------------------------------------------------------------------ prologue
+    def prologue(self):
+        p = self.p
+        T = V_TMP
+        p.s_load(s(4, 16), s(0, 2), 0)
+        p.s_load(s(20, 16), s(0, 2), 64)
+        p.v_and_b32(T[0], 63, v(0))                 # lane
+        p.v_lshrrev_b32(T[1], 6, v(0))              # wave
+        p.v_readfirstlane_b32(S_WID, T[1])
+        p.v_and_b32(T[2], 31, T[0])                 # c = lane & 31
+        p.v_lshrrev_b32(T[3], 5, T[0])              # h = lane >> 5
+        p.s_waitcnt(lgkmcnt=0)
+        p.s_mov_b64(S_STMASK, 0)
+        p.s_lshl_b32(S_LDA2, S_LDA.sub(0), 1)
+        p.s_lshl_b32(S_LDC2, S_LDC.sub(0), 1)
+        p.s_lshl_b32(S_LDR2, S_LDR.sub(0), 1)
+        p.s_lshl_b32(S_LDB2, S_LDB.sub(0), 1)
+        p.s_mul_i32(S_LDB2X48, S_LDB2, 48)
+        p.s_lshl_b32(S_T[0], S_WID, 4)
+        p.s_mul_i32(S_T[1], S_T[0], S_LDB2)         # w * 16 * ldb2 (< 2^32: N <= 4096 rows)
+        p.s_add_u32(S_WBASE, S_B.sub(0), S_T[1])
+        p.s_addc_u32(S_WBASE_HI, S_B.sub(1), 0)
+        p.s_lshl_b32(S_M0BASE, S_WID, 14)           # w * 16 KiB
+        p.s_lshl_b32(S_T[0], S_WID, 6)
+        p.s_mul_i32(S_XROW, S_T[0], S_LDA2)         # w * 64 * lda2
+        for mb in range(2):
+            for it in range(4):
+                p.s_add_u32(S_T[1], S_T[0], mb * 32 + 8 * it)
+                p.s_mul_i32(S_CROW[mb * 4 + it], S_T[1], S_LDC2)
+                p.s_mul_i32(S_RROW[mb * 4 + it], S_T[1], S_LDR2)
+        # descriptors: W whole; X / C / R per panel
+        for srd, base in ((SRD_T, S_BIAS),):
+            p.s_mov_b32(srd.sub(0), base.sub(0))
+            p.s_and_b32(srd.sub(1), base.sub(1), 0xffff)
+            p.s_mov_b32(srd.sub(2), 0xffffffff)
+            p.s_mov_b32(srd.sub(3), 0x00020000)
+        for srd in (SRD_X, SRD_C, SRD_R):
+            p.s_mov_b32(srd.sub(2), 0xffffffff)
+            p.s_mov_b32(srd.sub(3), 0x00020000)
+        # ---- lane constants
+        # fragment read addresses: row c (1 KiB pitch), logical 16-byte chunk 2 j + h, physical chunk = logical ^ (c & 15)
+        p.v_and_b32(T[4], 15, T[2])
+        p.v_lshlrev_b32(T[5], 10, T[2])             # c * 1024
+        for j in range(8):
+            p.v_add_u32(T[6], 2 * j, T[3])
+            p.v_xor_b32(T[6], T[6], T[4])
+            p.v_lshl_add_u32(V_WRD[j], T[6], 4, T[5])
+        p.v_lshlrev_b32(V_LANE16, 4, T[0])
+        # C store: lane -> (row lane >> 3, 16-byte chunk lane & 7)
+        p.v_lshrrev_b32(T[6], 3, T[0])              # lane >> 3
+        p.v_and_b32(T[7], 7, T[0])                  # lane & 7
+        p.v_mul_lo_u32(T[8], T[6], S_LDC2)
+        p.v_lshl_add_u32(V_COFF, T[7], 4, T[8])
+        # staging (wave-private 4 KiB at LDS_STG + w * 4096): [32 rows][128 B], 16-byte chunk q of row r stored at chunk q ^ (r & 7)
+        p.s_lshl_b32(S_T[2], S_WID, 12)
+        p.s_add_u32(S_T[2], S_T[2], LDS_STG)
+        p.v_and_b32(T[8], 7, T[2])                  # c & 7
+        p.v_lshlrev_b32(T[9], 7, T[2])              # c * 128
+        p.v_lshl_add_u32(T[9], T[8], 4, T[9])
+        p.v_lshl_add_u32(T[9], T[3], 3, T[9])       # + h * 8
+        p.v_add_u32(V_STW, S_T[2], T[9])
+        p.v_xor_b32(T[8], T[7], T[6])               # (lane & 7) ^ (lane >> 3)
+        p.v_lshlrev_b32(T[9], 7, T[6])
+        p.v_lshl_add_u32(T[9], T[8], 4, T[9])
+        p.v_add_u32(V_STRD, S_T[2], T[9])
+        p.v_lshlrev_b32(T[9], 4, T[3])
+        p.v_add_u32(V_BIASRD, LDS_BIAS, T[9])       # + h * 16
+        # A fragment loads: row (mb * 32 + c) of the wave's 64, 16 bytes at k = 16 ks + 8 h
+        for mb in range(2):
+            p.v_add_u32(T[8], mb * 32, T[2])
+            p.v_mul_lo_u32(T[8], T[8], S_LDA2)
+            p.v_lshl_add_u32(V_XOFF[mb], T[3], 4, T[8])
+        # ---- bias table -> LDS (N % 256 == 0; the host always passes a bias pointer: zeros when the GEMM has none)
+        p.v_lshlrev_b32(T[8], 2, v(0))
+        p.v_add_u32(T[9], LDS_BIAS, T[8])
+        p.s_mov_b32(S_T[3], 0)
+        p.s_lshl_b32(S_T[4], S_N, 2)
+        p.s_mov_b32(SRD_T.sub(2), S_T[4])           # num_records = 4 N: reads past bias[N) return 0
+        p.label("L_BIAS")
+        p.buffer_load(T[10], T[8], SRD_T, S_T[3])
+        p.s_waitcnt(vmcnt=0)
+        p.ds_write(T[9], T[10])
+        p.v_add_u32(T[9], 1024, T[9])
+        p.s_add_u32(S_T[3], S_T[3], 1024)
+        p.s_cmp("lt_u32", S_T[3], S_T[4])
+        p.s_cbranch_scc1("L_BIAS")
+        # ---- first panel
+        p.s_mov_b32(S_P, s(2))
+        p.s_mov_b32(S_PN, s(2))
+        self.set_panel_srd(SRD_X, S_A, S_PN, S_LDA2)
+        self.set_panel_srd(SRD_C, S_C, S_P, S_LDC2)
+        if self.aux == 1:
+            self.set_panel_srd(SRD_R, S_RES, S_P, S_LDR2)
+        for ks in range(KS):
+            for mb in range(2):
+                p.buffer_load(XFRAG(mb, ks), V_XOFF[mb], SRD_X, S_XROW, ks * 32)
+            if ks == 23:
+                p.s_waitcnt(vmcnt=0)
+        # W tile 0 -> buffer 0
+        p.s_mov_b32(S_WPTR.sub(0), S_WBASE)
+        p.s_mov_b32(S_WPTR.sub(1), S_WBASE_HI)
+        for t in range(16):
+            self.dma_piece(t, 0, first=(t == 0))
+        p.s_mov_b32(S_N0, 0)
+        p.s_waitcnt(vmcnt=0, lgkmcnt=0)
+        self.vm.wait(0)
+        self.lg.wait(0)
+        p.s_barrier()
+        p.v_mov_b32(V_BIASSTEP, V_BIASRD)
+        for nb in range(2):
+            for rg in range(4):
+                p.ds_read(BIASR(nb).sub(4 * rg, 4), V_BIASSTEP, nb * 128 + rg * 32)
+        for ks in range(3):
+            for nb in range(2):
+                self.wread(ks, nb, 0)
+        p.s_branch("L_FIRST")
+
+    def set_panel_srd(self, srd, base, panel, ld2):
+        """srd.base = base + panel * 256 * ld2 (64-bit)"""
+        p = self.p
+        p.s_lshl_b32(S_T[5], panel, 8)
+        p.s_mul_hi_u32(S_T[6], S_T[5], ld2)
+        p.s_mul_i32(S_T[5], S_T[5], ld2)
+        p.s_add_u32(srd.sub(0), base.sub(0), S_T[5])
+        p.s_addc_u32(S_T[6], base.sub(1), S_T[6])
+        p.s_and_b32(srd.sub(1), S_T[6], 0xffff)
+
+    def dma_piece(self, t, buf, first):
+        """one LDS-DMA instruction: row (w*16 + t) of the W tile whose first row's byte offset is in S_WOFF-progress, into LDS buffer buf"""
+        for th in self.dma_thunks(t, buf, first):
+            th()
+
+    def dma_thunks(self, t, buf, first):
+        p = self.p
+        out = []
+        if first:
+            if buf == 0:
+                out.append(lambda: p.s_mov_b32(M0, S_M0BASE))
+            else:
+                out.append(lambda: p.s_add_u32(M0, S_M0BASE, LDS_W[1]))
+        else:
+            out.append(lambda: p.s_add_u32(M0, M0, 1024))
+        # row & 15 == t (w*16 + t): lane i lands at physical chunk i, so it fetches logical chunk i ^ t
+        out.append(lambda: p.v_xor_b32(V_DMATMP, t << 4, V_LANE16))
+
+        def ld():
+            p.global_load_lds_x4(V_DMATMP, S_WPTR)
+            self.vm.issue(f"dma{t}")
+        out.append(ld)
+        out.append(lambda: p.s_add_u32(S_WPTR.sub(0), S_WPTR.sub(0), S_LDB2))
+        out.append(lambda: p.s_addc_u32(S_WPTR.sub(1), S_WPTR.sub(1), 0))
+        return out
+
+    def wread(self, ks, nb, buf):
+        j = ks % 8
+        self.ds_read(WFRAG(ks, nb), V_WRD[j], nb * 32768 + (ks // 8) * 256, f"w{ks}_{nb}")
+
+    # ------------------------------------------------------------------ epilogue of one n-step (previous step's accumulators)
+    def epi_stream(self, st, masked, earliest):
+        """list of (earliest_gap, thunk): the epilogue of accumulator set st, stores optionally under S_STMASK"""
+        p = self.p
+        items = []
+
+        def add(th, e=earliest):
+            items.append((e, th))
+        add(lambda: p.v_add_u32(V_CSTEP, S_NE2, V_COFF))
+        for mb in range(2):
+            for nb in range(2):
+                for rg in range(4):
+                    gi = nb * 4 + rg
+                    acc = ACC(st, nb, mb)
+                    pk = V_PK[gi]
+                    add(lambda acc=acc, pk=pk, rg=rg: p.v_cvt_pk_bf16_f32(pk.sub(0), acc.sub(4 * rg), acc.sub(4 * rg + 1)))
+                    add(lambda acc=acc, pk=pk, rg=rg: p.v_cvt_pk_bf16_f32(pk.sub(1), acc.sub(4 * rg + 2), acc.sub(4 * rg + 3)))
+                    add(lambda gi=gi: p.v_xor_b32(V_STWX, gi << 4, V_STW))
+                    add(lambda pk=pk: self.ds_write(V_STWX, pk))
+            tags = []
+            for it in range(4):
+                tg = self.tag(f"rb{mb}_{it}")
+                tags.append(tg)
+                add(lambda it=it, tg=tg: self.ds_read(V_RB[it], V_STRD, it * 1024, tg))
+            for it in range(4):
+                def st_(it=it, mb=mb, tags=tags):
+                    self.wait_for(lg_tags=[tags[it]])
+                    if masked:
+                        p.s_mov_b64(EXEC, S_STMASK)
+                    p.buffer_store(V_RB[it], V_CSTEP, SRD_C, S_CROW[mb * 4 + it])
+                    self.vm.issue(self.tag("st"))
+                    if masked:
+                        p.s_mov_b64(EXEC, -1)
+                add(st_)
+        return items
+
+    # ------------------------------------------------------------------ one n-step body
+    def body(self, kind, parity):
+        """kind: 'first' | 'mid' | 'last'; parity: LDS buffer holding this step's W tile = accumulator set of this step"""
+        p = self.p
+        st = parity
+        buf, nbuf = parity, parity ^ 1
+        NG = 4 * KS
+        fixed = [[] for _ in range(NG)]
+        pre = [[] for _ in range(NG)]
+        streams = []
+
+        # ---- W fragment reads, ring of 4 k-steps: (ks + 3, nb) right after the MFMA (ks, nb, mb = 0) -- its ring slot was last read by the
+        # MFMAs of k-step ks - 1.  The first three k-steps of the NEXT tile are read behind the barrier, at gaps 120 .. 125.
+        BAR_GAP = 119
+        for ks in range(KS - 3):
+            for nb in range(2):
+                fixed[4 * ks + 2 * nb + 1].append(lambda k3=ks + 3, nb=nb: self.wread(k3, nb, buf))
+        for k in range(3):
+            for nb in range(2):
+                fixed[BAR_GAP + 1 + 2 * k + nb].append(lambda k=k, nb=nb: self.wread(k, nb, nbuf))
+        # toggle the read addresses to the other buffer after their last use for this tile (chunk class j: last k-step 24 + j, read at gaps 4 (21 + j) + 1 / + 3)
+        for j in range(8):
+            fixed[4 * (21 + j) + 3].append(lambda j=j: p.v_xor_b32(V_WRD[j], 0x10000, V_WRD[j]))
+
+        # ---- barrier: every read of this tile issued (last: k-step 31 at gaps 113 / 115) and retired, own DMA pieces of the next tile landed
+        def barrier():
+            nv = self.vm.need({f"dma{t}" for t in range(16)})
+            p.s_waitcnt(vmcnt=nv if nv is not None else 0, lgkmcnt=0)
+            self.vm.wait(nv if nv is not None else 0)
+            self.lg.wait(0)
+            p.s_barrier()
+        fixed[BAR_GAP].insert(0, barrier)
+
+        # ---- scalar bookkeeping at the head of the step, then the LDS-DMA of the next tile
+        dma = []
+        if kind == "last":
+            dma.append((0, lambda: p.s_mov_b32(S_WPTR.sub(0), S_WBASE)))
+            dma.append((0, lambda: p.s_mov_b32(S_WPTR.sub(1), S_WBASE_HI)))
+            dma.append((0, lambda: p.s_mov_b32(S_NB4, 0)))
+        else:
+            dma.append((0, lambda: p.s_add_u32(S_WPTR.sub(0), S_WPTR.sub(0), S_LDB2X48)))
+            dma.append((0, lambda: p.s_addc_u32(S_WPTR.sub(1), S_WPTR.sub(1), 0)))
+            dma.append((0, lambda: p.s_add_u32(S_NB4, S_N0, 64)))
+            dma.append((0, lambda: p.s_lshl_b32(S_NB4, S_NB4, 2)))
+        for t in range(16):
+            for th in self.dma_thunks(t, nbuf, first=(t == 0)):
+                dma.append((1, th))
+        streams.append(dma)
+
+        # ---- panel switch (last step of a panel): the next panel's A fragments replace the ones whose last MFMA has been issued
+        if kind == "last":
+            p.s_add_u32(S_PN, S_P, S_GRID)
+            p.s_sub_u32(S_T[7], S_NPANELS, 1)
+            p.s_min_u32(S_PN, S_PN, S_T[7])          # past the end: re-fetch the last panel (never used)
+            for ins in self.panel_srd_thunks(SRD_X, S_A, S_PN, S_LDA2):
+                ins()
+            for ks in range(KS):
+                for mb in range(2):
+                    def xl(ks=ks, mb=mb):
+                        p.buffer_load(XFRAG(mb, ks), V_XOFF[mb], SRD_X, S_XROW, ks * 32)
+                        self.vm.issue(f"x{ks}")
+                    fixed[4 * ks + 3].append(xl)
+        if kind == "first":
+            for ks in range(KS):
+                pre[4 * ks].append(("vm", f"x{ks}"))
+
+        # ---- epilogue of the previous step, bias registers of the next step, then the bookkeeping that must follow the epilogue
+        epi = self.epi_stream(st ^ 1, masked=(kind == "first"), earliest=8)
+        epi.append((16, lambda: p.v_add_u32(V_BIASSTEP, S_NB4, V_BIASRD)))
+        for nb in range(2):
+            for rg in range(4):
+                epi.append((16, lambda nb=nb, rg=rg: self.ds_read(BIASR(nb).sub(4 * rg, 4), V_BIASSTEP, nb * 128 + rg * 32, self.tag("bias"))))
+        epi.append((16, lambda: p.s_lshl_b32(S_NE2, S_N0, 1)))
+        if kind == "last":
+            epi.append((16, lambda: p.s_mov_b32(S_N0, 0)))
+        else:
+            epi.append((16, lambda: p.s_add_u32(S_N0, S_N0, 64)))
+        if kind == "first":
+            epi.append((16, lambda: p.s_mov_b64(S_STMASK, -1)))
+            for ins in self.panel_srd_thunks(SRD_C, S_C, S_P, S_LDC2):
+                epi.append((16, ins))
+            if self.aux == 1:
+                for ins in self.panel_srd_thunks(SRD_R, S_RES, S_P, S_LDR2):
+                    epi.append((16, ins))
+            epi.append((16, lambda: p.s_lshr_b32(S_LOOP, S_N, 7)))
+            epi.append((16, lambda: p.s_sub_u32(S_LOOP, S_LOOP, 1)))
+        streams.append(epi)
+
+        # ---- emit
+        pos = [0] * len(streams)
+        nfill = 0
+        for g in range(NG):
+            ks, i = divmod(g, 4)
+            nb, mb = divmod(i, 2)
+            lg_tags = [f"w{ks}_{nb}"]
+            vm_tags = [t for (q, t) in pre[g] if q == "vm"]
+            if ks == 0:
+                lg_tags += [t for t in self.lg.q if t.startswith("bias")]
+            self.wait_for(vm_tags=vm_tags, lg_tags=lg_tags)
+            c = BIASR(nb) if ks == 0 else ACC(st, nb, mb)
+            p.v_mfma_f32_32x32x16_bf16(ACC(st, nb, mb), WFRAG(ks, nb), XFRAG(mb, ks), c)
+            for th in fixed[g]:
+                th()
+            n = 0
+            while n < self.CAP and g < BAR_GAP:
+                took = False
+                for si, sm in enumerate(streams):
+                    if n < self.CAP and pos[si] < len(sm) and sm[pos[si]][0] <= g:
+                        sm[pos[si]][1]()
+                        pos[si] += 1
+                        n += 1
+                        nfill += 1
+                        took = True
+                if not took:
+                    break
+            if g == BAR_GAP - 1:
+                # every DMA piece the barrier's vmcnt must cover and every LDS operation of the epilogue has been issued: the LGKM queue a
+                # step starts with is the six fragment reads behind the barrier, whatever step preceded it
+                for si, sm in enumerate(streams):
+                    if pos[si] != len(sm):
+                        raise RuntimeError(f"{self.name} {kind}: stream {si} has {len(sm) - pos[si]} instructions left at the barrier gap: raise CAP")
+        self.stats[(kind, parity)] = nfill
+
+    def panel_srd_thunks(self, srd, base, panel, ld2):
+        p = self.p
+        return [
+            lambda: p.s_lshl_b32(S_T[5], panel, 8),
+            lambda: p.s_mul_hi_u32(S_T[6], S_T[5], ld2),
+            lambda: p.s_mul_i32(S_T[5], S_T[5], ld2),
+            lambda: p.s_add_u32(srd.sub(0), base.sub(0), S_T[5]),
+            lambda: p.s_addc_u32(S_T[6], base.sub(1), S_T[6]),
+            lambda: p.s_and_b32(srd.sub(1), S_T[6], 0xffff),
+        ]
+
+    # ------------------------------------------------------------------ whole kernel
+    def build(self):
+        p = self.p
+        self.prologue()
+        p.label("L_LAST")
+        self.body("last", 1)
+        p.s_add_u32(S_P, S_P, S_GRID)
+        p.s_cmp("ge_u32", S_P, S_NPANELS)
+        p.s_cbranch_scc1("L_DRAIN")
+        p.label("L_FIRST")
+        self.body("first", 0)
+        p.s_cmp("eq_u32", S_LOOP, 0)
+        p.s_cbranch_scc1("L_LAST")
+        p.label("L_MID")
+        self.body("mid", 1)
+        self.body("mid", 0)
+        p.s_sub_u32(S_LOOP, S_LOOP, 1)
+        p.s_cmp("lg_u32", S_LOOP, 0)
+        p.s_cbranch_scc1("L_MID")
+        p.s_branch("L_LAST")
+        p.label("L_DRAIN")
+        # the last step's epilogue (accumulator set 1), nothing to hide it under; the prefetched fragments / DMA of a non-existent next step drain
+        p.s_waitcnt(vmcnt=0, lgkmcnt=0)
+        self.vm.wait(0)
+        self.lg.wait(0)
+        for _, th in self.epi_stream(1, masked=False, earliest=0):
+            th()
+        p.s_waitcnt(vmcnt=0, lgkmcnt=0)
+        p.s_endpgm()
+        return p
+
+    # ------------------------------------------------------------------ assembly text
+    def asm_text(self):
+        body = self.p.text()
+        name = self.name
+        return f"""// GENERATED by safevla_amd/asmgen/nt_as_gen.py -- do not edit.
+\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
+\t.text
+\t.protected {name}
+\t.globl {name}
+\t.p2align 8
+\t.type {name},@function
+{name}:
+{body}
+.L{name}_end:
+\t.size {name}, .L{name}_end-{name}
+
+\t.rodata
+\t.p2align 6
+\t.amdhsa_kernel {name}
+\t\t.amdhsa_group_segment_fixed_size {LDS_BYTES}
+\t\t.amdhsa_private_segment_fixed_size 0
+\t\t.amdhsa_kernarg_size {KARG_BYTES}
+\t\t.amdhsa_user_sgpr_count 2
+\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1
+\t\t.amdhsa_system_sgpr_workgroup_id_x 1
+\t\t.amdhsa_system_sgpr_workgroup_id_y 0
+\t\t.amdhsa_system_sgpr_workgroup_id_z 0
+\t\t.amdhsa_system_vgpr_workitem_id 0
+\t\t.amdhsa_next_free_vgpr 512
+\t\t.amdhsa_next_free_sgpr {N_SGPR}
+\t\t.amdhsa_accum_offset 256
+\t\t.amdhsa_reserve_vcc 1
+\t\t.amdhsa_float_round_mode_32 0
+\t\t.amdhsa_float_round_mode_16_64 0
+\t\t.amdhsa_float_denorm_mode_32 3
+\t\t.amdhsa_float_denorm_mode_16_64 3
+\t\t.amdhsa_dx10_clamp 1
+\t\t.amdhsa_ieee_mode 1
+\t.end_amdhsa_kernel
+
+\t.amdgpu_metadata
+---
+amdhsa.version: [ 1, 2 ]
+amdhsa.target: amdgcn-amd-amdhsa--gfx950
+amdhsa.kernels:
+  - .name: {name}
+    .symbol: {name}.kd
+    .kernarg_segment_size: {KARG_BYTES}
+    .group_segment_fixed_size: {LDS_BYTES}
+    .private_segment_fixed_size: 0
+    .kernarg_segment_align: 8
+    .wavefront_size: 64
+    .sgpr_count: {N_SGPR + 6}
+    .vgpr_count: 512
+    .agpr_count: 256
+    .max_flat_workgroup_size: 256
+    .args:
+      - {{ .size: {KARG_BYTES}, .offset: 0, .value_kind: by_value }}
+...
+\t.end_amdgpu_metadata
+"""
+
+
+# flavour -> generator options (the C dispatcher nt_as_try of csrc/gemm.hip picks by name)
+FLAVOURS = {
+    "f0": dict(),                                  # bias (or none): in_proj forward, out_proj input gradient
+}
+
+
+def generate(flavour="f0"):
+    g = NtAsGen(name=f"svla_nt_as_{flavour}", **FLAVOURS[flavour])
+    g.build()
+    return g

@@ -16,7 +16,9 @@
 // lane-linear) and on the fragment ds_reads (bank-conflict free, measured), counted s_waitcnt vmcnt + raw s_barrier, XCD-aware
 // tile order so the tiles that share an operand panel run on one XCD's L2.
 #include "common.h"
+#include "asm_kernels.h"
 #include <cstdlib>
+#include <cstring>
 
 #define BM 128
 #define BN 128
@@ -48,6 +50,7 @@ struct GemmNtArgs {
     unsigned char* bits_out;          // act == ReLU: also write the output's sign bits (blocked layout, see relu_bits_word)
     const unsigned char* bits_in;     // ReLU mask given as such bits instead of a bf16 activation tensor (relu_mask)
     DropCfg drop;                     // train-mode dropout after the activation, before the residual add (thr == 0: off)
+    int row0;         // global row index of A's row 0 (dropout counter / sign-bit block of the M-tail sub-problem behind the assembly kernels); 128-tile kernel only
     int dbg;          // timing-only ablations of the 256-tile kernel (tools/ab_gemm.py, tools/shape_gemm.py): 1 = no C stores,
                       // 2 = no epilogue, 64 = no fragment reads / MFMAs (operand DMA stream + barriers alone)
 };
@@ -257,7 +260,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p)
         u32x4 w;
         unsigned obits = 0, dkeep = 0;
         if (p.drop.thr) {
-            const unsigned long long e0 = (unsigned long long)m * p.drop.row_mult * p.N + n0 + ecc * 8;
+            const unsigned long long e0 = (unsigned long long)(m + p.row0) * p.drop.row_mult * p.N + n0 + ecc * 8;
             dkeep = drop_keep4(p.drop, e0) | (drop_keep4(p.drop, e0 + 4) << 4);
         }
 #pragma unroll
@@ -951,6 +954,64 @@ extern "C" int svla_gemm_force_small_tile(int on) {
     return SVLA_OK;
 }
 
+// ---- A-stationary assembly kernels (asmgen/nt_as_gen.py): K = 512, bf16 output, full 256-row panels; the M % 256 tail rows run as a
+// sub-problem on the 128-tile kernel (row0 keeps its dropout counters / sign-bit blocks on the global row index).
+#define NT_AS_NOT_TAKEN (-12345)
+struct NtAsKarg {      // = asmgen/nt_as_gen.py KARG
+    const void* A; long lda; const void* B; long ldb; const float* bias; const void* res; long ldr; void* C; long ldc;
+    int M, N; float alpha; int npanels; const void* bits; unsigned key, thr; float scale; int row_mult; const unsigned* seed_dev; unsigned stream_key; int grid;
+};
+static_assert(sizeof(NtAsKarg) == 128, "kernarg layout of the nt_as kernels");
+static int nt_as_try(const GemmNtArgs& p, hipStream_t stream) {
+    if (p.K != 512 || p.out_f32 || (p.N % 128) || p.N > 4096 || p.N < 128 || (p.dbg & 8192) || g_force_small_tile == 1) return NT_AS_NOT_TAKEN;
+    if (p.relu_mask) return NT_AS_NOT_TAKEN;
+    const int npanels = p.M / 256;
+    if (npanels < 512 && g_force_small_tile != 2) return NT_AS_NOT_TAKEN;      // fewer than two panels per CU: the tile kernels balance better
+    if (npanels < 1) return NT_AS_NOT_TAKEN;
+    const char* name = nullptr;
+    if (p.act == ACT_NONE && !p.residual && !p.bits_in && !p.bits_out && !p.drop.thr && p.alpha == 1.f) name = "svla_nt_as_f0";
+    if (!name || !svla_asm_has(name)) return NT_AS_NOT_TAKEN;
+    static int n_cu = 0;
+    static float* zero_bias = nullptr;
+    if (!n_cu) {
+        int dev = 0;
+        HIP_CHECK_RET(hipGetDevice(&dev));
+        HIP_CHECK_RET(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        HIP_CHECK_RET(hipMalloc(&zero_bias, 4096 * sizeof(float)));
+        HIP_CHECK_RET(hipMemset(zero_bias, 0, 4096 * sizeof(float)));
+    }
+    NtAsKarg k;
+    memset(&k, 0, sizeof(k));
+    k.A = p.A; k.lda = p.lda; k.B = p.B; k.ldb = p.ldb; k.bias = p.bias ? p.bias : zero_bias; k.res = p.residual; k.ldr = p.ldr; k.C = p.C; k.ldc = p.ldc;
+    k.M = npanels * 256; k.N = p.N; k.alpha = p.alpha; k.npanels = npanels; k.bits = p.bits_in ? (const void*)p.bits_in : (const void*)p.bits_out;
+    k.key = p.drop.key; k.thr = p.drop.thr; k.scale = p.drop.scale; k.row_mult = p.drop.row_mult; k.seed_dev = p.drop.seed_dev; k.stream_key = p.drop.stream_key;
+    k.grid = npanels < n_cu ? npanels : n_cu;
+    const int rc = svla_asm_launch(name, &k, sizeof(k), k.grid, 256, stream);
+    if (rc) return rc;
+    const int tail = p.M - npanels * 256;
+    if (tail > 0) {
+        GemmNtArgs q = p;
+        const size_t r0 = (size_t)npanels * 256;
+        q.A = p.A + r0 * p.lda;
+        q.C = (void*)((bf16_t*)p.C + r0 * p.ldc);
+        if (p.residual) q.residual = p.residual + r0 * p.ldr;
+        if (p.bits_in) q.bits_in = p.bits_in + (r0 >> 5) * (size_t)(p.N >> 6) * 256;
+        if (p.bits_out) q.bits_out = p.bits_out + (r0 >> 5) * (size_t)(p.N >> 6) * 256;
+        q.M = tail;
+        q.row0 = (int)r0;
+        const int mt = (tail + BM - 1) / BM, nt = p.N / BN;
+        const size_t lds = BM * (BN + 4) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(mt * nt), dim3(NTHREADS), lds, stream, q);
+        return svla_launch_status();
+    }
+    return SVLA_OK;
+}
+
 extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, long ldb, const float* bias,
                                  const bf16_t* residual, long ldr, const bf16_t* relu_mask, long ldm, void* C, long ldc,
                                  int M, int N, int K, int act, int out_f32, float alpha, unsigned char* relu_bits_out,
@@ -959,7 +1020,11 @@ extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, lon
     if ((relu_bits && (relu_mask || residual || out_f32)) || (relu_bits_out && (act != ACT_RELU || out_f32 || residual || relu_mask || relu_bits))) return SVLA_EINVAL;
     if (act < ACT_NONE || act > ACT_GELU) return SVLA_EINVAL;
     if ((lda % 8) || (ldb % 8) || (ldc % (out_f32 ? 4 : 8)) || (residual && (ldr % 8)) || (relu_mask && (ldm % 8))) return SVLA_EINVAL;
-    GemmNtArgs p{A, lda, B, ldb, bias, residual, ldr, relu_mask, ldm, C, ldc, M, N, K, act, out_f32, alpha, relu_bits_out, relu_bits, drop_cfg(drop), g_dbg};
+    GemmNtArgs p{A, lda, B, ldb, bias, residual, ldr, relu_mask, ldm, C, ldc, M, N, K, act, out_f32, alpha, relu_bits_out, relu_bits, drop_cfg(drop), 0, g_dbg};
+    {
+        const int rc = nt_as_try(p, (hipStream_t)stream);      // K = 512 row-streaming GEMMs: the A-stationary assembly kernels
+        if (rc != NT_AS_NOT_TAKEN) return rc;
+    }
     // N % 256 == 128 with N >= 384 (the ViT-S widths 384 and 1152): the last n-tile is a half tile (75 % / 90 % of the MFMA work useful) --
     // still well ahead of the 128-tile kernel
     if (!out_f32 && ((N % 256) == 0 || ((N % 128) == 0 && N >= 384)) && (K % BK64) == 0 && K >= 2 * BK64 && ((long)((M + 255) / 256) * ((N + 255) / 256) >= 160 || g_force_small_tile == 2) && g_force_small_tile != 1) {
