@@ -98,6 +98,10 @@ int svla_gemm_nt_bf16(const svla_bf16* A, long lda, const svla_bf16* B, long ldb
                       const svla_dropout* drop, void* stream);
 /* Test hook: force the 128x128-tile kernel even where the 256x256 one would be chosen (same cited layers). */
 int svla_gemm_force_small_tile(int on);
+/* Tool / test hook: launch kernel `name` of the embedded gfx950 assembly code object (safevla_amd/asmgen/) with a raw kernarg block --
+ * probes of the assembly builder's instruction semantics on hardware (tools/asm_probe.py); the GEMM entry points above dispatch to the
+ * generated kernels themselves (same cited layers). */
+int svla_asm_launch_raw(const char* name, const void* kernarg, int kernarg_bytes, int grid, int block, void* stream);
 /* dW[N,K] (fp32) += dY[M,N]^T . X[M,K]: weight gradients (autograd of the same layers); optional fused bias gradient
  * db[N] += sum_m dY[m,:] (db may be NULL).  N,K % 128 == 0. */
 int svla_gemm_tn_f32acc(const svla_bf16* dY, long ldy, const svla_bf16* X, long ldx, float* dW, long ldw, float* db, int M, int N,

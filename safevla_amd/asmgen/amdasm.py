@@ -467,7 +467,19 @@ class Prog:
     def v_bfe_u32(self, d, x, off, width):
         self._v3("v_bfe_u32", d, x, off, width, lambda p, q, r: (p >> (q & 31)) & ((1 << (r & 31)) - 1))
 
+    def v_mbcnt_lane_id(self, d):
+        """lane index 0..63 (v_mbcnt_lo + v_mbcnt_hi over an all-ones mask)"""
+        self._valu(f"v_mbcnt_lo_u32_b32 {_txt(d)}, -1, 0", lambda w: w.wr(d, np.minimum(LANES, 32).astype(np.uint32)))
+        self._valu(f"v_mbcnt_hi_u32_b32 {_txt(d)}, -1, {_txt(d)}", lambda w: w.wr(d, LANES.astype(np.uint32)))
+
     def v_readfirstlane_b32(self, d, x):
+        # gfx940-family hazard (measured: tools/asm_probe.py returned a stale register without it): a VALU write of x needs a wait state before
+        # v_readfirstlane reads it, and the SGPR it writes needs 5 before a vector-memory instruction uses it -- pad both sides here, always
+        self.s_nop(1)
+        self._v_readfirstlane_raw(d, x)
+        self.s_nop(4)
+
+    def _v_readfirstlane_raw(self, d, x):
         def fn(w):
             lanes = np.nonzero(w.lanes())[0]
             w.swr(d, int(w.rd(x)[lanes[0] if len(lanes) else 0]))

@@ -106,9 +106,10 @@ class QModel:
 class NtAsGen:
     CAP = 3            # fillers per MFMA gap taken from the streams (fixed-slot instructions come on top)
 
-    def __init__(self, name="svla_nt_as_f0", act=0, aux=0, drop=False, bits_out=False, alpha=False, cap=None):
+    def __init__(self, name="svla_nt_as_f0", act=0, aux=0, drop=False, bits_out=False, alpha=False, cap=None, dbg=""):
         self.name = name
         self.act, self.aux, self.drop, self.bits_out, self.alpha = act, aux, drop, bits_out, alpha
+        self.dbg = set(dbg.split(",")) if dbg else set()      # fault bisection builds: nostore / nodma / nox / nobias
         if cap is not None:
             self.CAP = cap
         self.p = Prog(name)
@@ -229,7 +230,10 @@ class NtAsGen:
         p.s_lshl_b32(S_T[4], S_N, 2)
         p.s_mov_b32(SRD_T.sub(2), S_T[4])           # num_records = 4 N: reads past bias[N) return 0
         p.label("L_BIAS")
-        p.buffer_load(T[10], T[8], SRD_T, S_T[3])
+        if "nobias" in self.dbg:
+            p.v_mov_b32(T[10], 0)
+        else:
+            p.buffer_load(T[10], T[8], SRD_T, S_T[3])
         p.s_waitcnt(vmcnt=0)
         p.ds_write(T[9], T[10])
         p.v_add_u32(T[9], 1024, T[9])
@@ -245,7 +249,8 @@ class NtAsGen:
             self.set_panel_srd(SRD_R, S_RES, S_P, S_LDR2)
         for ks in range(KS):
             for mb in range(2):
-                p.buffer_load(XFRAG(mb, ks), V_XOFF[mb], SRD_X, S_XROW, ks * 32)
+                if "nox" not in self.dbg:
+                    p.buffer_load(XFRAG(mb, ks), V_XOFF[mb], SRD_X, S_XROW, ks * 32)
             if ks == 23:
                 p.s_waitcnt(vmcnt=0)
         # W tile 0 -> buffer 0
@@ -296,6 +301,8 @@ class NtAsGen:
         out.append(lambda: p.v_xor_b32(V_DMATMP, t << 4, V_LANE16))
 
         def ld():
+            if "nodma" in self.dbg:
+                return
             p.global_load_lds_x4(V_DMATMP, S_WPTR)
             self.vm.issue(f"dma{t}")
         out.append(ld)
@@ -334,6 +341,8 @@ class NtAsGen:
             for it in range(4):
                 def st_(it=it, mb=mb, tags=tags):
                     self.wait_for(lg_tags=[tags[it]])
+                    if "nostore" in self.dbg:
+                        return
                     if masked:
                         p.s_mov_b64(EXEC, S_STMASK)
                     p.buffer_store(V_RB[it], V_CSTEP, SRD_C, S_CROW[mb * 4 + it])
@@ -402,6 +411,8 @@ class NtAsGen:
             for ks in range(KS):
                 for mb in range(2):
                     def xl(ks=ks, mb=mb):
+                        if "nox" in self.dbg:
+                            return
                         p.buffer_load(XFRAG(mb, ks), V_XOFF[mb], SRD_X, S_XROW, ks * 32)
                         self.vm.issue(f"x{ks}")
                     fixed[4 * ks + 3].append(xl)
@@ -575,6 +586,10 @@ amdhsa.kernels:
 FLAVOURS = {
     "f0": dict(),                                  # bias (or none): in_proj forward, out_proj input gradient
 }
+import os as _os
+if _os.environ.get("SVLA_ASM_DEBUG_VARIANTS"):      # fault-bisection builds (tools only)
+    for _d in ("nodma,nox,nobias", "nostore,nox,nobias", "nostore,nodma,nobias", "nostore,nodma,nox", "nostore,nodma,nox,nobias"):
+        FLAVOURS["f0_" + _d.replace(",", "_")] = dict(dbg=_d)
 
 
 def generate(flavour="f0"):

@@ -46,3 +46,8 @@ int svla_asm_launch(const char* name, const void* kernarg, size_t kernarg_bytes,
     HIP_CHECK_RET(hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, 0, stream, nullptr, extra));
     return svla_launch_status();
 }
+
+extern "C" int svla_asm_launch_raw(const char* name, const void* kernarg, int kernarg_bytes, int grid, int block, void* stream) {
+    if (!name || !kernarg || kernarg_bytes <= 0 || grid <= 0 || block <= 0) return SVLA_EINVAL;
+    return svla_asm_launch(name, kernarg, (size_t)kernarg_bytes, grid, block, (hipStream_t)stream);
+}

@@ -19,6 +19,7 @@
 #include "asm_kernels.h"
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
 
 #define BM 128
 #define BN 128
@@ -970,6 +971,11 @@ static int nt_as_try(const GemmNtArgs& p, hipStream_t stream) {
     if (npanels < 1) return NT_AS_NOT_TAKEN;
     const char* name = nullptr;
     if (p.act == ACT_NONE && !p.residual && !p.bits_in && !p.bits_out && !p.drop.thr && p.alpha == 1.f) name = "svla_nt_as_f0";
+    static char dbg_name[96];
+    if (name && getenv("SVLA_NT_AS_VARIANT")) {      // fault-bisection builds of tools/: svla_nt_as_f0_<variant>
+        snprintf(dbg_name, sizeof(dbg_name), "%s_%s", name, getenv("SVLA_NT_AS_VARIANT"));
+        name = dbg_name;
+    }
     if (!name || !svla_asm_has(name)) return NT_AS_NOT_TAKEN;
     static int n_cu = 0;
     static float* zero_bias = nullptr;
