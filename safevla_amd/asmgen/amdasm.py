@@ -394,10 +394,16 @@ class Prog:
         self._add(f"s_cbranch_scc0 {label}", fn, "branch")
 
     def s_memtime(self, d):
+        """64-bit shader clock through the scalar memory path: returns on lgkmcnt, out of order -- follow it with lgkmcnt(0)"""
         def fn(w):
-            w.swr(d, 0, 0)
-            w.swr(d, 0, 1)
-        self._add(f"s_memtime {_txt(d)}", fn, "smem_nowait")
+            w.emu.clock = getattr(w.emu, "clock", 0) + 1000
+
+            def land(t=w.emu.clock):
+                w.swr(d, t, 0)
+                w.swr(d, 0, 1)
+            w.lgq.append(land)
+            w.smem_out = getattr(w, "smem_out", 0) + 1
+        self._add(f"s_memtime {_txt(d)}", fn, "smem")
 
     # ------------------------------------------------------------------ VALU
     def _valu(self, text, fn):

@@ -5,22 +5,32 @@ architecture/models/allenact_transformer_models/allenact_dino_transformer.py:545
 input-gradient GEMM through linear2), the 256x256-tile kernel of csrc/gemm.hip.  Structure:
 
   * one workgroup of FOUR waves per CU (one wave per SIMD, 256 arch VGPRs + 256 AGPRs each), persistent over 256-row panels of A;
-  * wave w keeps ITS 64 rows x 512 k of A in the 256 AGPRs for the whole sweep over N (MFMA B operands read straight from the
-    accumulator file): A is fetched from HBM exactly once and never touches LDS;
+  * wave w keeps ITS 64 rows x 512 k of A in the 256 AGPRs for a whole sweep over N (MFMA B operands read straight from the accumulator
+    file): A is fetched from HBM exactly once and never touches LDS;
   * W streams L2 -> LDS by LDS-DMA, one 64-column x 512-k tile (64 KiB, rows XOR-swizzled on the DMA source address) per "n-step",
-    two buffers, ONE workgroup barrier per n-step (4096 MFMA cycles);
+    two buffers, ONE workgroup barrier per n-step (4096 MFMA cycles); the tile sequence 0, 1, .., N/64 - 1, 0, .. is shared by the
+    workgroup and never restarts;
   * per n-step a wave issues 128 v_mfma_f32_32x32x16_bf16 (2 n-blocks x 2 m-blocks x 32 k-steps) against 64 ds_read_b128: 0.5 LDS
     fragment reads per MFMA;
   * TWO accumulator sets (2 x 64 VGPRs): while n-step j accumulates into one, the epilogue of n-step j-1 (bias is the accumulator's
     initial value, activation / dropout / mask / residual, bf16 rounding, transposition through a wave-private 4-KiB LDS buffer, eight
     full-line stores) is interleaved, instruction by instruction, into the gaps between the MFMAs of step j -- the C stores leave the CU
     as a continuous trickle instead of a burst at the end of a 256x256 tile;
+  * PHASES: a wave's sweep over N may start at any tile of the shared sequence (the n-tiles of a panel are visited in a rotated order),
+    so wave w of workgroup g switches panels phi(g, w) = w * NS/4 + (g & cmask) steps after wave 0 of workgroup 0 does (it idles through
+    phi "dummy" steps at the start of the launch and (3 - w) * NS/4 at the end, serving the DMA and the barriers).  The next panel's A
+    fragments are fetched in the panel's last step, fragment by fragment as their last MFMA has been issued; with every wave of every
+    CU switching in the same step that was a chip-wide burst of 256 KiB per CU (measured: the last step took 22.8 k cycles instead of 5 k);
+    with phases the chip fetches A at a constant rate;
   * every s_waitcnt is counted by this generator from a model of the in-order VM / LGKM queues; amdasm.Emu checks the result.
 
-The instruction stream is emitted by a list scheduler: each MFMA is followed by up to CAP "filler" instructions taken from fixed slots
-(W fragment reads) and from ordered streams (LDS-DMA of the next W tile, epilogue of the previous step, panel switch).
+The instruction stream is emitted by a list scheduler: each MFMA is followed by up to CAP "filler" groups taken from fixed slots
+(W fragment reads) and from ordered streams (LDS-DMA of the next W tile, epilogue of the previous step).  A group is emitted
+whole (carry chains through SCC, M0 write + DMA).
 """
-from .amdasm import EXEC, M0, Prog, Reg, a, s, v
+import os as _os
+
+from .amdasm import EXEC, M0, Prog, a, s, v
 
 KS = 32                    # k-steps of 16 (K = 512)
 LDS_W = (0, 65536)
@@ -29,31 +39,33 @@ LDS_BIAS = 147456          # fp32 bias[N], N <= 4096 (the bias table doubles as 
 LDS_BYTES = 163840
 
 # ---- kernel arguments (byte offsets in the kernarg segment)
-KARG = dict(A=0, lda=8, B=16, ldb=24, bias=32, res=40, ldr=48, C=56, ldc=64, M=72, N=76, alpha=80, npanels=84, bits=88,
+KARG = dict(A=0, lda=8, B=16, ldb=24, bias=32, res=40, ldr=48, C=56, ldc=64, cmask=72, N=76, alpha=80, npanels=84, bits=88,
             key=96, thr=100, scale=104, row_mult=108, seed_dev=112, stream_key=120, grid=124)
 KARG_BYTES = 128
 
-# ---- SGPRs
+# ---- SGPRs (s0..s3 are free after the prologue: timing builds use them)
 S_A, S_LDA, S_B, S_LDB, S_BIAS, S_RES, S_LDR, S_C = s(4, 2), s(6, 2), s(8, 2), s(10, 2), s(12, 2), s(14, 2), s(16, 2), s(18, 2)
-S_LDC, S_M, S_N, S_ALPHA, S_NPANELS, S_BITS = s(20, 2), s(22), s(23), s(24), s(25), s(26, 2)
+S_LDC, S_CMASK, S_N, S_ALPHA, S_NPANELS, S_BITS = s(20, 2), s(22), s(23), s(24), s(25), s(26, 2)
 S_KEY, S_THR, S_SCALE, S_ROWMULT, S_SEEDDEV, S_STREAMKEY, S_GRID = s(28), s(29), s(30), s(31), s(32, 2), s(34), s(35)
 S_WID = s(36)
 S_LDA2, S_LDC2, S_LDR2 = s(37), s(38), s(39)
 SRD_X, SRD_C, SRD_R, SRD_T = s(40, 4), s(48, 4), s(52, 4), s(56, 4)
-S_P, S_PN = s(60), s(61)             # panel being accumulated; panel whose A is being fetched
+S_DUM, S_NEXTN0 = s(44), s(45)        # dummy steps left; n0 of the next step
+S_P, S_PN = s(60), s(61)              # panel being accumulated; panel whose A is being fetched
 S_LOOP = s(62)
 S_WBASE_HI, S_LDB2, S_LDB2X48, S_WBASE = s(63), s(64), s(65), s(66)      # S_WBASE(_HI): B + w * 16 * ldb2
-S_WPTR = s(90, 2)                     # address of the next W row this wave fetches
-S_M0BASE = s(67)
+S_M0NEXT = s(67)                      # LDS address of this wave's first row in the buffer the NEXT tile is fetched into
 S_NE2 = s(68)                         # 2 * n0 of the step whose epilogue is running
 S_N0 = s(69)                          # n0 of the step being accumulated
 S_CROW = [s(70 + i) for i in range(8)]   # store row offsets (w*64 + mb*32 + 8 it) * ldc2
 S_XROW = s(78)                        # w * 64 * lda2
 S_NB4 = s(79)                         # 4 * n0 of the next step (bias table offset)
-S_STMASK = s(80, 2)                   # exec mask of the epilogue stores (0 until the first n-step of the launch has been computed)
+S_STMASK = s(80, 2)                   # exec mask of the epilogue stores (0 until this wave's first n-step has been computed)
 S_T = [s(82 + i) for i in range(8)]   # scratch
+S_WPTR = s(90, 2)                     # address of the next W row this wave fetches
 S_RROW = [s(92 + i) for i in range(8)]   # residual row offsets (w*64 + mb*32 + 8 it) * ldr2
 N_SGPR = 100
+
 
 # ---- VGPRs
 def ACC(st, nb, mb):
@@ -74,7 +86,7 @@ V_COFF, V_CSTEP, V_STW, V_STRD, V_BIASRD, V_BIASSTEP = v(202), v(203), v(204), v
 V_XOFF = [v(208), v(209)]
 V_STWX = v(210)                       # staging write address of the current 8-byte piece
 V_PK = [v(212 + 2 * i, 2) for i in range(8)]       # converted pieces
-V_RB = [v(228 + 4 * i, 4) for i in range(4)]       # read-back (row-major) pieces = store data
+V_RB = [[v(228 + 4 * i, 4) for i in range(4)], [v(240 + 4 * i, 4) for i in range(4)]]      # read-back (row-major) pieces = store data, per slab (v240.. double as prologue temporaries)
 V_TMP = [v(244 + i) for i in range(12)]
 
 
@@ -104,14 +116,19 @@ class QModel:
 
 
 class NtAsGen:
-    CAP = 3            # fillers per MFMA gap taken from the streams (fixed-slot instructions come on top)
+    CAP = 3            # filler groups per MFMA gap taken from the streams (fixed-slot instructions come on top)
+    DMA_END = 72       # the last LDS-DMA piece of the next tile is issued by this gap (~1.5 k cycles before the barrier)
+    BAR_GAP = 119      # the barrier follows MFMA 119 (k-step 29); the last fragment reads of the tile are issued at gaps 113 / 115
 
-    def __init__(self, name="svla_nt_as_f0", act=0, aux=0, drop=False, bits_out=False, alpha=False, cap=None, dbg=""):
+    def __init__(self, name="svla_nt_as_f0", act=0, aux=0, drop=False, bits_out=False, alpha=False, cap=None, dbg="", stagger=0, epi_order=1, dma_end=None):
         self.name = name
         self.act, self.aux, self.drop, self.bits_out, self.alpha = act, aux, drop, bits_out, alpha
-        self.dbg = set(dbg.split(",")) if dbg else set()      # fault bisection builds: nostore / nodma / nox / nobias
+        self.dbg = set(dbg.split(",")) if dbg else set()      # timing-only / bisection builds (tools/): time, nostore, nodma, nox, noepi, ...
         if cap is not None:
             self.CAP = cap
+        self.stagger, self.epi_order = stagger, epi_order
+        if dma_end is not None:
+            self.DMA_END = dma_end
         self.p = Prog(name)
         self.vm = QModel(63)
         self.lg = QModel(15)
@@ -164,6 +181,9 @@ class NtAsGen:
         p.v_lshrrev_b32(T[3], 5, T[0])              # h = lane >> 5
         p.s_waitcnt(lgkmcnt=0)
         p.s_mov_b64(S_STMASK, 0)
+        if "time" in self.dbg:
+            for i in range(28, 35):
+                p.s_mov_b32(s(i), 0)
         p.s_lshl_b32(S_LDA2, S_LDA.sub(0), 1)
         p.s_lshl_b32(S_LDC2, S_LDC.sub(0), 1)
         p.s_lshl_b32(S_LDR2, S_LDR.sub(0), 1)
@@ -173,7 +193,7 @@ class NtAsGen:
         p.s_mul_i32(S_T[1], S_T[0], S_LDB2)         # w * 16 * ldb2 (< 2^32: N <= 4096 rows)
         p.s_add_u32(S_WBASE, S_B.sub(0), S_T[1])
         p.s_addc_u32(S_WBASE_HI, S_B.sub(1), 0)
-        p.s_lshl_b32(S_M0BASE, S_WID, 14)           # w * 16 KiB
+        p.s_lshl_b32(S_M0NEXT, S_WID, 14)           # w * 16 KiB: the prologue fetches tile 0 into buffer 0
         p.s_lshl_b32(S_T[0], S_WID, 6)
         p.s_mul_i32(S_XROW, S_T[0], S_LDA2)         # w * 64 * lda2
         for mb in range(2):
@@ -181,12 +201,10 @@ class NtAsGen:
                 p.s_add_u32(S_T[1], S_T[0], mb * 32 + 8 * it)
                 p.s_mul_i32(S_CROW[mb * 4 + it], S_T[1], S_LDC2)
                 p.s_mul_i32(S_RROW[mb * 4 + it], S_T[1], S_LDR2)
-        # descriptors: W whole; X / C / R per panel
-        for srd, base in ((SRD_T, S_BIAS),):
-            p.s_mov_b32(srd.sub(0), base.sub(0))
-            p.s_and_b32(srd.sub(1), base.sub(1), 0xffff)
-            p.s_mov_b32(srd.sub(2), 0xffffffff)
-            p.s_mov_b32(srd.sub(3), 0x00020000)
+        # descriptors: bias table source; A / C / residual per panel
+        p.s_mov_b32(SRD_T.sub(0), S_BIAS.sub(0))
+        p.s_and_b32(SRD_T.sub(1), S_BIAS.sub(1), 0xffff)
+        p.s_mov_b32(SRD_T.sub(3), 0x00020000)
         for srd in (SRD_X, SRD_C, SRD_R):
             p.s_mov_b32(srd.sub(2), 0xffffffff)
             p.s_mov_b32(srd.sub(3), 0x00020000)
@@ -223,7 +241,7 @@ class NtAsGen:
             p.v_add_u32(T[8], mb * 32, T[2])
             p.v_mul_lo_u32(T[8], T[8], S_LDA2)
             p.v_lshl_add_u32(V_XOFF[mb], T[3], 4, T[8])
-        # ---- bias table -> LDS (N % 256 == 0; the host always passes a bias pointer: zeros when the GEMM has none)
+        # ---- bias table -> LDS (the host always passes a bias pointer: zeros when the GEMM has none)
         p.v_lshlrev_b32(T[8], 2, v(0))
         p.v_add_u32(T[9], LDS_BIAS, T[8])
         p.s_mov_b32(S_T[3], 0)
@@ -240,40 +258,59 @@ class NtAsGen:
         p.s_add_u32(S_T[3], S_T[3], 1024)
         p.s_cmp("lt_u32", S_T[3], S_T[4])
         p.s_cbranch_scc1("L_BIAS")
+        # ---- phase of this wave: phi = w * NS/4 + (workgroup & cmask) dummy steps before its first panel, (3 - w) * NS/4 after its last
+        p.s_lshr_b32(S_T[0], S_N, 8)                # NS / 4
+        p.s_mul_i32(S_DUM, S_WID, S_T[0])
+        p.s_and_b32(S_T[1], s(2), S_CMASK)
+        p.s_add_u32(S_DUM, S_DUM, S_T[1])
         # ---- first panel
         p.s_mov_b32(S_P, s(2))
         p.s_mov_b32(S_PN, s(2))
-        self.set_panel_srd(SRD_X, S_A, S_PN, S_LDA2)
-        self.set_panel_srd(SRD_C, S_C, S_P, S_LDC2)
-        if self.aux == 1:
-            self.set_panel_srd(SRD_R, S_RES, S_P, S_LDR2)
+        self.panel_srd(SRD_X, S_A, S_PN, S_LDA2)
         for ks in range(KS):
             for mb in range(2):
                 if "nox" not in self.dbg:
                     p.buffer_load(XFRAG(mb, ks), V_XOFF[mb], SRD_X, S_XROW, ks * 32)
             if ks == 23:
                 p.s_waitcnt(vmcnt=0)
-        # W tile 0 -> buffer 0
-        p.s_mov_b32(S_WPTR.sub(0), S_WBASE)
-        p.s_mov_b32(S_WPTR.sub(1), S_WBASE_HI)
+        # ---- ROTATION: workgroup g starts the shared tile sequence at tile (g mod NS).  Without it every CU of the chip stores the same
+        # 128-byte column of C (row stride 2 N bytes: one L2 / HBM channel group) and fetches the same W tile at the same moment.
+        p.s_lshr_b32(S_T[0], S_N, 6)                # NS
+        p.s_mov_b32(S_T[1], s(2))
+        p.label("L_ROT")
+        p.s_cmp("lt_u32", S_T[1], S_T[0])
+        p.s_cbranch_scc1("L_ROTD")
+        p.s_sub_u32(S_T[1], S_T[1], S_T[0])
+        p.s_branch("L_ROT")
+        p.label("L_ROTD")
+        p.s_lshl_b32(S_N0, S_T[1], 6)               # n0 of the first tile
+        p.s_mul_i32(S_T[2], S_N0, S_LDB2)           # byte offset of its first row (< 2^32)
+        p.s_add_u32(S_WPTR.sub(0), S_WBASE, S_T[2])
+        p.s_addc_u32(S_WPTR.sub(1), S_WBASE_HI, 0)
         for t in range(16):
-            self.dma_piece(t, 0, first=(t == 0))
-        p.s_mov_b32(S_N0, 0)
+            for grp in self.dma_groups(t):
+                for th in grp:
+                    th()
+        p.s_xor_b32(S_M0NEXT, S_M0NEXT, 0x10000)
         p.s_waitcnt(vmcnt=0, lgkmcnt=0)
         self.vm.wait(0)
         self.lg.wait(0)
+        if "time" in self.dbg:
+            p.s_memtime(s(0, 2))
+            p.s_waitcnt(lgkmcnt=0)
+            p.s_mov_b32(s(28), s(0))
         p.s_barrier()
-        p.v_mov_b32(V_BIASSTEP, V_BIASRD)
+        p.s_lshl_b32(S_T[2], S_N0, 2)
+        p.v_add_u32(V_BIASSTEP, S_T[2], V_BIASRD)
         for nb in range(2):
             for rg in range(4):
                 p.ds_read(BIASR(nb).sub(4 * rg, 4), V_BIASSTEP, nb * 128 + rg * 32)
         for ks in range(3):
             for nb in range(2):
-                self.wread(ks, nb, 0)
-        p.s_branch("L_FIRST")
+                self.wread(ks, nb)
 
-    def set_panel_srd(self, srd, base, panel, ld2):
-        """srd.base = base + panel * 256 * ld2 (64-bit)"""
+    def panel_srd(self, srd, base, panel, ld2):
+        """srd.base = base + panel * 256 * ld2 (64-bit); one group: the carry travels through SCC"""
         p = self.p
         p.s_lshl_b32(S_T[5], panel, 8)
         p.s_mul_hi_u32(S_T[6], S_T[5], ld2)
@@ -282,48 +319,97 @@ class NtAsGen:
         p.s_addc_u32(S_T[6], base.sub(1), S_T[6])
         p.s_and_b32(srd.sub(1), S_T[6], 0xffff)
 
-    def dma_piece(self, t, buf, first):
-        """one LDS-DMA instruction: row (w*16 + t) of the W tile whose first row's byte offset is in S_WOFF-progress, into LDS buffer buf"""
-        for th in self.dma_thunks(t, buf, first):
-            th()
-
-    def dma_thunks(self, t, buf, first):
+    def dma_groups(self, t):
+        """LDS-DMA of row (w*16 + t) of the next W tile, as scheduler groups"""
         p = self.p
-        out = []
-        if first:
-            if buf == 0:
-                out.append(lambda: p.s_mov_b32(M0, S_M0BASE))
+
+        def g1():
+            if t == 0:
+                p.s_mov_b32(M0, S_M0NEXT)
             else:
-                out.append(lambda: p.s_add_u32(M0, S_M0BASE, LDS_W[1]))
-        else:
-            out.append(lambda: p.s_add_u32(M0, M0, 1024))
-        # row & 15 == t (w*16 + t): lane i lands at physical chunk i, so it fetches logical chunk i ^ t
-        out.append(lambda: p.v_xor_b32(V_DMATMP, t << 4, V_LANE16))
+                p.s_add_u32(M0, M0, 1024)
+            # row & 15 == t: lane i lands at physical chunk i, so it fetches logical chunk i ^ t
+            p.v_xor_b32(V_DMATMP, t << 4, V_LANE16)
 
-        def ld():
-            if "nodma" in self.dbg:
-                return
-            p.global_load_lds_x4(V_DMATMP, S_WPTR)
-            self.vm.issue(f"dma{t}")
-        out.append(ld)
-        out.append(lambda: p.s_add_u32(S_WPTR.sub(0), S_WPTR.sub(0), S_LDB2))
-        out.append(lambda: p.s_addc_u32(S_WPTR.sub(1), S_WPTR.sub(1), 0))
-        return out
+        def g2():
+            if "nodma" not in self.dbg:
+                p.global_load_lds_x4(V_DMATMP, S_WPTR)
+                self.vm.issue(f"dma{t}")
 
-    def wread(self, ks, nb, buf):
+        def g3():
+            p.s_add_u32(S_WPTR.sub(0), S_WPTR.sub(0), S_LDB2)
+            p.s_addc_u32(S_WPTR.sub(1), S_WPTR.sub(1), 0)
+        return [[g1], [g2], [g3]]
+
+    def wread(self, ks, nb):
         j = ks % 8
         self.ds_read(WFRAG(ks, nb), V_WRD[j], nb * 32768 + (ks // 8) * 256, f"w{ks}_{nb}")
 
+    def step_head(self):
+        """scalar bookkeeping every step starts with (one block, before its first MFMA): the next tile's n0 and W row pointer (the tile
+        sequence wraps at N)"""
+        p = self.p
+        p.s_add_u32(S_NEXTN0, S_N0, 64)
+        p.s_cmp("eq_u32", S_NEXTN0, S_N)
+        p.s_cselect_b32(S_NEXTN0, 0, S_NEXTN0)
+        p.s_lshl_b32(S_NB4, S_NEXTN0, 2)
+        p.s_add_u32(S_WPTR.sub(0), S_WPTR.sub(0), S_LDB2X48)
+        p.s_addc_u32(S_WPTR.sub(1), S_WPTR.sub(1), 0)
+        p.s_cmp("eq_u32", S_NEXTN0, 0)
+        p.s_cselect_b32(S_WPTR.sub(0), S_WBASE, S_WPTR.sub(0))
+        p.s_cselect_b32(S_WPTR.sub(1), S_WBASE_HI, S_WPTR.sub(1))
+
+    def barrier(self, kind):
+        p = self.p
+        nv = self.vm.need({f"dma{t}" for t in range(16)})
+        if "time" in self.dbg:
+            p.s_memtime(s(0, 2))
+        if "nobarwait" in self.dbg:      # timing-only: no wait for the DMA at the barrier (wrong results)
+            p.s_waitcnt(lgkmcnt=0)
+        else:
+            p.s_waitcnt(vmcnt=nv if nv is not None else 0, lgkmcnt=0)
+        self.vm.wait(nv if nv is not None else 0)
+        self.lg.wait(0)
+        if "time" in self.dbg and kind != "dummy":
+            ki = {"first": 0, "mid": 1, "last": 2}[kind]
+            p.s_sub_u32(s(3), s(0), s(28))
+            p.s_add_u32(s(29 + ki), s(29 + ki), s(3))
+            p.s_add_u32(s(32 + ki), s(32 + ki), 1)
+        if "time" in self.dbg:
+            p.s_mov_b32(s(28), s(0))
+        p.s_barrier()
+        if self.stagger and kind != "dummy":
+            # the four waves leave the barrier in the same cycle and run the same stream: every LDS read / DMA issue of the step would
+            # collide with the other three waves' (measured: SQ_WAIT_INST_LDS = 1.5 quad-cycles per MFMA).  Wave w idles w * (stagger + ~3)
+            # issue slots here, so the waves sit at different offsets inside the 32-cycle MFMA period until the next barrier.
+            self.uid += 1
+            done = f"L_STG{self.uid}"
+            for i in range(1, 4):
+                p.s_cmp("lt_u32", S_WID, i)
+                p.s_cbranch_scc1(done)
+                p.s_nop(self.stagger - 1)
+            p.label(done)
+
+    def step_tail_scalars(self):
+        p = self.p
+        p.s_lshl_b32(S_NE2, S_N0, 1)
+        p.s_mov_b32(S_N0, S_NEXTN0)
+        p.s_xor_b32(S_M0NEXT, S_M0NEXT, 0x10000)
+
     # ------------------------------------------------------------------ epilogue of one n-step (previous step's accumulators)
-    def epi_stream(self, st, masked, earliest):
-        """list of (earliest_gap, thunk): the epilogue of accumulator set st, stores optionally under S_STMASK"""
+    def epi_stream(self, st, masked, earliest, late=None):
+        """list of (earliest_gap, [thunks]): the epilogue of accumulator set st, stores optionally under S_STMASK.  Order (epi_order 1):
+        convert + stage slab 0, read it back, convert + stage slab 1 (LDS operations of a wave execute in order: the writes follow the
+        reads), store slab 0, read slab 1 back, [late: groups of the caller, e.g. the next step's bias reads], store slab 1 -- no store waits
+        for a read-back issued just ahead of it."""
         p = self.p
         items = []
 
-        def add(th, e=earliest):
-            items.append((e, th))
+        def add(*ths, e=earliest):
+            items.append((e, list(ths)))
         add(lambda: p.v_add_u32(V_CSTEP, S_NE2, V_COFF))
-        for mb in range(2):
+
+        def convert(mb):
             for nb in range(2):
                 for rg in range(4):
                     gi = nb * 4 + rg
@@ -333,11 +419,16 @@ class NtAsGen:
                     add(lambda acc=acc, pk=pk, rg=rg: p.v_cvt_pk_bf16_f32(pk.sub(1), acc.sub(4 * rg + 2), acc.sub(4 * rg + 3)))
                     add(lambda gi=gi: p.v_xor_b32(V_STWX, gi << 4, V_STW))
                     add(lambda pk=pk: self.ds_write(V_STWX, pk))
+
+        def readback(mb):
             tags = []
             for it in range(4):
                 tg = self.tag(f"rb{mb}_{it}")
                 tags.append(tg)
-                add(lambda it=it, tg=tg: self.ds_read(V_RB[it], V_STRD, it * 1024, tg))
+                add(lambda it=it, tg=tg, mb=mb: self.ds_read(V_RB[mb][it], V_STRD, it * 1024, tg))
+            return tags
+
+        def stores(mb, tags):
             for it in range(4):
                 def st_(it=it, mb=mb, tags=tags):
                     self.wait_for(lg_tags=[tags[it]])
@@ -345,60 +436,56 @@ class NtAsGen:
                         return
                     if masked:
                         p.s_mov_b64(EXEC, S_STMASK)
-                    p.buffer_store(V_RB[it], V_CSTEP, SRD_C, S_CROW[mb * 4 + it])
+                    p.buffer_store(V_RB[mb][it], V_CSTEP, SRD_C, S_CROW[mb * 4 + it])
                     self.vm.issue(self.tag("st"))
                     if masked:
                         p.s_mov_b64(EXEC, -1)
                 add(st_)
+        if self.epi_order == 0:
+            for mb in range(2):
+                convert(mb)
+                stores(mb, readback(mb))
+            items += late or []
+        else:
+            convert(0)
+            t0 = readback(0)
+            convert(1)
+            stores(0, t0)
+            t1 = readback(1)
+            items += late or []
+            stores(1, t1)
         return items
 
     # ------------------------------------------------------------------ one n-step body
-    def body(self, kind, parity):
-        """kind: 'first' | 'mid' | 'last'; parity: LDS buffer holding this step's W tile = accumulator set of this step"""
+    def body(self, kind, st):
+        """kind: 'first' | 'mid' | 'last' of this wave's sweep over a panel; st: accumulator set of this step"""
         p = self.p
-        st = parity
-        buf, nbuf = parity, parity ^ 1
         NG = 4 * KS
+        BAR = self.BAR_GAP
         fixed = [[] for _ in range(NG)]
         pre = [[] for _ in range(NG)]
         streams = []
 
         # ---- W fragment reads, ring of 4 k-steps: (ks + 3, nb) right after the MFMA (ks, nb, mb = 0) -- its ring slot was last read by the
-        # MFMAs of k-step ks - 1.  The first three k-steps of the NEXT tile are read behind the barrier, at gaps 120 .. 125.
-        BAR_GAP = 119
+        # MFMAs of k-step ks - 1.  The first three k-steps of the NEXT tile are read behind the barrier, at gaps BAR + 1 .. BAR + 6.
         for ks in range(KS - 3):
             for nb in range(2):
-                fixed[4 * ks + 2 * nb + 1].append(lambda k3=ks + 3, nb=nb: self.wread(k3, nb, buf))
+                fixed[4 * ks + 2 * nb + 1].append(lambda k3=ks + 3, nb=nb: self.wread(k3, nb))
         for k in range(3):
             for nb in range(2):
-                fixed[BAR_GAP + 1 + 2 * k + nb].append(lambda k=k, nb=nb: self.wread(k, nb, nbuf))
+                fixed[BAR + 1 + 2 * k + nb].append(lambda k=k, nb=nb: self.wread(k, nb))
         # toggle the read addresses to the other buffer after their last use for this tile (chunk class j: last k-step 24 + j, read at gaps 4 (21 + j) + 1 / + 3)
         for j in range(8):
             fixed[4 * (21 + j) + 3].append(lambda j=j: p.v_xor_b32(V_WRD[j], 0x10000, V_WRD[j]))
-
         # ---- barrier: every read of this tile issued (last: k-step 31 at gaps 113 / 115) and retired, own DMA pieces of the next tile landed
-        def barrier():
-            nv = self.vm.need({f"dma{t}" for t in range(16)})
-            p.s_waitcnt(vmcnt=nv if nv is not None else 0, lgkmcnt=0)
-            self.vm.wait(nv if nv is not None else 0)
-            self.lg.wait(0)
-            p.s_barrier()
-        fixed[BAR_GAP].insert(0, barrier)
+        fixed[BAR].insert(0, lambda: self.barrier(kind))
 
-        # ---- scalar bookkeeping at the head of the step, then the LDS-DMA of the next tile
+        # ---- LDS-DMA of the next tile
+        self.step_head()
         dma = []
-        if kind == "last":
-            dma.append((0, lambda: p.s_mov_b32(S_WPTR.sub(0), S_WBASE)))
-            dma.append((0, lambda: p.s_mov_b32(S_WPTR.sub(1), S_WBASE_HI)))
-            dma.append((0, lambda: p.s_mov_b32(S_NB4, 0)))
-        else:
-            dma.append((0, lambda: p.s_add_u32(S_WPTR.sub(0), S_WPTR.sub(0), S_LDB2X48)))
-            dma.append((0, lambda: p.s_addc_u32(S_WPTR.sub(1), S_WPTR.sub(1), 0)))
-            dma.append((0, lambda: p.s_add_u32(S_NB4, S_N0, 64)))
-            dma.append((0, lambda: p.s_lshl_b32(S_NB4, S_NB4, 2)))
         for t in range(16):
-            for th in self.dma_thunks(t, nbuf, first=(t == 0)):
-                dma.append((1, th))
+            for grp in self.dma_groups(t):
+                dma.append((1, grp))
         streams.append(dma)
 
         # ---- panel switch (last step of a panel): the next panel's A fragments replace the ones whose last MFMA has been issued
@@ -406,8 +493,7 @@ class NtAsGen:
             p.s_add_u32(S_PN, S_P, S_GRID)
             p.s_sub_u32(S_T[7], S_NPANELS, 1)
             p.s_min_u32(S_PN, S_PN, S_T[7])          # past the end: re-fetch the last panel (never used)
-            for ins in self.panel_srd_thunks(SRD_X, S_A, S_PN, S_LDA2):
-                ins()
+            self.panel_srd(SRD_X, S_A, S_PN, S_LDA2)
             for ks in range(KS):
                 for mb in range(2):
                     def xl(ks=ks, mb=mb):
@@ -421,28 +507,27 @@ class NtAsGen:
                 pre[4 * ks].append(("vm", f"x{ks}"))
 
         # ---- epilogue of the previous step, bias registers of the next step, then the bookkeeping that must follow the epilogue
-        epi = self.epi_stream(st ^ 1, masked=(kind == "first"), earliest=8)
-        epi.append((16, lambda: p.v_add_u32(V_BIASSTEP, S_NB4, V_BIASRD)))
+        late = [(16, [lambda: p.v_add_u32(V_BIASSTEP, S_NB4, V_BIASRD)])]
         for nb in range(2):
             for rg in range(4):
-                epi.append((16, lambda nb=nb, rg=rg: self.ds_read(BIASR(nb).sub(4 * rg, 4), V_BIASSTEP, nb * 128 + rg * 32, self.tag("bias"))))
-        epi.append((16, lambda: p.s_lshl_b32(S_NE2, S_N0, 1)))
-        if kind == "last":
-            epi.append((16, lambda: p.s_mov_b32(S_N0, 0)))
-        else:
-            epi.append((16, lambda: p.s_add_u32(S_N0, S_N0, 64)))
+                late.append((16, [lambda nb=nb, rg=rg: self.ds_read(BIASR(nb).sub(4 * rg, 4), V_BIASSTEP, nb * 128 + rg * 32, self.tag("bias"))]))
+        epi = self.epi_stream(st ^ 1, masked=(kind == "first"), earliest=8, late=late) if "noepi" not in self.dbg else late
+        epi.append((16, [self.step_tail_scalars]))
         if kind == "first":
-            epi.append((16, lambda: p.s_mov_b64(S_STMASK, -1)))
-            for ins in self.panel_srd_thunks(SRD_C, S_C, S_P, S_LDC2):
-                epi.append((16, ins))
-            if self.aux == 1:
-                for ins in self.panel_srd_thunks(SRD_R, S_RES, S_P, S_LDR2):
-                    epi.append((16, ins))
-            epi.append((16, lambda: p.s_lshr_b32(S_LOOP, S_N, 7)))
-            epi.append((16, lambda: p.s_sub_u32(S_LOOP, S_LOOP, 1)))
+            def first_tail():
+                p.s_mov_b64(S_STMASK, -1)
+                self.panel_srd(SRD_C, S_C, S_P, S_LDC2)
+                if self.aux == 1:
+                    self.panel_srd(SRD_R, S_RES, S_P, S_LDR2)
+                p.s_lshr_b32(S_LOOP, S_N, 7)
+                p.s_sub_u32(S_LOOP, S_LOOP, 1)
+            epi.append((16, [first_tail]))
         streams.append(epi)
 
-        # ---- emit
+        # ---- emit.  Each stream is PACED over its window of gaps (first gap, last gap): group k of n is due at first + k * span / n, so
+        # the DMA pieces, the stores and the epilogue's LDS traffic leave the wave as an even trickle instead of a burst at the head of the step
+        # (the CU's L1 <-> L2 path is the resource this kernel saturates: measured)
+        windows = [(1, self.DMA_END), (8, BAR - 1)]
         pos = [0] * len(streams)
         nfill = 0
         for g in range(NG):
@@ -457,41 +542,61 @@ class NtAsGen:
             p.v_mfma_f32_32x32x16_bf16(ACC(st, nb, mb), WFRAG(ks, nb), XFRAG(mb, ks), c)
             for th in fixed[g]:
                 th()
-            n = 0
-            while n < self.CAP and g < BAR_GAP:
-                took = False
+            if g < BAR:
                 for si, sm in enumerate(streams):
-                    if n < self.CAP and pos[si] < len(sm) and sm[pos[si]][0] <= g:
-                        sm[pos[si]][1]()
+                    g0, g1 = windows[si]
+                    due = len(sm) if g >= g1 else (0 if g < g0 else (len(sm) * (g - g0 + 1) + (g1 - g0)) // (g1 - g0 + 1))
+                    n = 0
+                    while pos[si] < due and sm[pos[si]][0] <= g and n < self.CAP:
+                        for th in sm[pos[si]][1]:
+                            th()
                         pos[si] += 1
                         n += 1
                         nfill += 1
-                        took = True
-                if not took:
-                    break
-            if g == BAR_GAP - 1:
+            if g == BAR - 1:
                 # every DMA piece the barrier's vmcnt must cover and every LDS operation of the epilogue has been issued: the LGKM queue a
                 # step starts with is the six fragment reads behind the barrier, whatever step preceded it
                 for si, sm in enumerate(streams):
-                    if pos[si] != len(sm):
-                        raise RuntimeError(f"{self.name} {kind}: stream {si} has {len(sm) - pos[si]} instructions left at the barrier gap: raise CAP")
-        self.stats[(kind, parity)] = nfill
+                    while pos[si] < len(sm):
+                        for th in sm[pos[si]][1]:
+                            th()
+                        pos[si] += 1
+                        nfill += 1
+        self.stats[(kind, st)] = nfill
 
-    def panel_srd_thunks(self, srd, base, panel, ld2):
+    def dummy_body(self):
+        """a step of a wave that has no panel in flight (before its first / after its last): its share of the DMA, the barrier, the
+        fragment reads behind it (never consumed: they keep the LGKM state every step starts with), no MFMA, no epilogue"""
         p = self.p
-        return [
-            lambda: p.s_lshl_b32(S_T[5], panel, 8),
-            lambda: p.s_mul_hi_u32(S_T[6], S_T[5], ld2),
-            lambda: p.s_mul_i32(S_T[5], S_T[5], ld2),
-            lambda: p.s_add_u32(srd.sub(0), base.sub(0), S_T[5]),
-            lambda: p.s_addc_u32(S_T[6], base.sub(1), S_T[6]),
-            lambda: p.s_and_b32(srd.sub(1), S_T[6], 0xffff),
-        ]
+        p.s_waitcnt(lgkmcnt=0)          # the fragment / bias reads the previous step left in flight: nobody consumes them here
+        self.lg.wait(0)
+        self.step_head()
+        for t in range(16):
+            for grp in self.dma_groups(t):
+                for th in grp:
+                    th()
+        for j in range(8):
+            p.v_xor_b32(V_WRD[j], 0x10000, V_WRD[j])
+        p.v_add_u32(V_BIASSTEP, S_NB4, V_BIASRD)          # the next step may be this wave's first real one: its accumulator initialiser
+        for nb in range(2):
+            for rg in range(4):
+                self.ds_read(BIASR(nb).sub(4 * rg, 4), V_BIASSTEP, nb * 128 + rg * 32, self.tag("bias"))
+        self.barrier("dummy")
+        for k in range(3):
+            for nb in range(2):
+                self.wread(k, nb)
+        self.step_tail_scalars()
 
     # ------------------------------------------------------------------ whole kernel
     def build(self):
         p = self.p
         self.prologue()
+        p.label("L_DUMA")
+        p.s_cmp("eq_u32", S_DUM, 0)
+        p.s_cbranch_scc1("L_FIRST")
+        self.dummy_body()
+        p.s_sub_u32(S_DUM, S_DUM, 1)
+        p.s_branch("L_DUMA")
         p.label("L_LAST")
         self.body("last", 1)
         p.s_add_u32(S_P, S_P, S_GRID)
@@ -509,15 +614,42 @@ class NtAsGen:
         p.s_cbranch_scc1("L_MID")
         p.s_branch("L_LAST")
         p.label("L_DRAIN")
-        # the last step's epilogue (accumulator set 1), nothing to hide it under; the prefetched fragments / DMA of a non-existent next step drain
+        # the last step's epilogue (accumulator set 1), nothing to hide it under; the fragments prefetched for a non-existent next step drain
         p.s_waitcnt(vmcnt=0, lgkmcnt=0)
         self.vm.wait(0)
         self.lg.wait(0)
-        for _, th in self.epi_stream(1, masked=False, earliest=0):
-            th()
+        for _, grp in self.epi_stream(1, masked=False, earliest=0):
+            for th in grp:
+                th()
+        # trailing dummy steps: (3 - w) * NS/4, so that every wave of the workgroup passes the same number of barriers
+        p.s_lshr_b32(S_T[0], S_N, 8)
+        p.s_sub_u32(S_T[1], 3, S_WID)
+        p.s_mul_i32(S_DUM, S_T[0], S_T[1])
+        p.label("L_DUMB")
+        p.s_cmp("eq_u32", S_DUM, 0)
+        p.s_cbranch_scc1("L_EXIT")
+        self.dummy_body()
+        p.s_sub_u32(S_DUM, S_DUM, 1)
+        p.s_branch("L_DUMB")
+        p.label("L_EXIT")
         p.s_waitcnt(vmcnt=0, lgkmcnt=0)
+        if "time" in self.dbg:
+            # cycles between consecutive barriers, summed by the kind of step the interval ends in: [first, mid, last] sums, then counts, to
+            # the debug buffer (kernarg 'bits') at ((workgroup * 4 + wave) * 8 + i) * 4
+            p.s_mov_b32(SRD_T.sub(0), S_BITS.sub(0))
+            p.s_and_b32(SRD_T.sub(1), S_BITS.sub(1), 0xffff)
+            p.s_mov_b32(SRD_T.sub(2), 0xffffffff)
+            p.s_lshl_b32(S_T[0], s(2), 2)
+            p.s_add_u32(S_T[0], S_T[0], S_WID)
+            p.s_lshl_b32(S_T[0], S_T[0], 5)
+            p.v_mov_b32(V_TMP[0], 0)
+            p.s_mov_b64(EXEC, 1)
+            for i in range(6):
+                p.v_mov_b32(V_TMP[1], s(29 + i))
+                p.buffer_store(V_TMP[1], V_TMP[0], SRD_T, S_T[0], 4 * i)
+            p.s_waitcnt(vmcnt=0)
         p.s_endpgm()
-        return p
+        return self
 
     # ------------------------------------------------------------------ assembly text
     def asm_text(self):
@@ -586,10 +718,11 @@ amdhsa.kernels:
 FLAVOURS = {
     "f0": dict(),                                  # bias (or none): in_proj forward, out_proj input gradient
 }
-import os as _os
-if _os.environ.get("SVLA_ASM_DEBUG_VARIANTS"):      # fault-bisection builds (tools only)
-    for _d in ("nodma,nox,nobias", "nostore,nox,nobias", "nostore,nodma,nobias", "nostore,nodma,nox", "nostore,nodma,nox,nobias"):
+if _os.environ.get("SVLA_ASM_DEBUG_VARIANTS"):      # timing-only / bisection builds (tools/time_nt_as.py)
+    for _d in ("time", "time,nostore", "time,nodma", "time,noepi", "time,nox", "time,nobarwait", "time,noepi,nodma,nox"):
         FLAVOURS["f0_" + _d.replace(",", "_")] = dict(dbg=_d)
+    for _k, _o in (("d40", dict(dma_end=40)), ("d56", dict(dma_end=56)), ("d90", dict(dma_end=90)), ("d104", dict(dma_end=104)), ("s8", dict(stagger=8)), ("e0", dict(epi_order=0))):
+        FLAVOURS["f0_" + _k] = _o
 
 
 def generate(flavour="f0"):

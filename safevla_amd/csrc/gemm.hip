@@ -960,7 +960,7 @@ extern "C" int svla_gemm_force_small_tile(int on) {
 #define NT_AS_NOT_TAKEN (-12345)
 struct NtAsKarg {      // = asmgen/nt_as_gen.py KARG
     const void* A; long lda; const void* B; long ldb; const float* bias; const void* res; long ldr; void* C; long ldc;
-    int M, N; float alpha; int npanels; const void* bits; unsigned key, thr; float scale; int row_mult; const unsigned* seed_dev; unsigned stream_key; int grid;
+    int cmask, N; float alpha; int npanels; const void* bits; unsigned key, thr; float scale; int row_mult; const unsigned* seed_dev; unsigned stream_key; int grid;
 };
 static_assert(sizeof(NtAsKarg) == 128, "kernarg layout of the nt_as kernels");
 static int nt_as_try(const GemmNtArgs& p, hipStream_t stream) {
@@ -989,9 +989,15 @@ static int nt_as_try(const GemmNtArgs& p, hipStream_t stream) {
     NtAsKarg k;
     memset(&k, 0, sizeof(k));
     k.A = p.A; k.lda = p.lda; k.B = p.B; k.ldb = p.ldb; k.bias = p.bias ? p.bias : zero_bias; k.res = p.residual; k.ldr = p.ldr; k.C = p.C; k.ldc = p.ldc;
-    k.M = npanels * 256; k.N = p.N; k.alpha = p.alpha; k.npanels = npanels; k.bits = p.bits_in ? (const void*)p.bits_in : (const void*)p.bits_out;
+    {      // phase spread over workgroups: (workgroup & cmask) < NS/4 extra steps, cmask + 1 = the largest power of two <= NS/4
+        int q = p.N / 256, m = 1;
+        while (m * 2 <= q) m *= 2;
+        k.cmask = q >= 1 ? m - 1 : 0;
+    }
+    k.N = p.N; k.alpha = p.alpha; k.npanels = npanels; k.bits = p.bits_in ? (const void*)p.bits_in : (const void*)p.bits_out;
     k.key = p.drop.key; k.thr = p.drop.thr; k.scale = p.drop.scale; k.row_mult = p.drop.row_mult; k.seed_dev = p.drop.seed_dev; k.stream_key = p.drop.stream_key;
     k.grid = npanels < n_cu ? npanels : n_cu;
+    if (getenv("SVLA_NT_AS_DBGBUF")) k.bits = (const void*)strtoull(getenv("SVLA_NT_AS_DBGBUF"), nullptr, 16);      // timing builds of tools/time_nt_as.py
     const int rc = svla_asm_launch(name, &k, sizeof(k), k.grid, 256, stream);
     if (rc) return rc;
     const int tail = p.M - npanels * 256;
