@@ -36,6 +36,10 @@ class Reg:
             return f"{self.kind}{self.idx}"
         return f"{self.kind}[{self.idx}:{self.idx + self.n - 1}]"
 
+    def __post_init__(self):
+        # gfx90a+: vector register tuples must start at an even register
+        assert not (self.kind in ("v", "a") and self.n > 1 and self.idx % 2), f"misaligned register tuple {self.kind}[{self.idx}:{self.idx + self.n - 1}]"
+
     def sub(self, i, n=1):
         assert 0 <= i and i + n <= self.n, (self, i, n)
         return Reg(self.kind, self.idx + i, n)
@@ -295,6 +299,18 @@ class Prog:
     def s_xor_b32(self, d, x, y):
         self._s2("s_xor_b32", d, x, y, lambda p, q, w: p ^ q, lambda p, q, r, w: (r & 0xffffffff) != 0)
 
+    def s_and_b64(self, d, x, y):
+        def fn(w):
+            def val(o):
+                if isinstance(o, Reg):
+                    return w.srd(o, 0) | (w.srd(o, 1) << 32)
+                return o & 0xffffffffffffffff if o >= 0 else o + (1 << 64)
+            r = val(x) & val(y)
+            w.scc = int(r != 0)
+            w.swr(d, r & 0xffffffff, 0)
+            w.swr(d, r >> 32, 1)
+        self._salu(f"s_and_b64 {_txt(d)}, {_txt(x) if isinstance(x, Reg) else x}, {_txt(y) if isinstance(y, Reg) else y}", fn)
+
     def s_min_u32(self, d, x, y):
         self._s2("s_min_u32", d, x, y, lambda p, q, w: min(p, q), lambda p, q, r, w: p < q)
 
@@ -535,6 +551,54 @@ class Prog:
                 out |= np.minimum(pa, qa).view(np.uint16).astype(np.uint32) << sh
             w.wr(d, out)
         self._valu(f"v_pk_min_i16 {_txt(d)}, {_txt(x)}, {_txt(y)}", fn)
+
+    def _pk16(self, name, d, x, y, f, suffix=""):
+        def fn(w):
+            p, q = w.rd(x), w.rd(y)
+            out = np.zeros(64, dtype=np.uint32)
+            for sh in (0, 16):
+                pa = ((p >> sh) & 0xffff).astype(np.int64)
+                qa = ((q >> sh) & 0xffff).astype(np.int64)
+                out |= (f(pa, qa) & 0xffff).astype(np.uint32) << sh
+            w.wr(d, out)
+        self._valu(f"{name} {_txt(d)}, {_txt(x)}, {_txt(y)}{suffix}", fn)
+
+    def v_pk_min_u16(self, d, x, y):
+        self._pk16("v_pk_min_u16", d, x, y, np.minimum)
+
+    def v_pk_sub_u16(self, d, x, y, clamp=False):
+        """per 16-bit half x - y; clamp: saturate at 0"""
+        if clamp:
+            self._pk16("v_pk_sub_u16", d, x, y, lambda p, q: np.maximum(p - q, 0), " clamp")
+        else:
+            self._pk16("v_pk_sub_u16", d, x, y, lambda p, q: p - q)
+
+    def v_bfe_i32(self, d, x, off, width):
+        def fn(w):
+            p = w.rd(x).astype(np.int64)
+            o, wd = w.rd(off).astype(np.int64) & 31, w.rd(width).astype(np.int64) & 31
+            val = (p >> o) & ((1 << wd) - 1)
+            sign = (val >> (wd - 1)) & 1
+            val = np.where(sign == 1, val - (1 << wd), val)
+            w.wr(d, (val & 0xffffffff).astype(np.uint32))
+        self._valu(f"v_bfe_i32 {_txt(d)}, {_txt(x)}, {_txt(off)}, {_txt(width)}", fn)
+
+    def v_bfi_b32(self, d, m, x, y):
+        """(m & x) | (~m & y)"""
+        self._v3("v_bfi_b32", d, m, x, y, lambda p, q, r: (p & q) | ((p ^ 0xffffffff) & r))
+
+    def v_permlane32_swap(self, x, y):
+        """swap x[lanes 32..63] with y[lanes 0..31] (a VALU write of x or y needs a wait state before it: padded here)"""
+        self.s_nop(1)
+
+        def fn(w):
+            a_, b_ = w.rd(x), w.rd(y)
+            na, nb_ = a_.copy(), b_.copy()
+            na[32:] = b_[:32]
+            nb_[:32] = a_[32:]
+            w.wr(x, na, masked=False)
+            w.wr(y, nb_, masked=False)
+        self._valu(f"v_permlane32_swap_b32 {_txt(x)}, {_txt(y)}", fn)
 
     def v_cmp_u32(self, op, d, x, y):
         """d: VCC or an SGPR pair (e64)"""

@@ -49,7 +49,7 @@ S_LDC, S_CMASK, S_N, S_ALPHA, S_NPANELS, S_BITS = s(20, 2), s(22), s(23), s(24),
 S_KEY, S_THR, S_SCALE, S_ROWMULT, S_SEEDDEV, S_STREAMKEY, S_GRID = s(28), s(29), s(30), s(31), s(32, 2), s(34), s(35)
 S_WID = s(36)
 S_LDA2, S_LDC2, S_LDR2 = s(37), s(38), s(39)
-SRD_X, SRD_C, SRD_R, SRD_T = s(40, 4), s(48, 4), s(52, 4), s(56, 4)
+SRD_X, SRD_C, SRD_T = s(40, 4), s(48, 4), s(56, 4)
 S_DUM, S_NEXTN0 = s(44), s(45)        # dummy steps left; n0 of the next step
 S_P, S_PN = s(60), s(61)              # panel being accumulated; panel whose A is being fetched
 S_LOOP = s(62)
@@ -63,8 +63,12 @@ S_NB4 = s(79)                         # 4 * n0 of the next step (bias table offs
 S_STMASK = s(80, 2)                   # exec mask of the epilogue stores (0 until this wave's first n-step has been computed)
 S_T = [s(82 + i) for i in range(8)]   # scratch
 S_WPTR = s(90, 2)                     # address of the next W row this wave fetches
-S_RROW = [s(92 + i) for i in range(8)]   # residual row offsets (w*64 + mb*32 + 8 it) * ldr2
-N_SGPR = 100
+SRD_B = s(92, 4)                      # sign-bit buffer of the panel being stored (bits_out) / accumulated (bits_in)
+S_BROW = [s(96), s(97)]               # (w*2 + mb) * N * 4: byte offset of the wave's slab row-block in the panel's sign bits
+S_RN2, S_PPE = s(98), s(99)           # row_mult * N / 2 (dropout pairs per row); pair index of row 0 of the panel whose epilogue is running
+S_ONE1, S_THR1, S_C1, S_RN32 = s(52), s(53), s(54), s(55)      # 0x00010001; (thr - 1) in both halves; 0x9E3779B1; 32 * S_RN2
+S_LO32 = s(100, 2)                    # exec mask of lanes 0..31
+N_SGPR = 102
 
 
 # ---- VGPRs
@@ -85,9 +89,16 @@ V_LANE16, V_DMATMP = v(200), v(201)
 V_COFF, V_CSTEP, V_STW, V_STRD, V_BIASRD, V_BIASSTEP = v(202), v(203), v(204), v(205), v(206), v(207)
 V_XOFF = [v(208), v(209)]
 V_STWX = v(210)                       # staging write address of the current 8-byte piece
-V_PK = [v(212 + 2 * i, 2) for i in range(8)]       # converted pieces
-V_RB = [[v(228 + 4 * i, 4) for i in range(4)], [v(240 + 4 * i, 4) for i in range(4)]]      # read-back (row-major) pieces = store data, per slab (v240.. double as prologue temporaries)
+V_PK = [v(212 + 2 * i, 2) for i in range(4)]       # converted pieces (rotating: a ds_write has read its data long before the pair comes round again)
+V_RB = [[v(220 + 4 * i, 4) for i in range(4)]] * 2      # read-back (row-major) pieces = store data (slab 0's stores are issued before slab 1's reads)
+V_L0, V_C8, V_H4 = v(236), v(237), v(211)           # flavour lane constants: dropout pair index of (row, 4 h); 8 * (lane & 31); 4 * (lane >> 5)
+V_F = [v(238 + i) for i in range(18)]               # flavour temporaries (v244.. double as prologue temporaries)
 V_TMP = [v(244 + i) for i in range(12)]
+
+
+def BW(par, mb):
+    """ReLU sign-bit words of a 32-row x 64-column slab as loaded (flavour bits_in has no bias: the bias registers' space)"""
+    return v(128 + (par * 2 + mb) * 2, 2)
 
 
 def XFRAG(mb, ks):
@@ -117,12 +128,17 @@ class QModel:
 
 class NtAsGen:
     CAP = 3            # filler groups per MFMA gap taken from the streams (fixed-slot instructions come on top)
+    PF_GAP = 24        # bits_in: the sign-bit words of this step's slabs are requested here (consumed ~100 gaps later)
     DMA_END = 72       # the last LDS-DMA piece of the next tile is issued by this gap (~1.5 k cycles before the barrier)
     BAR_GAP = 119      # the barrier follows MFMA 119 (k-step 29); the last fragment reads of the tile are issued at gaps 113 / 115
 
-    def __init__(self, name="svla_nt_as_f0", act=0, aux=0, drop=False, bits_out=False, alpha=False, cap=None, dbg="", stagger=0, epi_order=1, dma_end=None):
+    def __init__(self, name="svla_nt_as_f0", relu=False, drop=False, bits_out=False, bits_in=False, cap=None, dbg="", stagger=0, epi_order=1, dma_end=None):
         self.name = name
-        self.act, self.aux, self.drop, self.bits_out, self.alpha = act, aux, drop, bits_out, alpha
+        # epilogue flavour: relu (+ bits_out: the output's sign bits, + drop: train-mode dropout after the activation) | bits_in: alpha * product,
+        # zeroed where the ReLU sign bit of the forward activation is 0 (no bias) | none of them: + bias
+        self.relu, self.drop, self.bits_out, self.bits_in = relu, drop, bits_out, bits_in
+        self.bias = not bits_in
+        assert not (bits_in and (relu or drop or bits_out)) and (not bits_out or relu) and (not drop or relu)
         self.dbg = set(dbg.split(",")) if dbg else set()      # timing-only / bisection builds (tools/): time, nostore, nodma, nox, noepi, ...
         if cap is not None:
             self.CAP = cap
@@ -200,12 +216,11 @@ class NtAsGen:
             for it in range(4):
                 p.s_add_u32(S_T[1], S_T[0], mb * 32 + 8 * it)
                 p.s_mul_i32(S_CROW[mb * 4 + it], S_T[1], S_LDC2)
-                p.s_mul_i32(S_RROW[mb * 4 + it], S_T[1], S_LDR2)
         # descriptors: bias table source; A / C / residual per panel
         p.s_mov_b32(SRD_T.sub(0), S_BIAS.sub(0))
         p.s_and_b32(SRD_T.sub(1), S_BIAS.sub(1), 0xffff)
         p.s_mov_b32(SRD_T.sub(3), 0x00020000)
-        for srd in (SRD_X, SRD_C, SRD_R):
+        for srd in (SRD_X, SRD_C, SRD_B):
             p.s_mov_b32(srd.sub(2), 0xffffffff)
             p.s_mov_b32(srd.sub(3), 0x00020000)
         # ---- lane constants
@@ -241,23 +256,41 @@ class NtAsGen:
             p.v_add_u32(T[8], mb * 32, T[2])
             p.v_mul_lo_u32(T[8], T[8], S_LDA2)
             p.v_lshl_add_u32(V_XOFF[mb], T[3], 4, T[8])
-        # ---- bias table -> LDS (the host always passes a bias pointer: zeros when the GEMM has none)
-        p.v_lshlrev_b32(T[8], 2, v(0))
-        p.v_add_u32(T[9], LDS_BIAS, T[8])
-        p.s_mov_b32(S_T[3], 0)
-        p.s_lshl_b32(S_T[4], S_N, 2)
-        p.s_mov_b32(SRD_T.sub(2), S_T[4])           # num_records = 4 N: reads past bias[N) return 0
-        p.label("L_BIAS")
-        if "nobias" in self.dbg:
-            p.v_mov_b32(T[10], 0)
-        else:
-            p.buffer_load(T[10], T[8], SRD_T, S_T[3])
-        p.s_waitcnt(vmcnt=0)
-        p.ds_write(T[9], T[10])
-        p.v_add_u32(T[9], 1024, T[9])
-        p.s_add_u32(S_T[3], S_T[3], 1024)
-        p.s_cmp("lt_u32", S_T[3], S_T[4])
-        p.s_cbranch_scc1("L_BIAS")
+        # ---- flavour constants
+        p.s_mov_b32(S_LO32.sub(0), 0xffffffff)
+        p.s_mov_b32(S_LO32.sub(1), 0)
+        p.v_lshlrev_b32(V_H4, 2, T[3])              # 4 h
+        p.v_lshlrev_b32(V_C8, 3, T[2])              # 8 c
+        p.s_lshl_b32(S_T[0], S_WID, 1)
+        for mb in range(2):
+            p.s_add_u32(S_T[1], S_T[0], mb)
+            p.s_mul_i32(S_T[1], S_T[1], S_N)
+            p.s_lshl_b32(S_BROW[mb], S_T[1], 2)     # (w*2 + mb) * (N/64) * 256
+        if self.drop:
+            p.s_mul_i32(S_RN2, S_ROWMULT, S_N)
+            p.s_lshr_b32(S_RN2, S_RN2, 1)
+            p.s_lshl_b32(S_RN32, S_RN2, 5)
+            p.s_mov_b32(S_ONE1, 0x00010001)
+            p.s_sub_u32(S_T[1], S_THR, 1)
+            p.s_mul_i32(S_THR1, S_T[1], S_ONE1)      # (thr - 1) in both halves (thr <= 0xffff)
+            p.s_mov_b32(S_C1, 0x9E3779B1)
+            # pair index of (row w*64 + c of the panel, column 4 h): ((w*64 + c) * row_mult * N + 4 h) / 2; the host guarantees < 2^32 pairs
+            p.s_lshl_b32(S_T[1], S_WID, 6)
+            p.v_add_u32(T[8], S_T[1], T[2])
+            p.v_mul_lo_u32(T[8], T[8], S_RN2)
+            p.v_lshl_add_u32(V_L0, T[3], 1, T[8])
+            # device-resident pass seed (recorded launch sequences): key = *seed_dev ^ stream_key
+            p.s_or_b32(S_T[1], S_SEEDDEV.sub(0), S_SEEDDEV.sub(1))
+            p.s_cmp("eq_u32", S_T[1], 0)
+            p.s_cbranch_scc1("L_KEYOK")
+            p.s_load(S_KEY, S_SEEDDEV, 0)
+            p.s_waitcnt(lgkmcnt=0)
+            p.s_xor_b32(S_KEY, S_KEY, S_STREAMKEY)
+            p.label("L_KEYOK")
+        elif self.bits_out:
+            p.s_mov_b32(S_ONE1, 0x00010001)
+        if self.bias:
+            self.bias_table()
         # ---- phase of this wave: phi = w * NS/4 + (workgroup & cmask) dummy steps before its first panel, (3 - w) * NS/4 after its last
         p.s_lshr_b32(S_T[0], S_N, 8)                # NS / 4
         p.s_mul_i32(S_DUM, S_WID, S_T[0])
@@ -300,14 +333,36 @@ class NtAsGen:
             p.s_waitcnt(lgkmcnt=0)
             p.s_mov_b32(s(28), s(0))
         p.s_barrier()
-        p.s_lshl_b32(S_T[2], S_N0, 2)
-        p.v_add_u32(V_BIASSTEP, S_T[2], V_BIASRD)
-        for nb in range(2):
-            for rg in range(4):
-                p.ds_read(BIASR(nb).sub(4 * rg, 4), V_BIASSTEP, nb * 128 + rg * 32)
+        if self.bias:
+            p.s_lshl_b32(S_T[2], S_N0, 2)
+            p.v_add_u32(V_BIASSTEP, S_T[2], V_BIASRD)
+            for nb in range(2):
+                for rg in range(4):
+                    p.ds_read(BIASR(nb).sub(4 * rg, 4), V_BIASSTEP, nb * 128 + rg * 32)
         for ks in range(3):
             for nb in range(2):
                 self.wread(ks, nb)
+
+    def bias_table(self):
+        """bias[N] -> LDS (the host always passes a bias pointer: zeros when the GEMM has none)"""
+        p = self.p
+        T = V_TMP
+        p.v_lshlrev_b32(T[8], 2, v(0))
+        p.v_add_u32(T[9], LDS_BIAS, T[8])
+        p.s_mov_b32(S_T[3], 0)
+        p.s_lshl_b32(S_T[4], S_N, 2)
+        p.s_mov_b32(SRD_T.sub(2), S_T[4])           # num_records = 4 N: reads past bias[N) return 0
+        p.label("L_BIAS")
+        if "nobias" in self.dbg:
+            p.v_mov_b32(T[10], 0)
+        else:
+            p.buffer_load(T[10], T[8], SRD_T, S_T[3])
+        p.s_waitcnt(vmcnt=0)
+        p.ds_write(T[9], T[10])
+        p.v_add_u32(T[9], 1024, T[9])
+        p.s_add_u32(S_T[3], S_T[3], 1024)
+        p.s_cmp("lt_u32", S_T[3], S_T[4])
+        p.s_cbranch_scc1("L_BIAS")
 
     def panel_srd(self, srd, base, panel, ld2):
         """srd.base = base + panel * 256 * ld2 (64-bit); one group: the carry travels through SCC"""
@@ -318,6 +373,24 @@ class NtAsGen:
         p.s_add_u32(srd.sub(0), base.sub(0), S_T[5])
         p.s_addc_u32(S_T[6], base.sub(1), S_T[6])
         p.s_and_b32(srd.sub(1), S_T[6], 0xffff)
+
+    def bits_srd(self, panel):
+        """SRD_B.base = bits + panel * 8 slab rows * (N/64) slabs * 256 B = bits + panel * N * 32"""
+        p = self.p
+        p.s_mul_i32(S_T[5], panel, S_N)
+        p.s_lshl_b32(S_T[5], S_T[5], 5)
+        p.s_add_u32(SRD_B.sub(0), S_BITS.sub(0), S_T[5])
+        p.s_addc_u32(S_T[6], S_BITS.sub(1), 0)
+        p.s_and_b32(SRD_B.sub(1), S_T[6], 0xffff)
+
+    def flavour_panel_scalars(self):
+        """quantities of the panel whose epilogue runs from now on (set where SRD_C is)"""
+        p = self.p
+        if self.bits_out:
+            self.bits_srd(S_P)
+        if self.drop:
+            p.s_lshl_b32(S_T[5], S_P, 8)
+            p.s_mul_i32(S_PPE, S_T[5], S_RN2)
 
     def dma_groups(self, t):
         """LDS-DMA of row (w*16 + t) of the next W tile, as scheduler groups"""
@@ -409,16 +482,120 @@ class NtAsGen:
             items.append((e, list(ths)))
         add(lambda: p.v_add_u32(V_CSTEP, S_NE2, V_COFF))
 
+        C1 = 0x9E3779B1
+        F = V_F
+        VS, X, TT, MSK, A1, OBW = F[0:4], F[4], F[5], F[6], F[7], [F[8], F[9]]      # OBW: an even-aligned pair (one 8-byte store)
+        U, U2 = F[10], F[11]
+        BS = [F[12], F[13]]
+        par = st          # accumulator set whose epilogue this is = parity of the sign-bit words prefetched for it
+
+        def step_scalars():
+            # per-step scalars of the epilogue's slabs: dropout pair offsets, sign-bit slab offsets
+            if self.drop:
+                p.s_lshr_b32(S_T[0], S_NE2, 2)
+                p.s_add_u32(S_T[0], S_T[0], S_PPE)
+                p.s_add_u32(S_T[1], S_T[0], S_RN32)
+            if self.bits_out:
+                p.s_lshl_b32(S_T[2], S_NE2, 1)
+                p.s_add_u32(S_T[3], S_T[2], S_BROW[1])
+                p.s_add_u32(S_T[2], S_T[2], S_BROW[0])
+        if self.drop or self.bits_out:
+            add(step_scalars)
+
         def convert(mb):
+            if self.drop:
+                # A1 = pair index of (this lane's row, column n0 + 4 h) times C1; pair c of the slab row: (A1 + c C1) ^ key -> drop_mix
+                add(lambda mb=mb: p.v_add_u32(A1, S_T[mb], V_L0))
+                add(lambda: p.v_mul_lo_u32(A1, A1, S_C1))
+            if self.bits_in:
+                def shift(mb=mb):
+                    self.wait_for(vm_tags=[f"bw{par}_{mb}"])
+                    for nb in range(2):
+                        p.v_lshrrev_b32(BS[nb], V_H4, BW(par, mb).sub(nb))      # bit 8 rg + e = the sign bit of column nb*32 + 8 rg + 4 h + e
+                add(shift)
             for nb in range(2):
                 for rg in range(4):
                     gi = nb * 4 + rg
                     acc = ACC(st, nb, mb)
-                    pk = V_PK[gi]
-                    add(lambda acc=acc, pk=pk, rg=rg: p.v_cvt_pk_bf16_f32(pk.sub(0), acc.sub(4 * rg), acc.sub(4 * rg + 1)))
-                    add(lambda acc=acc, pk=pk, rg=rg: p.v_cvt_pk_bf16_f32(pk.sub(1), acc.sub(4 * rg + 2), acc.sub(4 * rg + 3)))
+                    pk = V_PK[gi % 4]
+                    for pr in range(2):
+                        src = [acc.sub(4 * rg + 2 * pr), acc.sub(4 * rg + 2 * pr + 1)]
+                        if self.bits_in:
+                            def masked_pair(src=src, pr=pr, nb=nb, rg=rg, pk=pk):
+                                for e in range(2):
+                                    p.v_bfe_i32(TT, BS[nb], 8 * rg + 2 * pr + e, 1)
+                                    p.v_mul_f32(VS[e], S_ALPHA, src[e])
+                                    p.v_and_b32(VS[e], TT, VS[e])
+                                p.v_cvt_pk_bf16_f32(pk.sub(pr), VS[0], VS[1])
+                            add(masked_pair)
+                            continue
+                        if self.drop:
+                            c = nb * 16 + rg * 4 + pr
+
+                            def hash_pair(c=c):
+                                p.v_add_u32(X, (c * C1) & 0xffffffff, A1)
+                                p.v_xor_b32(X, S_KEY, X)
+                                p.v_lshrrev_b32(TT, 16, X)
+                                p.v_xor_b32(X, TT, X)
+                                p.v_mul_u32_u24(X, 0xEB352D, X)
+                                p.v_lshrrev_b32(TT, 13, X)
+                                p.v_xor_b32(X, TT, X)
+                                p.v_mul_u32_u24(X, 0x6CA68B, X)
+                                p.v_lshrrev_b32(TT, 16, X)
+                                p.v_xor_b32(X, TT, X)
+                            add(hash_pair)
+
+                            def keep_mask():
+                                # per 16-bit half: all ones where the half >= thr (kept): sat(half - (thr - 1)) != 0
+                                p.v_pk_sub_u16(MSK, X, S_THR1, clamp=True)
+                                p.v_pk_min_u16(MSK, MSK, S_ONE1)
+                                p.v_pk_sub_u16(MSK, 0, MSK)
+                            add(keep_mask)
+
+                            def scaled(src=src, pr=pr, pk=pk):
+                                p.v_mul_f32(VS[0], S_SCALE, src[0])
+                                p.v_mul_f32(VS[1], S_SCALE, src[1])
+                                p.v_cvt_pk_bf16_f32(pk.sub(pr), VS[0], VS[1])
+                            add(scaled)
+                            add(lambda pk=pk, pr=pr: (p.v_pk_max_i16(pk.sub(pr), pk.sub(pr), 0), p.v_and_b32(pk.sub(pr), MSK, pk.sub(pr))))
+                        else:
+                            add(lambda src=src, pk=pk, pr=pr: p.v_cvt_pk_bf16_f32(pk.sub(pr), src[0], src[1]))
+                            if self.relu:
+                                add(lambda pk=pk, pr=pr: p.v_pk_max_i16(pk.sub(pr), pk.sub(pr), 0))      # negative halves (and -0) -> +0
+                    if self.bits_out:
+                        def signbits(pk=pk, nb=nb, rg=rg):
+                            # outputs are >= +0: min(half, 1) per half, the four bits folded into a nibble at bit 8 rg of the slab row's word
+                            p.v_pk_min_u16(U, pk.sub(0), S_ONE1)
+                            p.v_pk_min_u16(U2, pk.sub(1), S_ONE1)
+                            p.v_lshl_or_b32(U, U2, 2, U)
+                            p.v_lshrrev_b32(U2, 15, U)
+                            p.v_or_b32(U, U2, U)
+                            p.v_and_b32(U, 15, U)
+                            if rg == 0:
+                                p.v_mov_b32(OBW[nb], U)
+                            else:
+                                p.v_lshl_or_b32(OBW[nb], U, 8 * rg, OBW[nb])
+                        add(signbits)
                     add(lambda gi=gi: p.v_xor_b32(V_STWX, gi << 4, V_STW))
                     add(lambda pk=pk: self.ds_write(V_STWX, pk))
+            if self.bits_out:
+                def bits_store(mb=mb):
+                    # lanes c and c + 32 hold the two interleaved nibble sets of row c: shift into place, merge, ONE 8-byte store per row
+                    for nb in range(2):
+                        p.v_lshlrev_b32(OBW[nb], V_H4, OBW[nb])
+                        p.v_mov_b32(U, OBW[nb])
+                        p.v_permlane32_swap(OBW[nb], U)
+                        p.v_or_b32(OBW[nb], U, OBW[nb])      # lanes 0..31: own | partner's
+                    if "nostore" in self.dbg:
+                        return
+                    if masked:
+                        p.s_and_b64(EXEC, S_STMASK, S_LO32)
+                    else:
+                        p.s_mov_b64(EXEC, S_LO32)
+                    p.buffer_store(v(OBW[0].idx, 2), V_C8, SRD_B, S_T[2 + mb])
+                    self.vm.issue(self.tag("stb"))
+                    p.s_mov_b64(EXEC, -1)
+                add(bits_store)
 
         def readback(mb):
             tags = []
@@ -482,6 +659,17 @@ class NtAsGen:
 
         # ---- LDS-DMA of the next tile
         self.step_head()
+        if self.bits_in:
+            if kind == "first":
+                self.bits_srd(S_P)
+            # sign-bit words of this step's two slabs (consumed by its epilogue, in the next step): 8 bytes per lane = the slab row's word
+            def prefetch_bits():
+                for mb in range(2):
+                    p.s_lshl_b32(S_T[4], S_N0, 2)
+                    p.s_add_u32(S_T[4], S_T[4], S_BROW[mb])
+                    p.buffer_load(BW(st, mb), V_C8, SRD_B, S_T[4])
+                    self.vm.issue(f"bw{st}_{mb}")
+            fixed[self.PF_GAP].append(prefetch_bits)
         dma = []
         for t in range(16):
             for grp in self.dma_groups(t):
@@ -507,18 +695,19 @@ class NtAsGen:
                 pre[4 * ks].append(("vm", f"x{ks}"))
 
         # ---- epilogue of the previous step, bias registers of the next step, then the bookkeeping that must follow the epilogue
-        late = [(16, [lambda: p.v_add_u32(V_BIASSTEP, S_NB4, V_BIASRD)])]
-        for nb in range(2):
-            for rg in range(4):
-                late.append((16, [lambda nb=nb, rg=rg: self.ds_read(BIASR(nb).sub(4 * rg, 4), V_BIASSTEP, nb * 128 + rg * 32, self.tag("bias"))]))
+        late = []
+        if self.bias:
+            late.append((16, [lambda: p.v_add_u32(V_BIASSTEP, S_NB4, V_BIASRD)]))
+            for nb in range(2):
+                for rg in range(4):
+                    late.append((16, [lambda nb=nb, rg=rg: self.ds_read(BIASR(nb).sub(4 * rg, 4), V_BIASSTEP, nb * 128 + rg * 32, self.tag("bias"))]))
         epi = self.epi_stream(st ^ 1, masked=(kind == "first"), earliest=8, late=late) if "noepi" not in self.dbg else late
         epi.append((16, [self.step_tail_scalars]))
         if kind == "first":
             def first_tail():
                 p.s_mov_b64(S_STMASK, -1)
                 self.panel_srd(SRD_C, S_C, S_P, S_LDC2)
-                if self.aux == 1:
-                    self.panel_srd(SRD_R, S_RES, S_P, S_LDR2)
+                self.flavour_panel_scalars()
                 p.s_lshr_b32(S_LOOP, S_N, 7)
                 p.s_sub_u32(S_LOOP, S_LOOP, 1)
             epi.append((16, [first_tail]))
@@ -538,7 +727,7 @@ class NtAsGen:
             if ks == 0:
                 lg_tags += [t for t in self.lg.q if t.startswith("bias")]
             self.wait_for(vm_tags=vm_tags, lg_tags=lg_tags)
-            c = BIASR(nb) if ks == 0 else ACC(st, nb, mb)
+            c = (BIASR(nb) if self.bias else 0) if ks == 0 else ACC(st, nb, mb)
             p.v_mfma_f32_32x32x16_bf16(ACC(st, nb, mb), WFRAG(ks, nb), XFRAG(mb, ks), c)
             for th in fixed[g]:
                 th()
@@ -577,10 +766,11 @@ class NtAsGen:
                     th()
         for j in range(8):
             p.v_xor_b32(V_WRD[j], 0x10000, V_WRD[j])
-        p.v_add_u32(V_BIASSTEP, S_NB4, V_BIASRD)          # the next step may be this wave's first real one: its accumulator initialiser
-        for nb in range(2):
-            for rg in range(4):
-                self.ds_read(BIASR(nb).sub(4 * rg, 4), V_BIASSTEP, nb * 128 + rg * 32, self.tag("bias"))
+        if self.bias:
+            p.v_add_u32(V_BIASSTEP, S_NB4, V_BIASRD)          # the next step may be this wave's first real one: its accumulator initialiser
+            for nb in range(2):
+                for rg in range(4):
+                    self.ds_read(BIASR(nb).sub(4 * rg, 4), V_BIASSTEP, nb * 128 + rg * 32, self.tag("bias"))
         self.barrier("dummy")
         for k in range(3):
             for nb in range(2):
@@ -597,6 +787,10 @@ class NtAsGen:
         self.dummy_body()
         p.s_sub_u32(S_DUM, S_DUM, 1)
         p.s_branch("L_DUMA")
+        # the first generated body (LAST) is entered from a MID step at run time: seed the queue models with what such a step leaves behind
+        real, self.p = self.p, Prog("scratch")
+        self.body("mid", 0)
+        self.p = real
         p.label("L_LAST")
         self.body("last", 1)
         p.s_add_u32(S_P, S_P, S_GRID)
@@ -716,13 +910,18 @@ amdhsa.kernels:
 
 # flavour -> generator options (the C dispatcher nt_as_try of csrc/gemm.hip picks by name)
 FLAVOURS = {
-    "f0": dict(),                                  # bias (or none): in_proj forward, out_proj input gradient
+    "f0": dict(),                                               # bias (or none): in_proj forward, out_proj input gradient
+    "f1d": dict(relu=True, bits_out=True, drop=True),           # bias, ReLU, dropout, sign bits out: linear1 forward in train mode
+    "f1": dict(relu=True, bits_out=True),                       # ... eval mode / visual compressor
+    "f3": dict(bits_in=True),                                   # alpha * product under the ReLU sign bits: input gradient through linear2 (+ dropout scale)
 }
 if _os.environ.get("SVLA_ASM_DEBUG_VARIANTS"):      # timing-only / bisection builds (tools/time_nt_as.py)
     for _d in ("time", "time,nostore", "time,nodma", "time,noepi", "time,nox", "time,nobarwait", "time,noepi,nodma,nox"):
         FLAVOURS["f0_" + _d.replace(",", "_")] = dict(dbg=_d)
     for _k, _o in (("d40", dict(dma_end=40)), ("d56", dict(dma_end=56)), ("d90", dict(dma_end=90)), ("d104", dict(dma_end=104)), ("s8", dict(stagger=8)), ("e0", dict(epi_order=0))):
         FLAVOURS["f0_" + _k] = _o
+    for _k in ("f1d", "f1", "f3"):
+        FLAVOURS[_k + "_time"] = dict(FLAVOURS[_k], dbg="time") if _k != "f1d" else FLAVOURS[_k]
 
 
 def generate(flavour="f0"):

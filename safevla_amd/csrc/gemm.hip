@@ -970,7 +970,14 @@ static int nt_as_try(const GemmNtArgs& p, hipStream_t stream) {
     if (npanels < 512 && g_force_small_tile != 2) return NT_AS_NOT_TAKEN;      // fewer than two panels per CU: the tile kernels balance better
     if (npanels < 1) return NT_AS_NOT_TAKEN;
     const char* name = nullptr;
-    if (p.act == ACT_NONE && !p.residual && !p.bits_in && !p.bits_out && !p.drop.thr && p.alpha == 1.f) name = "svla_nt_as_f0";
+    if (p.residual) return NT_AS_NOT_TAKEN;
+    if (p.bits_in) {      // input gradient under the ReLU sign bits (+ dropout scale as alpha): no bias
+        if (p.act == ACT_NONE && !p.bias && !p.drop.thr && !p.bits_out) name = "svla_nt_as_f3";
+    } else if (p.act == ACT_RELU && p.bits_out && p.alpha == 1.f) {
+        // the dropout counter of the assembly kernel is 32 bits wide: element pairs of the whole logical tensor must fit
+        if (!p.drop.thr) name = "svla_nt_as_f1";
+        else if ((unsigned long long)p.M * (unsigned long long)p.drop.row_mult * (unsigned long long)p.N / 2 < 0xffffffffull) name = "svla_nt_as_f1d";
+    } else if (p.act == ACT_NONE && !p.bits_out && !p.drop.thr && p.alpha == 1.f) name = "svla_nt_as_f0";
     static char dbg_name[96];
     if (name && getenv("SVLA_NT_AS_VARIANT")) {      // fault-bisection builds of tools/: svla_nt_as_f0_<variant>
         snprintf(dbg_name, sizeof(dbg_name), "%s_%s", name, getenv("SVLA_NT_AS_VARIANT"));

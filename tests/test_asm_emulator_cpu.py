@@ -1,0 +1,120 @@
+"""The generated gfx950 assembly GEMM kernels (safevla_amd/asmgen/nt_as_gen.py) executed instruction by instruction in the lane-accurate
+emulator of asmgen/amdasm.py (asynchronous loads land only at the s_waitcnt that retires them; LDS-DMA targets are poisoned until then),
+against a numpy restatement of the epilogues of csrc/gemm.hip (reference layers: nn.TransformerEncoderLayer linears of
+architecture/models/allenact_transformer_models/allenact_dino_transformer.py:545-552).  CPU only: this is what validates a schedule
+before it is ever run on a GPU; tests/test_kernels_gpu.py compares the same kernels with the HIP kernels on hardware."""
+import struct
+
+import numpy as np
+import pytest
+
+from safevla_amd.asmgen import nt_as_gen as G
+from safevla_amd.asmgen.amdasm import Emu, bf16_to_f32, f32_to_bf16_rne
+
+K = 512
+
+
+def _bf16(x):
+    return f32_to_bf16_rne(np.asarray(x, dtype=np.float32)).astype(np.uint16)
+
+
+def _drop_keep(M, N, key, thr, row_mult):
+    """keep[m, n] of svla_dropout (csrc/common.h drop_bits / drop_mix) for element index (m * row_mult) * N + n"""
+    e = (np.arange(M, dtype=np.uint64)[:, None] * np.uint64(row_mult * N) + np.arange(N, dtype=np.uint64)[None, :])
+    pair = e >> np.uint64(1)
+    x = ((pair & np.uint64(0xffffffff)) * np.uint64(0x9E3779B1)) & np.uint64(0xffffffff)
+    x ^= (((pair >> np.uint64(32)) * np.uint64(0x85EBCA77)) & np.uint64(0xffffffff))
+    x ^= np.uint64(key)
+    x ^= x >> np.uint64(16)
+    x = ((x & np.uint64(0xffffff)) * np.uint64(0xEB352D)) & np.uint64(0xffffffff)
+    x ^= x >> np.uint64(13)
+    x = ((x & np.uint64(0xffffff)) * np.uint64(0x6CA68B)) & np.uint64(0xffffffff)
+    x ^= x >> np.uint64(16)
+    r = np.where((e & np.uint64(1)) == 0, x & np.uint64(0xffff), x >> np.uint64(16))
+    return r >= np.uint64(thr)
+
+
+def _bits_pack(pos, N):
+    """[M, N] bool -> the blocked sign-bit layout of relu_bits_word (csrc/gemm.hip): [M/32][N/64][32 rows][8 bytes]"""
+    M = pos.shape[0]
+    b = np.packbits(pos.reshape(M // 32, 32, N // 64, 64), axis=-1, bitorder="little")       # [M/32, 32, N/64, 8]
+    return np.ascontiguousarray(b.transpose(0, 2, 1, 3)).reshape(-1)
+
+
+def run_kernel(flavour, M, N, grid, order=None, seed=0, alpha=1.0, key=0x1234567, p_drop=0.1, row_mult=1, gen_kw=None):
+    g = G.NtAsGen(name="t", **dict(G.FLAVOURS[flavour], **(gen_kw or {})))
+    g.build()
+    rs = np.random.RandomState(seed)
+    X = _bf16(rs.standard_normal((M, K)))
+    W = _bf16(rs.standard_normal((N, K)) * 0.05)
+    bias = rs.standard_normal(N).astype(np.float32) if g.bias else np.zeros(N, dtype=np.float32)
+    C = np.full((M, N), 0x7fc0, dtype=np.uint16)
+    thr = int(p_drop * 65536 + 0.5)
+    scale = np.float32(1.0 / (1.0 - p_drop))
+    bits_in_bool = rs.rand(M, N) < 0.6
+    bits = _bits_pack(bits_in_bool, N) if g.bits_in else np.zeros(M * N // 8, dtype=np.uint8)
+    npanels = M // 256
+    q = max(N // 256, 1)
+    cmask = (1 << (q.bit_length() - 1)) - 1
+    for wg in range(min(grid, npanels)):
+        emu = Emu(g.p)
+        aX, aW, aB, aC, aBits = emu.alloc(X), emu.alloc(W), emu.alloc(bias), emu.alloc(C, writable=True), emu.alloc(bits, writable=True)
+        ka = bytearray(G.KARG_BYTES)
+
+        def put(name, fmt, val):
+            struct.pack_into(fmt, ka, G.KARG[name], val)
+        put("A", "<Q", aX); put("lda", "<q", K); put("B", "<Q", aW); put("ldb", "<q", K); put("bias", "<Q", aB)
+        put("C", "<Q", aC); put("ldc", "<q", N); put("cmask", "<i", cmask); put("N", "<i", N); put("alpha", "<f", alpha)
+        put("npanels", "<i", npanels); put("grid", "<i", grid); put("bits", "<Q", aBits)
+        put("key", "<I", key); put("thr", "<I", thr); put("scale", "<f", float(scale)); put("row_mult", "<i", row_mult)
+        emu.run(ka, wg, order=order)
+    acc = (bf16_to_f32(X).astype(np.float64) @ bf16_to_f32(W).astype(np.float64).T).astype(np.float32)
+    out = bf16_to_f32(C)
+    if g.bits_in:
+        ref = np.where(bits_in_bool, acc * np.float32(alpha), np.float32(0))
+    else:
+        ref = acc + bias
+        if g.drop:
+            ref = np.where(_drop_keep(M, N, key, thr, row_mult), ref * scale, np.float32(0))
+        if g.relu:
+            ref = np.maximum(ref, 0)
+    return out, ref, bits, g
+
+
+def check(out, ref):
+    assert not np.isnan(out).any(), f"{int(np.isnan(out).sum())} NaNs (a read of LDS-DMA data that had not landed, or an unwritten output)"
+    err = np.abs(out - ref)
+    tol = 2.0 ** -7 * np.abs(ref) + 2e-2          # one bf16 rounding + fp32 accumulation order
+    assert (err <= tol).all(), f"{int((err > tol).sum())} elements off, max {err.max()}"
+
+
+@pytest.mark.parametrize("order", [None, [3, 2, 1, 0]])
+def test_nt_as_bias_two_panels_both_wave_orders(order):
+    out, ref, _, _ = run_kernel("f0", 512, 512, 1, order=order)
+    check(out, ref)
+
+
+def test_nt_as_bias_three_workgroups_rotated_tiles():
+    out, ref, _, _ = run_kernel("f0", 768, 1024, 3)
+    check(out, ref)
+
+
+def test_nt_as_relu_signbits():
+    out, ref, bits, _ = run_kernel("f1", 512, 512, 1)
+    check(out, ref)
+    assert (bits == _bits_pack(out > 0, 512)).all()
+    assert (out >= 0).all()
+
+
+def test_nt_as_relu_dropout_signbits_matches_the_dropout_counter():
+    out, ref, bits, _ = run_kernel("f1d", 512, 512, 2, row_mult=3)
+    check(out, ref)
+    assert (bits == _bits_pack(out > 0, 512)).all()
+    kept = _drop_keep(512, 512, 0x1234567, int(0.1 * 65536 + 0.5), 3)
+    assert (out[~kept] == 0).all() and 0.85 < kept.mean() < 0.95
+
+
+def test_nt_as_signbit_mask_alpha():
+    out, ref, _, _ = run_kernel("f3", 512, 512, 1, alpha=1.0 / 0.9)
+    check(out, ref)
+    assert (out.view(np.uint32) != 0x80000000).all()          # masked elements are +0, as in the HIP kernels
