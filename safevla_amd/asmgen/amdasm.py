@@ -600,6 +600,16 @@ class Prog:
             w.wr(y, nb_, masked=False)
         self._valu(f"v_permlane32_swap_b32 {_txt(x)}, {_txt(y)}", fn)
 
+    def v_dot2c_f32_bf16(self, d, x, y):
+        """d += x.bf16[0] * y.bf16[0] + x.bf16[1] * y.bf16[1] (fp32)"""
+        def fn(w):
+            p, q = w.rd(x), w.rd(y)
+            acc = w.rd(d).view(np.float32).astype(np.float64)
+            for sh in (0, 16):
+                acc = acc + bf16_to_f32(((p >> sh) & 0xffff).astype(np.uint16)).astype(np.float64) * bf16_to_f32(((q >> sh) & 0xffff).astype(np.uint16)).astype(np.float64)
+            w.wr(d, acc.astype(np.float32).view(np.uint32))
+        self._valu(f"v_dot2c_f32_bf16 {_txt(d)}, {_txt(x)}, {_txt(y)}", fn)
+
     def v_cmp_u32(self, op, d, x, y):
         """d: VCC or an SGPR pair (e64)"""
         f = {"ge": np.greater_equal, "lt": np.less, "eq": np.equal, "ne": np.not_equal, "gt": np.greater, "le": np.less_equal}[op]
@@ -680,6 +690,37 @@ class Prog:
             if len(w.lgq) > 15:
                 raise EmuError(f"wave {w.wid}: more than 15 LGKM operations outstanding (4-bit counter)")
         self._add(f"{name} {_txt(d)}, {_txt(addr)}" + (f" offset:{off}" if off else ""), fn, "lds")
+
+    def ds_read_b64_tr_b16(self, d, addr, off=0):
+        """gfx950 transposed LDS read: within each group of 16 lanes, lane p addresses 4 contiguous bf16 = row p >> 2, column quad p & 3 of a
+        [4][16] block; lane i receives column i of the block (rows 0..3) as 4 bf16 = 2 dwords."""
+        assert d.n == 2 and 0 <= off <= 65535
+
+        def fn(w):
+            ad = self._ds_addr(w, addr, off)
+            lds = w.emu.lds
+            if np.any(ad % 8) or np.any(ad + 8 > lds.size):
+                raise EmuError(f"wave {w.wid}: misaligned / out-of-range transposed LDS read")
+            raw = np.stack([lds[ad + b] for b in range(8)], axis=1).astype(np.uint32)       # [64][8]
+            h = (raw[:, 0::2] | (raw[:, 1::2] << 8))                                         # [64][4] bf16 of the addressed quad
+            out = np.zeros((64, 4), dtype=np.uint32)
+            for l in range(64):
+                g, i = l & ~15, l & 15
+                for r in range(4):
+                    out[l, r] = h[g + 4 * r + (i >> 2), i & 3]
+            w.emu.lds_rd_bytes += 8 * 64
+            w._chk(d, "load-destination write")
+            w.mark(d)
+
+            def land():
+                w.unmark(d)
+                arr = w.V if d.kind == "v" else w.A
+                arr[d.idx] = out[:, 0] | (out[:, 1] << 16)
+                arr[d.idx + 1] = out[:, 2] | (out[:, 3] << 16)
+            w.lgq.append(land)
+            if len(w.lgq) > 15:
+                raise EmuError(f"wave {w.wid}: more than 15 LGKM operations outstanding (4-bit counter)")
+        self._add(f"ds_read_b64_tr_b16 {_txt(d)}, {_txt(addr)}" + (f" offset:{off}" if off else ""), fn, "lds")
 
     def ds_write(self, addr, src, off=0):
         nb = 4 * src.n
@@ -788,6 +829,23 @@ class Prog:
             w.retire(w.vmq, 63)
         self._add(f"global_load_lds_dwordx4 {_txt(voff)}, {_txt(sbase)}", fn, "vmem")
 
+    def buffer_atomic_add_f32(self, src, vaddr, srd, soff, off=0):
+        """no-return fp32 atomic add of src (one dword per lane)"""
+        assert src.n == 1 and 0 <= off <= 4095
+
+        def fn(w):
+            ad, rng, nrec = self._buf_addr(w, vaddr, srd, soff, off)
+            m = w.lanes()
+            vals = w.rd(src).view(np.float32).copy()
+
+            def land():
+                for l in np.nonzero(m)[0]:
+                    if rng[l] + 4 <= nrec:
+                        _atomic_add_f32(w.emu, int(ad[l]), vals[l])
+            w.vmq.append(land)
+            w.retire(w.vmq, 63)
+        self._add(f"buffer_atomic_add_f32 {_txt(src)}, {_txt(vaddr)}, {_txt(srd)}, {_txt(soff)} offen" + (f" offset:{off}" if off else ""), fn, "vmem")
+
     def buffer_store(self, src, vaddr, srd, soff, off=0, nt=False):
         nd = src.n
         name = {1: "buffer_store_dword", 2: "buffer_store_dwordx2", 4: "buffer_store_dwordx4"}[nd]
@@ -807,6 +865,11 @@ class Prog:
             w.vmq.append(land)
             w.retire(w.vmq, 63)          # 6-bit counter: the hardware stalls the issue until an older operation has returned
         self._add(f"{name} {_txt(src)}, {_txt(vaddr)}, {_txt(srd)}, {_txt(soff)} offen" + (f" offset:{off}" if off else "") + (" nt" if nt else ""), fn, "vmem")
+
+
+def _atomic_add_f32(emu, addr, val):
+    cur = emu.mem_read(addr, 4).view(np.float32)[0]
+    emu.mem_write(addr, np.array([np.float32(cur) + np.float32(val)], dtype=np.float32).view(np.uint8))
 
 
 class Emu:

@@ -1512,6 +1512,13 @@ extern "C" int svla_gemm_tn_f32acc(const bf16_t* dY, long ldy, const bf16_t* X, 
             HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_tn256_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
             attr256 = true;
         }
+        if (!(g_dbg & (128 | 8192)) && !g_svla_det.i64[0] && !g_svla_det.i64[1] && svla_asm_has("svla_tn_os")) {
+            // output-stationary assembly kernel (asmgen/tn_os_gen.py): 4 waves x 128 x 128 accumulators, 4-slot LDS-DMA ring
+            struct { const void* dY; long ldy; const void* X; long ldx; float* dW; long ldw; float* db; int M, N, K, chunk_rows, ntile, ntk, grid, pad; } k =
+                {dY, ldy, X, ldx, dW, ldw, db, M, N, K, chunk_rows, ntile256, K / 256, ntile256 * chunks, 0};
+            static_assert(sizeof(k) == 88, "kernarg layout of svla_tn_os");
+            return svla_asm_launch("svla_tn_os", &k, sizeof(k), ntile256 * chunks, 256, (hipStream_t)stream);
+        }
         if (!(g_dbg & 128)) {
             static bool attr8p = false;
             if (!attr8p) {

@@ -118,3 +118,42 @@ def test_nt_as_signbit_mask_alpha():
     out, ref, _, _ = run_kernel("f3", 512, 512, 1, alpha=1.0 / 0.9)
     check(out, ref)
     assert (out.view(np.uint32) != 0x80000000).all()          # masked elements are +0, as in the HIP kernels
+
+
+def run_tn(M, N, Kc, chunk_rows, grid, with_bias=True, seed=0):
+    from safevla_amd.asmgen import tn_os_gen as T
+    g = T.generate()
+    rs = np.random.RandomState(seed)
+    dY = _bf16(rs.standard_normal((M, N)))
+    X = _bf16(rs.standard_normal((M, Kc)))
+    dW = rs.standard_normal((N, Kc)).astype(np.float32)
+    db = rs.standard_normal(N).astype(np.float32)
+    dW0, db0 = dW.copy(), db.copy()
+    ntk, ntile = Kc // 256, (N // 256) * (Kc // 256)
+    for wg in range(grid):
+        emu = Emu(g.p, lds_bytes=T.LDS_BYTES)
+        aY, aX, aW, aB = emu.alloc(dY), emu.alloc(X), emu.alloc(dW, writable=True), emu.alloc(db, writable=True)
+        ka = bytearray(T.KARG_BYTES)
+
+        def put(name, fmt, val):
+            struct.pack_into(fmt, ka, T.KARG[name], val)
+        put("dY", "<Q", aY); put("ldy", "<q", N); put("X", "<Q", aX); put("ldx", "<q", Kc); put("dW", "<Q", aW); put("ldw", "<q", Kc)
+        put("db", "<Q", aB if with_bias else 0); put("M", "<i", M); put("N", "<i", N); put("K", "<i", Kc); put("chunk_rows", "<i", chunk_rows)
+        put("ntile", "<i", ntile); put("ntk", "<i", ntk); put("grid", "<i", grid)
+        emu.run(ka, wg)
+    yf, xf = bf16_to_f32(dY).astype(np.float64), bf16_to_f32(X).astype(np.float64)
+    return dW, dW0 + yf.T @ xf, db, db0 + (yf.sum(0) if with_bias else 0)
+
+
+def test_tn_os_two_chunks_bias_gradient():
+    # one 256 x 256 tile, two row chunks (96 + 64 rows: three slots and two), bias gradient on
+    dW, rW, db, rb = run_tn(160, 256, 256, 96, 2)
+    assert np.abs(dW - rW).max() < 2e-3 * np.abs(rW).max()
+    assert np.abs(db - rb).max() < 2e-3 * max(1.0, np.abs(rb).max())
+
+
+def test_tn_os_two_k_tiles_share_the_bias_turns():
+    # 256 x 512: two tiles per chunk (k-tile 0 / 1 take the bias gradient of alternate slots), five slots (ring wrap-around)
+    dW, rW, db, rb = run_tn(160, 256, 512, 160, 2)
+    assert np.abs(dW - rW).max() < 2e-3 * np.abs(rW).max()
+    assert np.abs(db - rb).max() < 2e-3 * max(1.0, np.abs(rb).max())

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Weight-gradient GEMM: 8-phase kernel (gemm_tn8p) vs the 2-buffer kernel (gemm_tn256, flag 128): agreement, then timing."""
+"""Weight-gradient GEMM: the output-stationary assembly kernel (asmgen/tn_os_gen.py, variant 0) vs the 8-phase HIP kernel (gemm_tn8p, flag 8192) vs the
+2-buffer kernel (gemm_tn256, flag 128): agreement with fp32 torch, then timing."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,18 +13,18 @@ for (M, n, k) in [(64 * 700, 512, 512), (64 * 1111, 256, 768), (64 * 600, 1536, 
     dY, X = rb(M, n), rb(M, k)
     ref = dY.float().t() @ X.float(); refb = dY.float().sum(0)
     outs = {}
-    for v in (0, 128):
+    for v in (0, 8192):
         for rep in range(3):
             sel(v); dW = torch.zeros(n, k, device="cuda"); db = torch.zeros(n, device="cuda")
             ops.gemm_tn_acc(dY, X, dW, M, n, k, db=db); torch.cuda.synchronize()
             e = ((dW - ref).abs().max() / ref.abs().max()).item(); eb = ((db - refb).abs().max() / refb.abs().max()).item()
             if e > 2e-3 or eb > 2e-3: print(f"MISMATCH v{v} M={M} N={n} K={k}: rel err dW {e:.2e} db {eb:.2e} (rep {rep})", flush=True)
         outs[v] = (e, eb)
-    print(f"checked M={M} N={n} K={k}: rel err vs fp32 torch  new {outs[0][0]:.1e}/{outs[0][1]:.1e}  old {outs[128][0]:.1e}/{outs[128][1]:.1e}", flush=True)
+    print(f"checked M={M} N={n} K={k}: rel err vs fp32 torch  asm {outs[0][0]:.1e}/{outs[0][1]:.1e}  hip 8-phase {outs[8192][0]:.1e}/{outs[8192][1]:.1e}", flush=True)
     del dY, X
 sel(0)
 M = int(os.environ.get("AB_ROWS", 16384)) * 181
-VAR = [int(v) for v in os.environ.get('AB_VARIANTS', '0,128').split(',')]
+VAR = [int(v) for v in os.environ.get('AB_VARIANTS', '0,8192').split(',')]
 for (n, k, bias) in [(512, 512, True), (1536, 512, True), (2048, 512, True), (512, 2048, True), (1024, 512, True), (512, 512, False)]:
     dY, X = rb(M, n), rb(M, k)
     dW = torch.zeros(n, k, device="cuda"); db = torch.zeros(n, device="cuda") if bias else None
