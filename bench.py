@@ -255,7 +255,7 @@ def kernel_sources_sha():
 
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "safevla_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "safevla_amd", "csrc", "*.h")) +
-                    glob.glob(os.path.join(ROOT, "include", "*.h"))):
+                    glob.glob(os.path.join(ROOT, "safevla_amd", "asmgen", "*.py")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()
@@ -472,22 +472,26 @@ def main():
         executed = sum(v["flops"] for v in allk.values())
         # HBM bytes per launch from the rocprofv3 PMC passes of this same command (tools/profile_round.sh -> profiles/).  The file carries the
         # hash of the kernel sources it was measured on: a file from another build is refused (traffic = null) instead of being quoted
-        traffic, traffic_src = None, None
-        for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_hbm_traffic.json")), reverse=True):
+        traffic, traffic_src, traffic_shape = None, None, None
+        for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_hbm_traffic_by_shape.json")), reverse=True):
             try:
                 doc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 if doc.get("kernel_sources_sha256") != kernel_sources_sha():
                     continue
-                inst = [v for k, v in doc["kernels"].items() if "gemm_nt8p" in k or "gemm_nt256" in k]      # one entry per epilogue instantiation: launch-weighted mean
-                traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in inst) / sum(v["launches"] for v in inst))
-                traffic_src = cand
+                # the (kernel, M, N, K) of the NT family with the largest share of the profiled update: ITS bytes per launch next to ITS algorithmic bytes
+                nt = [r for r in doc["shapes"] if "error" not in r and ("nt_as" in r["kernel"] or "gemm_nt" in r["kernel"])]
+                top = max(nt, key=lambda r: r["total_ms_profiled"])
+                traffic, traffic_src = round(top["hbm_bytes_per_launch"]), cand
+                traffic_shape = {k: top[k] for k in ("kernel", "M", "N", "K", "launches", "algorithmic_bytes_per_launch", "ratio_to_algorithmic", "avg_duration_us_profiled")}
                 break
             except Exception:
                 pass
-        roof = {"bound": "mfma", "kernel": "gemm_nt8p_bf16_kernel (svla_gemm_nt_bf16: persistent 256x256x64 tile, 8-phase ping-pong over a 16-KiB half-tile LDS-DMA ring)", "achieved": round(g["tflops"], 1),
+        roof = {"bound": "mfma", "kernel": "svla_gemm_nt_bf16, row-streaming shapes: svla_nt_as_* (generated gfx950 assembly, A panel stationary in 256 AGPRs per wave, K = 512) + "
+                                           "gemm_nt8p_bf16_kernel (HIP, persistent 256x256x64 tile, K > 512 / residual epilogues); all launches of one update, HIP events", "achieved": round(g["tflops"], 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(g["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_unit": (f"HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/{traffic_src}, same kernel sources as this build; launch-weighted over the epilogue instantiations)"
-                                 if traffic is not None else "null: no profiles/*_pmc_hbm_traffic.json was measured on this build's kernel sources (tools/profile_round.sh)"),
+                "traffic_unit": (f"HBM bytes per launch of the family's largest-share (kernel, shape) -- traffic_shape -- (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/{traffic_src}, same kernel sources as this build)"
+                                 if traffic is not None else "null: no profiles/*_pmc_hbm_traffic_by_shape.json was measured on this build's kernel sources (tools/profile_round.sh)"),
+                "traffic_shape": traffic_shape,
                 "launches_per_update": g["launches"], "avg_launch_ms": round(g["avg_ms"], 4), "flops_per_launch": g["flops"] / max(1, g["launches"]),
                 "share_of_update": round(g["total_s"] / (ms * 1e-3), 3),
                 "other_mfma_kernels": {k: {"achieved_tflops": round(v["tflops"], 1), "launches": v["launches"], "avg_launch_ms": round(v["avg_ms"], 4),
@@ -498,8 +502,9 @@ def main():
                 # the other roof: this GEMM family is d = 512 wide (<= 256 FLOP/B at N = K = 512, below the 312 FLOP/B ridge of 2.5 PF / 8 TB/s),
                 # so the HBM roof binds before the MFMA one; counter traffic per launch / live launch duration
                 # (tiny configurations launch none of the 256-tile kernels: no launch duration to divide by, and the profiled traffic is not theirs)
-                "hbm_view": None if (traffic is None or g["avg_ms"] <= 0) else {"achieved_TBps": round(traffic / (g["avg_ms"] * 1e-3) / 1e12, 3), "peak_TBps": PEAK_HBM_TBPS,
-                                                          "frac": round(traffic / (g["avg_ms"] * 1e-3) / 1e12 / PEAK_HBM_TBPS, 4)}}
+                "hbm_view": None if traffic is None else {"achieved_TBps": round(traffic / (traffic_shape["avg_duration_us_profiled"] * 1e-6) / 1e12, 3), "peak_TBps": PEAK_HBM_TBPS,
+                                                          "frac": round(traffic / (traffic_shape["avg_duration_us_profiled"] * 1e-6) / 1e12 / PEAK_HBM_TBPS, 4),
+                                                          "note": "traffic_shape's bytes over ITS profiled launch duration"}}
     cpu = None
     acting = None
     ns = None

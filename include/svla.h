@@ -152,14 +152,19 @@ int svla_attn_bwd_two_pass(int on);
  * (safevla_amd/build.py), so the header stays the single source of truth.  Returns 0, or the first non-zero status with
  * *failed_at = the index of the failing call. */
 int svla_replay_calls(int n, const int* fn_ids, const int* arg_offsets, const unsigned long long* args, int* failed_at);
+/* fn_ids are positions in THIS header: the generated dispatcher reports the hash of the ordered 'name(types)' list it was built from, and the
+ * binding (safevla_amd/_lib.py) refuses a library whose stamp differs from the header it parsed. */
+int svla_replay_abi_stamp(unsigned long long* stamp);
 
 /* ---- deterministic gradient accumulation --------------------------------------------------------------------------------------
  * Every weight / bias / LayerNorm / embedding gradient of the backward (torch autograd of the layers cited above, e.g.
  * allenact_dino_transformer.py:545-552, feeding the Adam step of training/online/dinov2_vits_tsfm_base.py:331-334) is accumulated across
  * workgroups with fp32 atomics, so its last bits depend on arrival order.  svla_det_config(slot, f32_base, i64_shadow, n) registers
  * an int64 shadow (zero-initialised, n elements) of the fp32 range [f32_base, f32_base + n): from then on every such accumulation
- * whose target lies in a registered range is added to the shadow as 64-bit fixed point (2^-40 resolution; integer adds commute, so the
- * sum is bitwise repeatable and exact) instead.  svla_det_finalize adds shadow * 2^-40 into the fp32 buffer and clears the shadow.
+ * whose target lies in a registered range is added to the shadow as 64-bit fixed point (2^-52 resolution, |partial| < 2048; integer adds commute,
+ * so the sum is bitwise repeatable; each partial is rounded once to the grid, non-finite partials bypass the shadow) instead.
+ * svla_det_finalize adds shadow * 2^-52 into the fp32 buffer and clears the shadow.  Repeatable are the GRADIENTS: the clip coefficient (fp64
+ * atomics of the squared norm) and the three loss sums are still accumulated in arrival order.
  * slot 0 / 1: two independent ranges (the flat gradient buffer; a scratch range for accumulated intermediates).  NULL, NULL, 0
  * unregisters.  bf16 product path only (the fp32 verification kernels keep their atomics). */
 int svla_det_config(int slot, float* f32_base, long long* i64_shadow, long n);

@@ -35,6 +35,30 @@ def parse_header(path: str = HEADER) -> Dict[str, List[Tuple[str, object]]]:
     return out
 
 
+def abi_signature(path: str = HEADER) -> str:
+    """ordered 'name(type,type,...)' list of the entry points svla_replay_calls dispatches by integer id (declaration order of the header, the
+    replay entry itself excluded).  build.py bakes its hash into the generated dispatcher (svla_replay_abi_stamp); _Lib compares."""
+    src = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+    out = []
+    for m in re.finditer(r"\bint\s+(svla_\w+)\s*\((.*?)\)\s*;", src, flags=re.S):
+        if m.group(1) == "svla_replay_calls":
+            continue
+        tys = []
+        for a in m.group(2).split(","):
+            a = " ".join(a.split())
+            name = re.findall(r"(\w+)$", a)[0]
+            tys.append(a[: -len(name)].strip().replace(" ", ""))
+        out.append(f"{m.group(1)}({','.join(tys)})")
+    return ";".join(out)
+
+
+def abi_stamp(path: str = HEADER) -> int:
+    h = 0xcbf29ce484222325
+    for b in abi_signature(path).encode():
+        h = ((h ^ b) * 0x100000001b3) & 0xffffffffffffffff
+    return h
+
+
 class SvlaError(RuntimeError):
     pass
 
@@ -59,6 +83,14 @@ class _Lib:
             fn = getattr(self.cdll, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = ctypes.c_int
             fn.argtypes = [ct for _, ct in args]
+        # svla_replay_calls dispatches by integer id = position of the declaration in the header: a library built from another revision of the
+        # header would call the wrong kernel with reinterpreted arguments.  The generated dispatcher carries the hash of the ordered
+        # signature list it was built from.
+        stamp = ctypes.c_ulonglong(0)
+        self.cdll.svla_replay_abi_stamp(ctypes.byref(stamp))
+        if stamp.value != abi_stamp():
+            raise SvlaError(f"{LIB_PATH} was built from a different include/svla.h (entry-point table stamp {stamp.value:#x}, header {abi_stamp():#x}): "
+                            "rebuild with `python safevla_amd/build.py`")
 
     recorder = None      # optional list: every call is appended as (bound C function, args) -- launch-replay experiments (tools/replay_probe.py)
 

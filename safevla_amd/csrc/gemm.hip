@@ -947,6 +947,18 @@ static int launch_nt256(const GemmNtArgs& p, int grid, hipStream_t stream) {
 #undef NT256_CASE
 
 static int g_force_small_tile = 0, g_dbg = 0;
+// SVLA_GEMM_LOG=<file>: one line "kernel M N K" per big-GEMM launch, in launch order -- tools/prof_summarize.py joins it with the rocprofv3
+// counter rows of the same kernel names (i-th dispatch <-> i-th line), so HBM traffic is reported per (kernel, shape) and not as a launch-weighted mean
+static void gemm_log(const char* kernel, int M, int N, int K) {
+    static FILE* f = nullptr;
+    static bool init = false;
+    if (!init) {
+        init = true;
+        const char* path = getenv("SVLA_GEMM_LOG");
+        if (path) f = fopen(path, "w");
+    }
+    if (f) { fprintf(f, "%s %d %d %d\n", kernel, M, N, K); fflush(f); }
+}
 // on = 0/1/2: normal dispatch / force the 128x128 kernels / force the 256-tile kernels wherever their shape constraints hold (tests); on = 10 + f: flags f of the 256-tile kernels -- timing-only ablations 1 / 2 / 64,
 // 128 / 256 = force the 2-buffer kernel (gemm_nt256k64) / the 8-phase kernel (gemm_nt8p) (A/B comparisons)
 extern "C" int svla_gemm_force_small_tile(int on) {
@@ -1005,6 +1017,7 @@ static int nt_as_try(const GemmNtArgs& p, hipStream_t stream) {
     k.key = p.drop.key; k.thr = p.drop.thr; k.scale = p.drop.scale; k.row_mult = p.drop.row_mult; k.seed_dev = p.drop.seed_dev; k.stream_key = p.drop.stream_key;
     k.grid = npanels < n_cu ? npanels : n_cu;
     if (getenv("SVLA_NT_AS_DBGBUF")) k.bits = (const void*)strtoull(getenv("SVLA_NT_AS_DBGBUF"), nullptr, 16);      // timing builds of tools/time_nt_as.py
+    gemm_log(name, npanels * 256, p.N, p.K);
     const int rc = svla_asm_launch(name, &k, sizeof(k), k.grid, 256, stream);
     if (rc) return rc;
     const int tail = p.M - npanels * 256;
@@ -1056,6 +1069,7 @@ extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, lon
             if (n_cu < 8) n_cu = 8;
         }
         const int ntiles = ((M + 255) / 256) * ((N + 255) / 256);
+        gemm_log(nt_use_8p(p) ? "gemm_nt8p_bf16_kernel" : "gemm_nt256k64_bf16_kernel", M, N, K);
         int grid = n_cu;                       // persistent: one 512-thread workgroup (160 KiB LDS) per CU
         while (grid > 8 && (grid / 8) * 8 > ntiles) grid -= 8;
         return launch_nt256(p, grid, (hipStream_t)stream);
@@ -1517,6 +1531,7 @@ extern "C" int svla_gemm_tn_f32acc(const bf16_t* dY, long ldy, const bf16_t* X, 
             struct { const void* dY; long ldy; const void* X; long ldx; float* dW; long ldw; float* db; int M, N, K, chunk_rows, ntile, ntk, grid, pad; } k =
                 {dY, ldy, X, ldx, dW, ldw, db, M, N, K, chunk_rows, ntile256, K / 256, ntile256 * chunks, 0};
             static_assert(sizeof(k) == 88, "kernarg layout of svla_tn_os");
+            gemm_log("svla_tn_os", M, N, K);
             return svla_asm_launch("svla_tn_os", &k, sizeof(k), ntile256 * chunks, 256, (hipStream_t)stream);
         }
         if (!(g_dbg & 128)) {
@@ -1525,6 +1540,7 @@ extern "C" int svla_gemm_tn_f32acc(const bf16_t* dY, long ldy, const bf16_t* X, 
                 HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_tn8p_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
                 attr8p = true;
             }
+            gemm_log("gemm_tn8p_bf16_kernel", M, N, K);
             hipLaunchKernelGGL(gemm_tn8p_bf16_kernel, dim3(ntile256 * chunks), dim3(NT256_THREADS), lds256, (hipStream_t)stream, q);
             return svla_launch_status();
         }

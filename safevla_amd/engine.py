@@ -276,11 +276,13 @@ class PPOLagEngine:
                 n_total = counts[i]
                 m.zero_grad()
                 self._sums.zero_()
-                chunk = cfg.env_chunk or (b1 - b0)
+                chunk = cfg.env_chunk or max(1, b1 - b0)
                 for c0 in range(b0, b1, chunk):
                     self._accumulate(storage.batch_slice(c0, min(b1, c0 + chunk)), n_total, lam, last=c0 + chunk >= b1,
                                      cache_key=(c0, min(b1, c0 + chunk)))
-                self.optimizer_step(reduced=True)
+                # a rank whose shard has fewer envs than minibatches (uneven strong-scaling shards) owns NO rows of this minibatch: it still joins the
+                # three per-tower all-reduces (in tower order, like the asynchronous ones of the other ranks) with its zeroed gradient
+                self.optimizer_step(reduced=b1 > b0)
                 parallel.allreduce_sum_(self._sums)
                 info_acc += self._sums / n_total
                 n_mb += 1

@@ -72,3 +72,25 @@ def test_bench_two_ranks_well_formed_line(scaling):
     assert out["config"]["global_envs"] == envs and out["loss"]["env_steps"] == 8 * envs
     assert out["value"] > 0 and abs(out["value"] - 8 * envs / (out["ms_per_step"] * 1e-3)) < 1e-2 * out["value"]
     assert out["roofline"] is not None and "frac" in out["roofline"]
+
+
+def test_bench_eight_ranks_strong_scaling_fetch_plumbing():
+    """BASELINE configs[3] as the driver will launch it on the 8-GPU node -- `bench.py --gpus 8 --scaling strong --global-envs 250` under
+    torch.distributed.run -- with the eight ranks sharing this box's one GPU through gloo (uneven shards: 250 = 2 x 32 + 6 x 31; three asynchronous
+    per-tower all-reduces in flight on eight ranks; the single count all-reduce; the cost accumulator), short rollouts (T = 4).  RCCL itself needs
+    one GPU per rank and has never run here; what this pins is everything else the first SCALE run of C4 could die on."""
+    import json
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SVLA_DIST_BACKEND="gloo")
+    port = 29800 + (os.getpid() % 90)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--T", "4",
+           "--no-cpu-baseline", "--no-secondary", "--no-roofline", "--scaling", "strong", "--global-envs", "250", "--task", "Fetch"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["scaling"] == "strong"
+    assert out["config"]["global_envs"] == 250 and out["loss"]["env_steps"] == 4 * 250
+    assert out["value"] > 0 and all(v == v for v in out["loss"].values() if isinstance(v, float))

@@ -199,3 +199,46 @@ def test_c5_shard_mixed_tasks_long_instructions(model):
         assert not torch.equal(model.arena.flat_p[lo:hi], p0[lo:hi])
     model.arena.flat_p.copy_(p0)
     model.sync_weights(frozen=False)
+
+
+def test_c4_shard_fetch_chunked_equals_unchunked_and_lambda_moves(model):
+    """BASELINE configs[3]'s single-GPU half: ONE rank's shard of the 256-env Fetch run over 8 GPUs = 32 envs x 256 steps (env_offset: envs 96..127
+    of the global run).  (a) eval mode: the one-pass gradient (the bench's execution: the assembly GEMMs of asmgen/ carry it at this size) equals the
+    accumulation over two env-chunks of 16; (b) train mode: one full update with the cost constraint active is finite, moves every tower, and lambda
+    rises (Jc above the limit).  The 8-GPU half (gradient / cost all-reduce) is covered at world sizes 2 and 8 by tests/test_dp_gpu.py and the bench tests."""
+    from safevla_amd.engine import PPOLagConfig, PPOLagEngine
+    from safevla_amd.synth_env import SynthSpec, fill_synthetic_rollout
+
+    model.eval()
+    T, B = 256, 32
+    st, nxt, ep = fill_synthetic_rollout(model, SynthSpec(T=T, B=B, L=12, task="Fetch", seed=14, env_offset=96), device=DEV)
+    st.compute_returns(nxt["next_value"], nxt["next_c_value"])
+    grads, sums = {}, {}
+    for chunk in (None, 16):
+        eng = PPOLagEngine(model, PPOLagConfig(env_chunk=chunk, cost_limit=2.31964))
+        model.zero_grad()
+        eng._sums.zero_()
+        step = chunk or B
+        for c0 in range(0, B, step):
+            eng._accumulate(st.batch_slice(c0, c0 + step), T * B, 0.2, last=c0 + step >= B)
+        grads[chunk], sums[chunk] = model.arena.flat_g.clone(), eng._sums.clone()
+        del eng
+        torch.cuda.empty_cache()
+    a, b = grads[None].double(), grads[16].double()
+    assert torch.isfinite(a).all() and a.norm().item() > 0
+    assert torch.nn.functional.cosine_similarity(a, b, dim=0).item() > 0.9999
+    assert ((a - b).norm() / a.norm()).item() < 1e-2
+    np.testing.assert_allclose(sums[None].cpu().numpy(), sums[16].cpu().numpy(), rtol=1e-4, atol=1e-6)
+    model.zero_grad()
+    model.train()
+    cfg = PPOLagConfig(env_chunk=None, cost_limit=2.31964)
+    eng = PPOLagEngine(model, cfg)
+    p0 = model.arena.flat_p.clone()
+    assert ep["episode_cost_sum"] / ep["n_episodes"] > cfg.cost_limit
+    info = eng.update(st, nxt["next_value"], nxt["next_c_value"], ep["episode_cost_sum"], ep["n_episodes"])
+    assert info["env_steps"] == T * B and all(np.isfinite(v) for v in info.values())
+    assert info["lagrangian_multiplier"] > cfg.lambda_init
+    for lo, hi in model.arena.tower_ranges:
+        assert not torch.equal(model.arena.flat_p[lo:hi], p0[lo:hi])
+    model.arena.flat_p.copy_(p0)
+    model.sync_weights(frozen=False)

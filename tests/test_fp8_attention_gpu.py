@@ -113,3 +113,33 @@ def test_fp8_backward_is_zero_for_zero_upstream_gradient(ops):
     dqkv = torch.full_like(d, 7.0)
     ops.attn_fp8_bwd(f8, out, lse, torch.zeros_like(out), dqkv, dqkv[:, H * 64:], dqkv[:, 2 * H * 64:], 3 * H * 64, 0.125)
     assert (dqkv == 0).all()
+
+
+@pytest.mark.parametrize("S,p", [(40, 0.0), (65, 0.1), (181, 0.0), (181, 0.1), (233, 0.1), (256, 0.0)])
+def test_fp8_backward_matches_quantisation_aware_reference(ops, S, p):
+    """svla_attn_fp8_bwd against oracle/ref_fp8_attn.bwd: the same e4m3 / e5m2 casts at the same points (P x 256, dS x 2^-13, per-slice scales),
+    fed with the kernel's own forward outputs -- what is left is accumulation order, exp2 vs exp and the bf16 rounding of the outputs.  Gate: 1 % relative
+    Frobenius error per gradient (measured 1e-3 .. 4e-3); a wrong e5m2 scale or a mis-permuted reduction slot is a 100 % error here, where the fp32 ladder's
+    12 % gate could pass a few per cent.  The forward with dropout is checked against the same restatement on the way."""
+    from oracle import ref_fp8_attn as R
+    from oracle.ref_model import hash_dropout
+    rows, H, scale = 3, 8, 0.125
+    qkv, do = _case(rows, S, H, 300 + S)
+    q, k, v = [_heads(qkv[:, i * H * 64:(i + 1) * H * 64], rows, S, H) for i in range(3)]
+    dropc = ops.Dropout(seed=0xC0FFEE, stream=4, p=p) if p > 0 else None
+    keep = (hash_dropout(torch.ones(rows, H, S, S), 0xC0FFEE, 4, p, attn_S=S) > 0) if p > 0 else None
+    ds = 1.0 / (1.0 - p)
+    d = qkv.to(DEV).bfloat16()
+    f8 = ops.attn_fp8_quant(d, 3 * H * 64, rows, S, H)
+    out, lse = ops.attn_fp8_fwd(f8, scale, drop=dropc)
+    dqkv = torch.zeros_like(d)
+    ops.attn_fp8_bwd(f8, out, lse, do.to(DEV).bfloat16(), dqkv, dqkv[:, H * 64:], dqkv[:, 2 * H * 64:], 3 * H * 64, scale, drop=dropc)
+    torch.cuda.synchronize()
+    o_k, lse_k = _heads(out.float().cpu(), rows, S, H), lse.cpu().view(rows, H, S)
+    o_ref, lse_ref = R.fwd(q, k, v, scale, keep=keep, drop_scale=ds)
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    assert rel(o_k, o_ref) < 1e-2 and (lse_k - lse_ref).abs().mean().item() < 1e-4, (rel(o_k, o_ref), (lse_k - lse_ref).abs().max().item())
+    dq, dk, dv = R.bwd(q, k, v, o_k, lse_k, _heads(do, rows, S, H), scale, keep=keep, drop_scale=ds)
+    for i, (n, want) in enumerate((("dQ", dq), ("dK", dk), ("dV", dv))):
+        got = _heads(dqkv[:, i * H * 64:(i + 1) * H * 64].float().cpu(), rows, S, H)
+        assert rel(got, want) < 1e-2, (n, S, p, rel(got, want))

@@ -677,3 +677,91 @@ def test_degenerate_sizes(ops):
     qkv = bf(rnd(1, 3 * 64, seed=3)).to(DEV).bfloat16()
     o, lse = ops.attn_fwd(qkv, qkv[:, 64:], qkv[:, 128:], 192, 1, 1, 1, 0.125)
     close(o.float(), qkv[:, 128:].float(), 1e-2, 1e-2, "S = 1 attention returns V")
+
+
+# ------------------------------------------------------------------------------------------------ generated assembly GEMMs (asmgen/)
+def _asm_off(ops, off):
+    from safevla_amd._lib import lib
+    lib().call("svla_gemm_force_small_tile", 10 + (8192 if off else 0))
+
+
+@pytest.mark.parametrize("N", [512, 1536])
+@pytest.mark.parametrize("flavour", ["bias", "relu_bits", "relu_drop_bits", "bits_in"])
+def test_gemm_nt_assembly_kernels(ops, N, flavour):
+    """The A-stationary assembly kernels (svla_nt_as_*, asmgen/nt_as_gen.py; K = 512, >= 512 row panels) behind svla_gemm_nt_bf16: against the
+    fp32 torch restatement of the epilogue (dropout mask from the counter definition), against the HIP kernels they replace (flag 8192 = assembly
+    off: at most one bf16 rounding apart -- the bias is the accumulator's initial value instead of an addition at the end), sign bits equal,
+    identical from run to run, ragged M (the tail rows run on the 128-tile kernel with the global row index)."""
+    M, K, p = 256 * 520 + 77, 512, 0.1
+    A = bf(rnd(M, K, seed=41)).to(DEV).bfloat16(); B = bf(rnd(N, K, seed=42, scale=0.05)).to(DEV).bfloat16(); bias = rnd(N, seed=43, scale=0.5).to(DEV)
+    kw, want = {}, None
+    acc = A.float() @ B.float().t()
+    if flavour == "bias":
+        kw = dict(bias=bias)
+        want = acc + bias
+    elif flavour in ("relu_bits", "relu_drop_bits"):
+        kw = dict(bias=bias, act=ops.ACT_RELU)
+        want = torch.relu(acc + bias)
+        if flavour == "relu_drop_bits":
+            kw["drop"] = ops.Dropout(seed=99, stream=3, p=p)
+            idx = (np.arange(M, dtype=np.uint64)[:, None] * np.uint64(N)) + np.arange(N, dtype=np.uint64)[None, :]
+            want = want * _keep_np(99, 3, p, idx).float().to(DEV) / (1 - p)
+    else:
+        mask = torch.rand(M, N, device=DEV) < 0.6
+        h = torch.where(mask, 1.0, -1.0).bfloat16()
+        bits = torch.zeros(ops.relu_bits_bytes(M, N), device=DEV, dtype=torch.uint8)
+        _asm_off(ops, True)
+        ops.gemm_nt(h, torch.eye(N, device=DEV).bfloat16(), M, N, N, act=ops.ACT_RELU, relu_bits_out=bits)      # sign bits of h through the HIP kernel
+        kw = dict(relu_bits=bits, alpha=1 / (1 - p))
+        want = torch.where(mask, acc / (1 - p), torch.zeros((), device=DEV))
+    outs = {}
+    try:
+        for off in (True, False, False):
+            _asm_off(ops, off)
+            k2 = dict(kw)
+            if "relu" in flavour:
+                k2["relu_bits_out"] = torch.zeros(ops.relu_bits_bytes(M, N), device=DEV, dtype=torch.uint8)
+            y = ops.gemm_nt(A, B, M, N, K, **k2)
+            torch.cuda.synchronize()
+            outs.setdefault(off, []).append((y, k2.get("relu_bits_out")))
+    finally:
+        _asm_off(ops, False)
+    (hip, hip_bits), (a1, b1), (a2, b2) = outs[True][0], outs[False][0], outs[False][1]
+    assert torch.equal(a1.view(torch.int16), a2.view(torch.int16)), "assembly kernel differs from run to run"
+    close(a1.float(), want, 1e-2, 2e-2, f"asm {flavour} vs fp32 torch")
+    d = (a1.float() - hip.float()).abs()
+    assert (d <= hip.float().abs() * 2.0 ** -7 + 1e-6).all(), f"asm vs HIP kernel: max {d.max().item()}"
+    if b1 is not None:
+        assert torch.equal(b1, b2)
+        assert (b1 != hip_bits).float().mean().item() < 1e-4          # a value that rounds to exactly 0 in one of the two may flip its bit
+        pos = (a1.float() > 0)
+        chk = torch.zeros(ops.relu_bits_bytes(M, N), device=DEV, dtype=torch.uint8)
+        _asm_off(ops, True)
+        try:
+            ops.gemm_nt(torch.where(pos, 1.0, -1.0).bfloat16(), torch.eye(N, device=DEV).bfloat16(), M, N, N, act=ops.ACT_RELU, relu_bits_out=chk)
+        finally:
+            _asm_off(ops, False)
+        assert torch.equal(chk, b1), "sign bits are not (output > 0)"
+
+
+@pytest.mark.parametrize("N,K", [(512, 512), (1536, 512), (512, 2048)])
+def test_gemm_tn_assembly_kernel(ops, N, K):
+    """The output-stationary assembly weight-gradient kernel (svla_tn_os, asmgen/tn_os_gen.py) behind svla_gemm_tn_f32acc: accumulation into a
+    non-zero dW, fused bias gradient, against fp32 torch and the HIP 8-phase kernel."""
+    M = 64 * 700
+    dY = bf(rnd(M, N, seed=51)).to(DEV).bfloat16(); X = bf(rnd(M, K, seed=52)).to(DEV).bfloat16()
+    w0, b0 = rnd(N, K, seed=53).to(DEV), rnd(N, seed=54).to(DEV)
+    want_w = w0 + dY.float().t() @ X.float(); want_b = b0 + dY.float().sum(0)
+    res = {}
+    try:
+        for off in (False, True):
+            _asm_off(ops, off)
+            dW, db = w0.clone(), b0.clone()
+            ops.gemm_tn_acc(dY, X, dW, M, N, K, db=db)
+            torch.cuda.synchronize()
+            res[off] = (dW, db)
+    finally:
+        _asm_off(ops, False)
+    for off in (False, True):
+        assert ((res[off][0] - want_w).abs().max() / want_w.abs().max()).item() < 1e-4
+        assert ((res[off][1] - want_b).abs().max() / want_b.abs().max()).item() < 1e-4

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Run ON the GPU box after rocprofv3: reduce result DBs (written under /tmp) to small text/JSON summaries in gpurun_out/.
   prof_summarize.py stats <db> <out.txt> <title...>     kernel-trace --stats table
-  prof_summarize.py pmc <fetch_db> <write_db> <out.json> HBM traffic per launch from FETCH_SIZE / WRITE_SIZE passes"""
+  prof_summarize.py pmc <fetch_db> <write_db> <out.json> HBM traffic per launch from FETCH_SIZE / WRITE_SIZE passes
+  prof_summarize.py pmc_shapes <fetch_db> <write_db> <launch_log> <out.json>   the same keyed by (kernel, M, N, K)"""
 import json, sqlite3, sys
 
 def stats(db, out, title):
@@ -20,6 +21,49 @@ def _sources_sha():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     return bench.kernel_sources_sha()
+
+def pmc_shapes(fdb, wdb, log, out):
+    """per (kernel, M, N, K): mean FETCH / WRITE bytes per launch, joined with the launch log of SVLA_GEMM_LOG (i-th dispatch of a kernel name
+    <-> i-th log line of that name), next to the algorithmic bytes of the shape"""
+    import collections
+    def rows(path, counter):
+        cur = sqlite3.connect(path).cursor()
+        d = collections.defaultdict(list)
+        cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+        order = "dispatch_id" if "dispatch_id" in cols else ("start" if "start" in cols else "rowid")
+        for n, v, dur in cur.execute(f"select kernel_name, value, duration from counters_collection where counter_name=? order by {order}", (counter,)):
+            d[n.split("(")[0].replace("void ", "").split("<")[0]].append((v, dur))
+        return d
+    f, w = rows(fdb, "FETCH_SIZE"), rows(wdb, "WRITE_SIZE")
+    logs = collections.defaultdict(list)
+    for line in open(log):
+        k, M, N, K = line.split()
+        logs[k].append((int(M), int(N), int(K)))
+    res = {"_method": "rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2), --kernel-trace only, on `python bench.py --steps 1 --warmup 0 "
+                      "--no-cpu-baseline --no-roofline --no-secondary` with SVLA_GEMM_LOG: the i-th dispatch of a kernel name is the i-th logged launch of that "
+                      "name; counters are KiB; gfx950: FETCH_SIZE reports half of a wide (16 B/lane) coalesced stream (MI355X_MICROARCH.md, HBM) => fetch bytes = "
+                      "2*FETCH_SIZE*1024, WRITE_SIZE as is.  algorithmic_bytes: NT 2*(M*K + M*N) [+ residual / sign bits], TN 2*M*(N + K).",
+           "kernel_sources_sha256": _sources_sha(), "shapes": []}
+    for k, shp in logs.items():
+        fk, wk = f.get(k, []), w.get(k, [])
+        if len(fk) != len(shp) or len(wk) != len(shp):
+            res["shapes"].append({"kernel": k, "error": f"{len(shp)} logged launches vs {len(fk)} / {len(wk)} counter rows"})
+            continue
+        agg = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
+        for (M, N, K), (fv, fd), (wv, wd) in zip(shp, fk, wk):
+            a = agg[(M, N, K)]
+            a[0] += 1; a[1] += 2 * fv * 1024; a[2] += wv * 1024; a[3] += fd
+        for (M, N, K), (n, fb, wb, dur) in sorted(agg.items(), key=lambda kv: -kv[1][3]):
+            alg = 2 * M * (N + K) if "tn" in k else 2 * (M * K + M * N)
+            res["shapes"].append({"kernel": k, "M": M, "N": N, "K": K, "launches": n, "fetch_bytes_per_launch": fb / n, "write_bytes_per_launch": wb / n,
+                                  "hbm_bytes_per_launch": (fb + wb) / n, "algorithmic_bytes_per_launch": alg, "ratio_to_algorithmic": round((fb + wb) / n / alg, 3),
+                                  "avg_duration_us_profiled": dur / n / 1e3, "total_ms_profiled": dur / 1e6})
+    res["shapes"].sort(key=lambda r: -r.get("total_ms_profiled", 0))
+    json.dump(res, open(out, "w"), indent=1)
+    for r in res["shapes"][:14]:
+        if "error" in r: print(r); continue
+        print(f'{r["kernel"][:28]:28s} M={r["M"]:8d} N={r["N"]:5d} K={r["K"]:5d} n={r["launches"]:4d} hbm={r["hbm_bytes_per_launch"]/1e9:7.3f} GB alg={r["algorithmic_bytes_per_launch"]/1e9:7.3f} GB x{r["ratio_to_algorithmic"]:.2f} {r["avg_duration_us_profiled"]:9.1f} us')
+
 
 def pmc(fdb, wdb, out):
     def q(path, counter):
@@ -42,5 +86,7 @@ def pmc(fdb, wdb, out):
 
 if sys.argv[1] == "stats":
     stats(sys.argv[2], sys.argv[3], " ".join(sys.argv[4:]))
+elif sys.argv[1] == "pmc_shapes":
+    pmc_shapes(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
 else:
     pmc(sys.argv[2], sys.argv[3], sys.argv[4])

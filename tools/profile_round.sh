@@ -16,9 +16,11 @@ DB=$(find /tmp/p_kt -name "*.db" | head -1)
 python $REPO/tools/prof_summarize.py stats "$DB" $OUT/${TAG}_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- $CMD ($TAG; warm-up update + 1 timed update + acting pass of the synthetic rollout)" > /dev/null
 if [ "${SKIP_PMC:-0}" != "1" ]; then
   CMD0="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-secondary $*"
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_f -o f -- $CMD0 > /dev/null 2> /tmp/f.err
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_w -o w -- $CMD0 > /dev/null 2> /tmp/w.err
+  SVLA_GEMM_LOG=/tmp/gemm_f.log rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_f -o f -- $CMD0 > /dev/null 2> /tmp/f.err
+  SVLA_GEMM_LOG=/tmp/gemm_w.log rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_w -o w -- $CMD0 > /dev/null 2> /tmp/w.err
   FDB=$(find /tmp/p_f -name "*.db" | head -1); WDB=$(find /tmp/p_w -name "*.db" | head -1)
   python $REPO/tools/prof_summarize.py pmc "$FDB" "$WDB" $OUT/${TAG}_pmc_hbm_traffic.json > /dev/null
+  cmp -s /tmp/gemm_f.log /tmp/gemm_w.log || echo "WARNING: the two passes launched different GEMM sequences"
+  python $REPO/tools/prof_summarize.py pmc_shapes "$FDB" "$WDB" /tmp/gemm_f.log $OUT/${TAG}_pmc_hbm_traffic_by_shape.json
 fi
 ls -la $OUT | grep "$TAG"
