@@ -12,6 +12,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """a rendezvous port nobody holds (a fixed one collided once in a full-suite run: TIME_WAIT of an earlier test's store)"""
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
 @pytest.mark.parametrize("backend", ["gloo", "rccl"])
 def test_two_ranks_equal_single_process_gradient(tmp_path, backend):
     """backend "gloo": two ranks share the one GPU of the test box; "rccl": one rank per GPU over RCCL ("nccl" on ROCm) -- runs wherever
@@ -27,7 +35,7 @@ def test_two_ranks_equal_single_process_gradient(tmp_path, backend):
         env["SVLA_DIST_BACKEND"] = "gloo"
     else:
         env.pop("SVLA_DIST_BACKEND", None)
-    port = 29600 + (os.getpid() % 300)
+    port = _free_port()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "tests", "helpers", "dp_worker.py"), out, str(T), str(B)],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
@@ -59,7 +67,7 @@ def test_bench_two_ranks_well_formed_line(scaling):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SVLA_DIST_BACKEND="gloo")
-    port = 29950 + (os.getpid() % 40) + (0 if scaling == "weak" else 41)
+    port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--T", "8",
            "--envs-per-gpu", "4", "--no-cpu-baseline", "--no-secondary", "--scaling", scaling, "--global-envs", "7"]
@@ -84,7 +92,7 @@ def test_bench_eight_ranks_strong_scaling_fetch_plumbing():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SVLA_DIST_BACKEND="gloo")
-    port = 29800 + (os.getpid() % 90)
+    port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--T", "4",
            "--no-cpu-baseline", "--no-secondary", "--no-roofline", "--scaling", "strong", "--global-envs", "250", "--task", "Fetch"]
