@@ -357,22 +357,25 @@ def timed_updates(eng, st, nxt, ep, steps, warmup, world, dev):
     return dt / steps * 1e3, info, step
 
 
-def secondary_config(model, dev, name, task, T, B, L, env_chunk, cost_limit, fp8=False):
+def secondary_config(model, dev, name, task, T, B, L, env_chunk, cost_limit, fp8=False, t5_per_row=False):
     """Another BASELINE configuration through the same engine (1 warm-up + 1 timed update; parity-test cases, not the bench line).
     fp8: the fusion-encoder attention on the e4m3 / e5m2 kernels (BASELINE configs[4]: "fp8 MFMA attention"), acting pass included."""
     from safevla_amd.engine import PPOLagConfig, PPOLagEngine
     from safevla_amd.synth_env import SynthSpec, fill_synthetic_rollout
 
     model.set_fp8_attention(fp8)
+    model.t5_dropout_per_row = t5_per_row      # the reference's train-mode T5 statistics: one dropout realisation per (t, b) row and tower
     try:
         st, nxt, ep = fill_synthetic_rollout(model, SynthSpec(T=T, B=B, L=L, task=task, seed=4321), device=dev)
         eng = PPOLagEngine(model, PPOLagConfig(env_chunk=env_chunk, cost_limit=cost_limit))
         ms, info, _ = timed_updates(eng, st, nxt, ep, 1, 1, 1, dev)
     finally:
         model.set_fp8_attention(False)
+        model.t5_dropout_per_row = False
     S = 169 + L
     U = int(st.observations["goal_token_ids"][:T].reshape(T * B, -1).unique(dim=0).shape[0])
     return {"workload": name, "task": task, "rollout_steps": T, "envs": B, "goal_tokens": L, "env_chunk": env_chunk, "attention": "fp8 (e4m3 / e5m2)" if fp8 else "bf16",
+            "t5_dropout": "per (t, b) row and tower, as the reference draws it (allenact_dino_transformer.py:193,591-605)" if t5_per_row else "per unique goal and pass (default)",
             "ms_per_update": round(ms, 2),
             "env_steps_per_s": round(T * B / (ms * 1e-3), 1),
             "reference_equivalent_tflops": round(flops_per_update(T * B, S, L, U, 4) / (ms * 1e-3) / 1e12, 1),
@@ -526,7 +529,8 @@ def main():
         secondary = [guarded(secondary_config, model, dev, "C4-shard: one GPU's 32 envs of BASELINE configs[3] (Fetch, 256 envs over 8 GPUs)", "Fetch", 256, 32, 12, None, 2.31964),
                      guarded(secondary_config, model, dev, "C2: BASELINE configs[1] (ObjectNav, 32 envs x 128 steps)", "ObjectNav", 128, 32, 12, None, 2.31964),
                      guarded(secondary_config, model, dev, "C5-shard: mixed ObjectNav+PickUp+Fetch sampler (env e -> task e mod 3), 64-token instructions, 32 envs/GPU", "Mixed", 256, 32, 64, None, 2.31964),
-                     guarded(secondary_config, model, dev, "C5-shard fp8: the same with the fusion-encoder attention on fp8 MFMA (BASELINE configs[4])", "Mixed", 256, 32, 64, None, 2.31964, True)]
+                     guarded(secondary_config, model, dev, "C5-shard fp8: the same with the fusion-encoder attention on fp8 MFMA (BASELINE configs[4])", "Mixed", 256, 32, 64, None, 2.31964, True),
+                     guarded(secondary_config, model, dev, "C3 with the reference-faithful T5 dropout (the headline workload, t5_dropout_per_row=True)", "PickUp", 256, 64, 12, None, 2.31964, False, True)]
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
