@@ -751,7 +751,7 @@ class Prog:
         so = w.srd(soff) if isinstance(soff, Reg) else soff
         return base + so + voff + off, voff + off, nrec
 
-    def buffer_load(self, d, vaddr, srd, soff, off=0, n=None):
+    def buffer_load(self, d, vaddr, srd, soff, off=0, nt=False):
         nd = d.n
         name = {1: "buffer_load_dword", 2: "buffer_load_dwordx2", 4: "buffer_load_dwordx4"}[nd]
         assert 0 <= off <= 4095
