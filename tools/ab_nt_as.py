@@ -8,6 +8,7 @@ from safevla_amd import ops
 from safevla_amd._lib import lib
 sel = lambda v: lib().call("svla_gemm_force_small_tile", 10 + v)
 FLAVS = os.environ.get("AB_FLAVS", "plain,bias").split(",")
+VARS = [int(x) for x in os.environ.get("AB_VARS", "0,8192").split(",")]      # 0: assembly kernels, 8192: HIP kernels
 
 def kwargs(flav, M, n):
     bias = torch.randn(n, device="cuda")
@@ -61,7 +62,7 @@ for (n, flav) in [(512, "plain"), (1536, "bias"), (2048, "bias"), (1024, "bias")
     kw = kwargs(flav, M, n)
     res = {}
     for rep in range(3):
-        for v in (0, 8192):
+        for v in VARS:
             sel(v)
             for _ in range(2): ops.gemm_nt(A, B, M, n, 512, out=out, **kw)
             torch.cuda.synchronize()
@@ -71,6 +72,6 @@ for (n, flav) in [(512, "plain"), (1536, "bias"), (2048, "bias"), (1024, "bias")
             e1.record(); torch.cuda.synchronize()
             res.setdefault(v, []).append(e0.elapsed_time(e1) / 10)
     sel(0)
-    print(f"N={n} K=512 {flav}: " + "  ".join(f"{'asm' if a == 0 else 'hip'}: {min(t):.3f} ms ({2*M*n*512/min(t)/1e9:.0f} TF)" for a, t in res.items()), flush=True)
+    print(f"N={n} K=512 {flav}: " + "  ".join(f"{ {0: 'asm', 8192: 'hip'}[a]}: {min(t):.3f} ms ({2*M*n*512/min(t)/1e9:.0f} TF)" for a, t in res.items()), flush=True)
     del A, B, out, kw
 sys.exit(1 if nbad else 0)

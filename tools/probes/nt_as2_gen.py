@@ -1,0 +1,1012 @@
+"""NEGATIVE RESULT, kept as a probe (round 4; not built into the library -- to try it: copy next to safevla_amd/asmgen/nt_as_gen.py, fix the relative
+imports and add it to build.py).  Second generation of the A-stationary NT kernel: the next panel's A rows are staged through 64 KiB of LDS by full-line
+LDS-DMA (W ring = two 32-KiB K halves, two barriers per n-step) instead of fragment-shaped loads into the dead AGPRs.  Correct in the emulator and on
+the MI355X; it removes the 10 k-cycle spike of the panel-switch step but not its cost (every panel switch still costs ~3-4 k cycles per wave: first the
+in-order VM queue -- fixed by issuing the W DMAs ahead of the staging DMAs --, then the issue slots of 64 more DMA groups on ONE wave, which the barrier
+hands to the other three): 1.15-1.19 PF at N >= 1536, the same as the first generation (profiles/r04_nt_as_step_timing.txt).
+
+Generator of the A-stationary NT GEMM kernels for gfx950 (C[M,N] = epi(A[M,512] . W[N,512]^T), M % 256 == 0, N % 128 == 0).
+
+Replaces, for the K = 512 linears of the fusion encoder (reference: nn.TransformerEncoder layers of
+architecture/models/allenact_transformer_models/allenact_dino_transformer.py:545-552,702-708 -- in_proj, out_proj, linear1, and the
+input-gradient GEMM through linear2), the 256x256-tile kernel of csrc/gemm.hip.  Structure:
+
+  * one workgroup of FOUR waves per CU (one wave per SIMD, 256 arch VGPRs + 256 AGPRs each), persistent over 256-row panels of A;
+  * wave w keeps ITS 64 rows x 512 k of A in the 256 AGPRs for a whole sweep over N (MFMA B operands read straight from the accumulator
+    file): A is fetched from HBM exactly once and never touches LDS;
+  * W streams L2 -> LDS by LDS-DMA, one 64-column x 512-k tile (64 KiB, rows XOR-swizzled on the DMA source address) per "n-step",
+    two buffers, ONE workgroup barrier per n-step (4096 MFMA cycles); the tile sequence 0, 1, .., N/64 - 1, 0, .. is shared by the
+    workgroup and never restarts;
+  * per n-step a wave issues 128 v_mfma_f32_32x32x16_bf16 (2 n-blocks x 2 m-blocks x 32 k-steps) against 64 ds_read_b128: 0.5 LDS
+    fragment reads per MFMA;
+  * TWO accumulator sets (2 x 64 VGPRs): while n-step j accumulates into one, the epilogue of n-step j-1 (bias is the accumulator's
+    initial value, activation / dropout / mask / residual, bf16 rounding, transposition through a wave-private 4-KiB LDS buffer, eight
+    full-line stores) is interleaved, instruction by instruction, into the gaps between the MFMAs of step j -- the C stores leave the CU
+    as a continuous trickle instead of a burst at the end of a 256x256 tile;
+  * PHASES: a wave's sweep over N may start at any tile of the shared sequence (the n-tiles of a panel are visited in a rotated order),
+    so wave w of workgroup g switches panels phi(g, w) = w * NS/4 + (g & cmask) steps after wave 0 of workgroup 0 does (it idles through
+    phi "dummy" steps at the start of the launch and (3 - w) * NS/4 at the end, serving the DMA and the barriers).  The next panel's A
+    fragments are fetched in the panel's last step, fragment by fragment as their last MFMA has been issued; with every wave of every
+    CU switching in the same step that was a chip-wide burst of 256 KiB per CU (measured: the last step took 22.8 k cycles instead of 5 k);
+    with phases the chip fetches A at a constant rate;
+  * every s_waitcnt is counted by this generator from a model of the in-order VM / LGKM queues; amdasm.Emu checks the result.
+
+The instruction stream is emitted by a list scheduler: each MFMA is followed by up to CAP "filler" groups taken from fixed slots
+(W fragment reads) and from ordered streams (LDS-DMA of the next W tile, epilogue of the previous step).  A group is emitted
+whole (carry chains through SCC, M0 write + DMA).
+"""
+import os as _os
+
+from safevla_amd.asmgen.amdasm import EXEC, M0, Prog, a, s, v
+
+KS = 32                    # k-steps of 16 (K = 512)
+LDS_W = (0, 32768)         # W half-tiles [64 n][256 k] (512-byte rows): k-lo halves always in buffer 0, k-hi halves in buffer 1
+LDS_XS = 65536             # 64 KiB staging of ONE wave's next A panel: [8 k-slices of 64 k][64 rows][128 B]; the waves' phases keep their windows apart
+LDS_STG = 131072           # + wave * 4096
+LDS_BIAS = 147456          # fp32 bias[N], N <= 4096 (the bias table doubles as the accumulator initialiser)
+LDS_BYTES = 163840
+
+# ---- kernel arguments (byte offsets in the kernarg segment)
+KARG = dict(A=0, lda=8, B=16, ldb=24, bias=32, res=40, ldr=48, C=56, ldc=64, cmask=72, N=76, alpha=80, npanels=84, bits=88,
+            key=96, thr=100, scale=104, row_mult=108, seed_dev=112, stream_key=120, grid=124)
+KARG_BYTES = 128
+
+# ---- SGPRs (s0..s3 are free after the prologue: timing builds use them)
+S_A, S_LDA, S_B, S_LDB, S_BIAS, S_RES, S_LDR, S_C = s(4, 2), s(6, 2), s(8, 2), s(10, 2), s(12, 2), s(14, 2), s(16, 2), s(18, 2)
+S_LDC, S_CMASK, S_N, S_ALPHA, S_NPANELS, S_BITS = s(20, 2), s(22), s(23), s(24), s(25), s(26, 2)
+S_KEY, S_THR, S_SCALE, S_ROWMULT, S_SEEDDEV, S_STREAMKEY, S_GRID = s(28), s(29), s(30), s(31), s(32, 2), s(34), s(35)
+S_WID = s(36)
+S_LDA2, S_LDC2, S_LDR2 = s(37), s(38), s(39)
+SRD_X, SRD_C, SRD_T = s(40, 4), s(48, 4), s(56, 4)
+S_DUM, S_NEXTN0 = s(44), s(45)        # dummy steps left; n0 of the next step
+S_WCUR = s(46, 2)                     # first W row of this wave's share of the CURRENT tile (row n0 + 16 w)
+S_WNEXT = [s(39), s(67)]              # ... of the next tile (lo, hi)
+S_XB, S_XRUN = s(14, 2), s(56, 2)     # next panel's A rows of this wave (row w * 64); running pointer of the staging DMA
+S_8LDA2, S_2LDB2 = s(16), s(17)
+S_P, S_PN = s(60), s(61)              # panel being accumulated; panel whose A is being fetched
+S_LOOP = s(62)
+S_WBASE_HI, S_LDB2, S_LDB2X48, S_WBASE = s(63), s(64), s(65), s(66)      # S_WBASE(_HI): B + w * 16 * ldb2
+S_NE2 = s(68)                         # 2 * n0 of the step whose epilogue is running
+S_N0 = s(69)                          # n0 of the step being accumulated
+S_CROW = [s(70 + i) for i in range(8)]   # store row offsets (w*64 + mb*32 + 8 it) * ldc2
+S_XROW = s(78)                        # w * 64 * lda2
+S_NB4 = s(79)                         # 4 * n0 of the next step (bias table offset)
+S_STMASK = s(80, 2)                   # exec mask of the epilogue stores (0 until this wave's first n-step has been computed)
+S_T = [s(82 + i) for i in range(8)]   # scratch
+S_WPTR = s(90, 2)                     # address of the next W row this wave fetches
+SRD_B = s(92, 4)                      # sign-bit buffer of the panel being stored (bits_out) / accumulated (bits_in)
+S_BROW = [s(96), s(97)]               # (w*2 + mb) * N * 4: byte offset of the wave's slab row-block in the panel's sign bits
+S_RN2, S_PPE = s(98), s(99)           # row_mult * N / 2 (dropout pairs per row); pair index of row 0 of the panel whose epilogue is running
+S_ONE1, S_THR1, S_C1, S_RN32 = s(52), s(53), s(54), s(55)      # 0x00010001; (thr - 1) in both halves; 0x9E3779B1; 32 * S_RN2
+S_LO32 = s(100, 2)                    # exec mask of lanes 0..31
+N_SGPR = 102
+
+
+# ---- VGPRs
+def ACC(st, nb, mb):
+    return v(st * 64 + (nb * 2 + mb) * 16, 16)
+
+
+def BIASR(nb):
+    return v(128 + nb * 16, 16)
+
+
+def WFRAG(ks, nb):
+    return v(160 + ((ks % 4) * 2 + nb) * 4, 4)
+
+
+V_WRD = [v(192 + j) for j in range(8)]
+V_DCH, V_DMATMP = v(200), v(201)       # W DMA: ((lane & 31) ^ (lane >> 5)) << 4 (source chunk before the per-row-pair XOR); scratch
+V_DROW, V_XSRC0 = v(250), v(251)       # W DMA: (lane >> 5) * ldb2; staging DMA source offset (even row groups)
+V_XP = [v(252 + i) for i in range(4)]  # staging read addresses of the A fragment with k-step kk inside its 64-k slice
+V_COFF, V_CSTEP, V_STW, V_STRD, V_BIASRD, V_BIASSTEP = v(202), v(203), v(204), v(205), v(206), v(207)
+V_XOFF = [v(208), v(209)]
+V_STWX = v(210)                       # staging write address of the current 8-byte piece
+V_PK = [v(212 + 2 * i, 2) for i in range(4)]       # converted pieces (rotating: a ds_write has read its data long before the pair comes round again)
+V_RB = [[v(220 + 4 * i, 4) for i in range(4)]] * 2      # read-back (row-major) pieces = store data (slab 0's stores are issued before slab 1's reads)
+V_L0, V_C8, V_H4 = v(236), v(237), v(211)           # flavour lane constants: dropout pair index of (row, 4 h); 8 * (lane & 31); 4 * (lane >> 5)
+V_F = [v(238 + i) for i in range(12)]               # flavour temporaries (v244.. double as prologue temporaries)
+V_TMP = [v(244 + i) for i in range(12)]
+
+
+def BW(par, mb):
+    """ReLU sign-bit words of a 32-row x 64-column slab as loaded (flavour bits_in has no bias: the bias registers' space)"""
+    return v(128 + (par * 2 + mb) * 2, 2)
+
+
+def XFRAG(mb, ks):
+    return a((mb * KS + ks) * 4, 4)
+
+
+class QModel:
+    """In-order completion queue (VM or LGKM) as the generator sees it: tags of the operations issued and not yet known retired."""
+
+    def __init__(self, maxcnt):
+        self.q = []
+        self.maxcnt = maxcnt
+
+    def issue(self, tag):
+        self.q.append(tag)
+
+    def need(self, tags):
+        """largest count n such that waiting for 'at most n outstanding' retires every tag in tags; None if none of them is in the queue"""
+        idx = [i for i, t in enumerate(self.q) if t in tags]
+        if not idx:
+            return None
+        return min(len(self.q) - 1 - max(idx), self.maxcnt)
+
+    def wait(self, n):
+        self.q = self.q[len(self.q) - n:] if n > 0 else []
+
+
+class NtAsGen:
+    CAP = 3            # filler groups per MFMA gap taken from the streams (fixed-slot instructions come on top)
+    PF_GAP = 24        # bits_in: the sign-bit words of this step's slabs are requested here (consumed ~100 gaps later)
+    XA_END = 52        # last gap of the first staging-DMA window of the step before a panel switch
+    WA_END, WB_END = 28, 92      # last gap of the two W DMA windows (k-hi half of this tile / k-lo half of the next): ~0.9 k cycles before their barriers
+    BAR0, BAR_GAP = 55, 119      # the two barriers of a step follow MFMA 55 / 119 (k-steps 13 / 29): the last fragment reads of each W half are issued 4 gaps earlier
+
+    def __init__(self, name="svla_nt_as_f0", relu=False, drop=False, bits_out=False, bits_in=False, cap=None, dbg="", stagger=0, epi_order=1, dma_end=None, store_nt=True, load_nt=False, wa_end=None, wb_end=None):
+        self.name = name
+        # epilogue flavour: relu (+ bits_out: the output's sign bits, + drop: train-mode dropout after the activation) | bits_in: alpha * product,
+        # zeroed where the ReLU sign bit of the forward activation is 0 (no bias) | none of them: + bias
+        self.relu, self.drop, self.bits_out, self.bits_in = relu, drop, bits_out, bits_in
+        self.bias = not bits_in
+        assert not (bits_in and (relu or drop or bits_out)) and (not bits_out or relu) and (not drop or relu)
+        self.dbg = set(dbg.split(",")) if dbg else set()      # timing-only / bisection builds (tools/): time, nostore, nodma, nox, noepi, ...
+        if cap is not None:
+            self.CAP = cap
+        self.stagger, self.epi_order, self.store_nt, self.load_nt = stagger, epi_order, store_nt, load_nt
+        if wa_end is not None:
+            self.WA_END = wa_end
+        if wb_end is not None:
+            self.WB_END = wb_end
+        self.p = Prog(name)
+        self.vm = QModel(63)
+        self.lg = QModel(15)
+        self.uid = 0
+        self.stats = {}
+
+    # ------------------------------------------------------------------ helpers
+    def tag(self, base):
+        self.uid += 1
+        return f"{base}#{self.uid}"
+
+    def wait_for(self, vm_tags=(), lg_tags=()):
+        nv = self.vm.need(set(vm_tags)) if vm_tags else None
+        nl = self.lg.need(set(lg_tags)) if lg_tags else None
+        if nv is None and nl is None:
+            return
+        self.p.s_waitcnt(vmcnt=nv, lgkmcnt=nl)
+        if nv is not None:
+            self.vm.wait(nv)
+        if nl is not None:
+            self.lg.wait(nl)
+
+    def lg_room(self):
+        # the LGKM counter has 4 bits: never let the model's queue pass 15 (LDS operations retire in order within ~100 cycles, so in
+        # steady state this wait finds its operations long retired)
+        if len(self.lg.q) >= 15:
+            self.p.s_waitcnt(lgkmcnt=11)
+            self.lg.wait(11)
+
+    def ds_read(self, d, addr, off, tag):
+        self.lg_room()
+        self.p.ds_read(d, addr, off)
+        self.lg.issue(tag)
+
+    def ds_write(self, addr, src, off=0):
+        self.lg_room()
+        self.p.ds_write(addr, src, off)
+        self.lg.issue(self.tag("dsw"))
+
+    # ------------------------------------------------------------------ prologue
+    def prologue(self):
+        p = self.p
+        T = V_TMP
+        p.s_load(s(4, 16), s(0, 2), 0)
+        p.s_load(s(20, 16), s(0, 2), 64)
+        p.v_and_b32(T[0], 63, v(0))                 # lane
+        p.v_lshrrev_b32(T[1], 6, v(0))              # wave
+        p.v_readfirstlane_b32(S_WID, T[1])
+        p.v_and_b32(T[2], 31, T[0])                 # c = lane & 31
+        p.v_lshrrev_b32(T[3], 5, T[0])              # h = lane >> 5
+        p.s_waitcnt(lgkmcnt=0)
+        p.s_mov_b64(S_STMASK, 0)
+        if "time" in self.dbg:
+            for i in range(28, 35):
+                p.s_mov_b32(s(i), 0)
+        p.s_lshl_b32(S_LDA2, S_LDA.sub(0), 1)
+        p.s_lshl_b32(S_LDC2, S_LDC.sub(0), 1)
+        p.s_lshl_b32(S_LDR2, S_LDR.sub(0), 1)
+        p.s_lshl_b32(S_LDB2, S_LDB.sub(0), 1)
+        p.s_mul_i32(S_LDB2X48, S_LDB2, 48)
+        p.s_lshl_b32(S_T[0], S_WID, 4)
+        p.s_mul_i32(S_T[1], S_T[0], S_LDB2)         # w * 16 * ldb2 (< 2^32: N <= 4096 rows)
+        p.s_add_u32(S_WBASE, S_B.sub(0), S_T[1])
+        p.s_addc_u32(S_WBASE_HI, S_B.sub(1), 0)
+        p.s_lshl_b32(S_2LDB2, S_LDB2, 1)
+        p.s_lshl_b32(S_8LDA2, S_LDA2, 3)
+        p.s_lshl_b32(S_T[0], S_WID, 6)
+        p.s_mul_i32(S_XROW, S_T[0], S_LDA2)         # w * 64 * lda2
+        for mb in range(2):
+            for it in range(4):
+                p.s_add_u32(S_T[1], S_T[0], mb * 32 + 8 * it)
+                p.s_mul_i32(S_CROW[mb * 4 + it], S_T[1], S_LDC2)
+        # descriptors: bias table source; A / C / residual per panel
+        p.s_mov_b32(SRD_T.sub(0), S_BIAS.sub(0))
+        p.s_and_b32(SRD_T.sub(1), S_BIAS.sub(1), 0xffff)
+        p.s_mov_b32(SRD_T.sub(3), 0x00020000)
+        for srd in (SRD_X, SRD_C, SRD_B):
+            p.s_mov_b32(srd.sub(2), 0xffffffff)
+            p.s_mov_b32(srd.sub(3), 0x00020000)
+        # ---- lane constants
+        # fragment read addresses: row c (512-byte pitch: one K half), logical 16-byte chunk 2 j + h, physical chunk = logical ^ (c & 15)
+        p.v_and_b32(T[4], 15, T[2])
+        p.v_lshlrev_b32(T[5], 9, T[2])              # c * 512
+        for j in range(8):
+            p.v_add_u32(T[6], 2 * j, T[3])
+            p.v_xor_b32(T[6], T[6], T[4])
+            p.v_lshl_add_u32(V_WRD[j], T[6], 4, T[5])
+        # W DMA: one instruction = 2 rows x 512 B; lane i lands at (row i >> 5, physical chunk i & 31) and fetches logical chunk
+        # (i & 31) ^ (row & 15), row & 15 = 2 t + (i >> 5) for the t-th instruction of the wave
+        p.v_lshrrev_b32(T[6], 5, T[0])
+        p.v_and_b32(T[7], 31, T[0])
+        p.v_xor_b32(T[7], T[7], T[6])
+        p.v_lshlrev_b32(V_DCH, 4, T[7])
+        # C store: lane -> (row lane >> 3, 16-byte chunk lane & 7)
+        p.v_lshrrev_b32(T[6], 3, T[0])              # lane >> 3
+        p.v_and_b32(T[7], 7, T[0])                  # lane & 7
+        p.v_mul_lo_u32(T[8], T[6], S_LDC2)
+        p.v_lshl_add_u32(V_COFF, T[7], 4, T[8])
+        # staging (wave-private 4 KiB at LDS_STG + w * 4096): [32 rows][128 B], 16-byte chunk q of row r stored at chunk q ^ (r & 7)
+        p.s_lshl_b32(S_T[2], S_WID, 12)
+        p.s_add_u32(S_T[2], S_T[2], LDS_STG)
+        p.v_and_b32(T[8], 7, T[2])                  # c & 7
+        p.v_lshlrev_b32(T[9], 7, T[2])              # c * 128
+        p.v_lshl_add_u32(T[9], T[8], 4, T[9])
+        p.v_lshl_add_u32(T[9], T[3], 3, T[9])       # + h * 8
+        p.v_add_u32(V_STW, S_T[2], T[9])
+        p.v_xor_b32(T[8], T[7], T[6])               # (lane & 7) ^ (lane >> 3)
+        p.v_lshlrev_b32(T[9], 7, T[6])
+        p.v_lshl_add_u32(T[9], T[8], 4, T[9])
+        p.v_add_u32(V_STRD, S_T[2], T[9])
+        p.v_lshlrev_b32(T[9], 4, T[3])
+        p.v_add_u32(V_BIASRD, LDS_BIAS, T[9])       # + h * 16
+        # A fragment loads: row (mb * 32 + c) of the wave's 64, 16 bytes at k = 16 ks + 8 h
+        for mb in range(2):
+            p.v_add_u32(T[8], mb * 32, T[2])
+            p.v_mul_lo_u32(T[8], T[8], S_LDA2)
+            p.v_lshl_add_u32(V_XOFF[mb], T[3], 4, T[8])
+        # ---- flavour constants
+        p.s_mov_b32(S_LO32.sub(0), 0xffffffff)
+        p.s_mov_b32(S_LO32.sub(1), 0)
+        p.v_lshlrev_b32(V_H4, 2, T[3])              # 4 h
+        p.v_lshlrev_b32(V_C8, 3, T[2])              # 8 c
+        p.s_lshl_b32(S_T[0], S_WID, 1)
+        for mb in range(2):
+            p.s_add_u32(S_T[1], S_T[0], mb)
+            p.s_mul_i32(S_T[1], S_T[1], S_N)
+            p.s_lshl_b32(S_BROW[mb], S_T[1], 2)     # (w*2 + mb) * (N/64) * 256
+        if self.drop:
+            p.s_mul_i32(S_RN2, S_ROWMULT, S_N)
+            p.s_lshr_b32(S_RN2, S_RN2, 1)
+            p.s_lshl_b32(S_RN32, S_RN2, 5)
+            p.s_mov_b32(S_ONE1, 0x00010001)
+            p.s_sub_u32(S_T[1], S_THR, 1)
+            p.s_mul_i32(S_THR1, S_T[1], S_ONE1)      # (thr - 1) in both halves (thr <= 0xffff)
+            p.s_mov_b32(S_C1, 0x9E3779B1)
+            # pair index of (row w*64 + c of the panel, column 4 h): ((w*64 + c) * row_mult * N + 4 h) / 2; the host guarantees < 2^32 pairs
+            p.s_lshl_b32(S_T[1], S_WID, 6)
+            p.v_add_u32(T[8], S_T[1], T[2])
+            p.v_mul_lo_u32(T[8], T[8], S_RN2)
+            p.v_lshl_add_u32(V_L0, T[3], 1, T[8])
+            # device-resident pass seed (recorded launch sequences): key = *seed_dev ^ stream_key
+            p.s_or_b32(S_T[1], S_SEEDDEV.sub(0), S_SEEDDEV.sub(1))
+            p.s_cmp("eq_u32", S_T[1], 0)
+            p.s_cbranch_scc1("L_KEYOK")
+            p.s_load(S_KEY, S_SEEDDEV, 0)
+            p.s_waitcnt(lgkmcnt=0)
+            p.s_xor_b32(S_KEY, S_KEY, S_STREAMKEY)
+            p.label("L_KEYOK")
+        elif self.bits_out:
+            p.s_mov_b32(S_ONE1, 0x00010001)
+        if self.bias:
+            self.bias_table()
+        # ---- phase of this wave: phi = w * NS/4 + (workgroup & cmask) dummy steps before its first panel, (3 - w) * NS/4 after its last
+        p.s_lshr_b32(S_T[0], S_N, 8)                # NS / 4
+        p.s_mul_i32(S_DUM, S_WID, S_T[0])
+        p.s_and_b32(S_T[1], s(2), S_CMASK)
+        p.s_add_u32(S_DUM, S_DUM, S_T[1])
+        # ---- first panel
+        p.s_mov_b32(S_P, s(2))
+        p.s_mov_b32(S_PN, s(2))
+        self.panel_srd(SRD_X, S_A, S_PN, S_LDA2)
+        for ks in range(KS):
+            for mb in range(2):
+                if "nox" not in self.dbg:
+                    p.buffer_load(XFRAG(mb, ks), V_XOFF[mb], SRD_X, S_XROW, ks * 32)
+            if ks == 23:
+                p.s_waitcnt(vmcnt=0)
+        # ---- ROTATION: workgroup g starts the shared tile sequence at tile (g mod NS).  Without it every CU of the chip stores the same
+        # 128-byte column of C (row stride 2 N bytes: one L2 / HBM channel group) and fetches the same W tile at the same moment.
+        p.s_lshr_b32(S_T[0], S_N, 6)                # NS
+        p.s_mov_b32(S_T[1], s(2))
+        p.label("L_ROT")
+        p.s_cmp("lt_u32", S_T[1], S_T[0])
+        p.s_cbranch_scc1("L_ROTD")
+        p.s_sub_u32(S_T[1], S_T[1], S_T[0])
+        p.s_branch("L_ROT")
+        p.label("L_ROTD")
+        p.s_lshl_b32(S_N0, S_T[1], 6)               # n0 of the first tile
+        p.s_mul_i32(S_T[2], S_N0, S_LDB2)           # byte offset of its first row (< 2^32)
+        p.s_add_u32(S_WCUR.sub(0), S_WBASE, S_T[2])
+        p.s_addc_u32(S_WCUR.sub(1), S_WBASE_HI, 0)
+        # ---- lane constants of the W / staging DMAs and of the staging reads (v250..v255: written last, they alias prologue temporaries)
+        p.v_and_b32(T[0], 63, v(0))                 # lane
+        p.v_lshrrev_b32(T[1], 5, T[0])
+        p.v_mul_lo_u32(V_DROW, T[1], S_LDB2)        # (lane >> 5) * ldb2
+        # staging DMA: one instruction = 8 rows x 128 B of a 64-k slice; lane i lands at (row 8 q + (i >> 3), physical chunk i & 7) and fetches
+        # logical chunk (i & 7) ^ ((row >> 1) & 7), (row >> 1) & 7 = (i >> 4) for even q, (i >> 4) ^ 4 for odd q (one XOR of 64 on the offset)
+        p.v_lshrrev_b32(T[1], 3, T[0])
+        p.v_mul_lo_u32(T[2], T[1], S_LDA2)
+        p.v_and_b32(T[3], 7, T[0])
+        p.v_lshrrev_b32(T[4], 4, T[0])
+        p.v_xor_b32(T[3], T[3], T[4])
+        p.v_lshl_add_u32(V_XSRC0, T[3], 4, T[2])
+        # staging reads: fragment (mb, ks = 4 slice + kk): row mb*32 + c of the slice, logical chunk 2 kk + h -> physical ^ ((c >> 1) & 7)
+        p.v_and_b32(T[1], 31, T[0])                 # c
+        p.v_lshrrev_b32(T[2], 5, T[0])              # h
+        p.v_lshrrev_b32(T[3], 1, T[1])
+        p.v_and_b32(T[3], 7, T[3])
+        p.v_lshlrev_b32(T[4], 7, T[1])              # c * 128
+        p.v_add_u32(T[4], LDS_XS, T[4])
+        for kk in range(4):
+            p.v_add_u32(T[5], 2 * kk, T[2])
+            p.v_xor_b32(T[5], T[5], T[3])
+            p.v_lshl_add_u32(V_XP[kk], T[5], 4, T[4])
+        # ---- k-lo half of the first tile -> buffer 0 (its k-hi half is fetched by the first step itself, like every step's)
+        for grp in self.wdma_groups(0, S_WCUR, tagbase="dmaL"):
+            for th in grp:
+                th()
+        p.s_waitcnt(vmcnt=0, lgkmcnt=0)
+        self.vm.wait(0)
+        self.lg.wait(0)
+        if "time" in self.dbg:
+            p.s_memtime(s(0, 2))
+            p.s_waitcnt(lgkmcnt=0)
+            p.s_mov_b32(s(28), s(0))
+        p.s_barrier()
+        if self.bias:
+            p.s_lshl_b32(S_T[2], S_N0, 2)
+            p.v_add_u32(V_BIASSTEP, S_T[2], V_BIASRD)
+            for nb in range(2):
+                for rg in range(4):
+                    p.ds_read(BIASR(nb).sub(4 * rg, 4), V_BIASSTEP, nb * 128 + rg * 32)
+        for ks in range(3):
+            for nb in range(2):
+                self.wread(ks, nb)
+
+    def bias_table(self):
+        """bias[N] -> LDS (the host always passes a bias pointer: zeros when the GEMM has none)"""
+        p = self.p
+        T = V_TMP
+        p.v_lshlrev_b32(T[8], 2, v(0))
+        p.v_add_u32(T[9], LDS_BIAS, T[8])
+        p.s_mov_b32(S_T[3], 0)
+        p.s_lshl_b32(S_T[4], S_N, 2)
+        p.s_mov_b32(SRD_T.sub(2), S_T[4])           # num_records = 4 N: reads past bias[N) return 0
+        p.label("L_BIAS")
+        if "nobias" in self.dbg:
+            p.v_mov_b32(T[10], 0)
+        else:
+            p.buffer_load(T[10], T[8], SRD_T, S_T[3])
+        p.s_waitcnt(vmcnt=0)
+        p.ds_write(T[9], T[10])
+        p.v_add_u32(T[9], 1024, T[9])
+        p.s_add_u32(S_T[3], S_T[3], 1024)
+        p.s_cmp("lt_u32", S_T[3], S_T[4])
+        p.s_cbranch_scc1("L_BIAS")
+
+    def panel_srd(self, srd, base, panel, ld2):
+        """srd.base = base + panel * 256 * ld2 (64-bit); one group: the carry travels through SCC"""
+        p = self.p
+        p.s_lshl_b32(S_T[5], panel, 8)
+        p.s_mul_hi_u32(S_T[6], S_T[5], ld2)
+        p.s_mul_i32(S_T[5], S_T[5], ld2)
+        p.s_add_u32(srd.sub(0), base.sub(0), S_T[5])
+        p.s_addc_u32(S_T[6], base.sub(1), S_T[6])
+        p.s_and_b32(srd.sub(1), S_T[6], 0xffff)
+
+    def bits_srd(self, panel):
+        """SRD_B.base = bits + panel * 8 slab rows * (N/64) slabs * 256 B = bits + panel * N * 32"""
+        p = self.p
+        p.s_mul_i32(S_T[5], panel, S_N)
+        p.s_lshl_b32(S_T[5], S_T[5], 5)
+        p.s_add_u32(SRD_B.sub(0), S_BITS.sub(0), S_T[5])
+        p.s_addc_u32(S_T[6], S_BITS.sub(1), 0)
+        p.s_and_b32(SRD_B.sub(1), S_T[6], 0xffff)
+
+    def flavour_panel_scalars(self):
+        """quantities of the panel whose epilogue runs from now on (set where SRD_C is)"""
+        p = self.p
+        if self.bits_out:
+            self.bits_srd(S_P)
+        if self.drop:
+            p.s_lshl_b32(S_T[5], S_P, 8)
+            p.s_mul_i32(S_PPE, S_T[5], S_RN2)
+
+    def wdma_groups(self, half, base, tagbase):
+        """scheduler groups: the 8 LDS-DMA instructions with which this wave fetches its 16 rows (2 per instruction) of one K half of a W tile
+        whose first row of the wave's share is at `base` (an SGPR pair, or a [lo, hi] list), into buffer `half`"""
+        p = self.p
+        lo, hi = (base.sub(0), base.sub(1)) if not isinstance(base, list) else base
+        groups = []
+        for t in range(8):
+            def g(t=t):
+                if t == 0:
+                    p.s_add_u32(S_WPTR.sub(0), lo, half * 512)
+                    p.s_addc_u32(S_WPTR.sub(1), hi, 0)
+                else:
+                    p.s_add_u32(S_WPTR.sub(0), S_WPTR.sub(0), S_2LDB2)
+                    p.s_addc_u32(S_WPTR.sub(1), S_WPTR.sub(1), 0)
+                p.s_lshl_b32(S_T[4], S_WID, 13)         # this wave's rows 16 w .. of the half-tile: 16 * 512 B
+                p.s_add_u32(M0, S_T[4], LDS_W[half] + t * 1024)
+                p.v_xor_b32(V_DMATMP, (2 * t) << 4, V_DCH)      # logical chunk = physical ^ (row & 15), row & 15 = 2 t + (lane >> 5)
+                p.v_add_u32(V_DMATMP, V_DMATMP, V_DROW)
+                if "nodma" not in self.dbg:
+                    p.global_load_lds_x4(V_DMATMP, S_WPTR)
+                    self.vm.issue(f"{tagbase}{t}")
+            groups.append([g])
+        return groups
+
+    def xdma_groups(self):
+        """scheduler groups: the 64 LDS-DMA instructions that stage this wave's rows of the NEXT panel (8 rows x 128 B each, slice-major)"""
+        p = self.p
+        groups = []
+        for ksg in range(KS // 4):
+            for q in range(8):
+                def g(ksg=ksg, q=q):
+                    if q == 0:
+                        p.s_add_u32(S_XRUN.sub(0), S_XB.sub(0), ksg * 128)
+                        p.s_addc_u32(S_XRUN.sub(1), S_XB.sub(1), 0)
+                    else:
+                        p.s_add_u32(S_XRUN.sub(0), S_XRUN.sub(0), S_8LDA2)
+                        p.s_addc_u32(S_XRUN.sub(1), S_XRUN.sub(1), 0)
+                    p.s_mov_b32(M0, LDS_XS + ksg * 8192 + q * 1024)
+                    src = V_XSRC0
+                    if q & 1:
+                        p.v_xor_b32(V_DMATMP, 64, V_XSRC0)
+                        src = V_DMATMP
+                    else:
+                        p.s_nop(0)
+                    if "nox" not in self.dbg:
+                        p.global_load_lds_x4(src, S_XRUN)
+                        self.vm.issue(f"xd{ksg}")
+                groups.append([g])
+        return groups
+
+    def wread(self, ks, nb):
+        j = ks % 8
+        self.ds_read(WFRAG(ks, nb), V_WRD[j], LDS_W[ks // 16] + nb * 16384 + ((ks % 16) // 8) * 256, f"w{ks}_{nb}")
+
+    def step_head(self):
+        """scalar bookkeeping every step starts with (one block, before its first MFMA): the next tile's n0 and first W row (the tile sequence
+        wraps at N)"""
+        p = self.p
+        p.s_add_u32(S_NEXTN0, S_N0, 64)
+        p.s_cmp("eq_u32", S_NEXTN0, S_N)
+        p.s_cselect_b32(S_NEXTN0, 0, S_NEXTN0)
+        p.s_lshl_b32(S_NB4, S_NEXTN0, 2)
+        p.s_lshl_b32(S_T[4], S_LDB2, 6)             # 64 rows
+        p.s_add_u32(S_WNEXT[0], S_WCUR.sub(0), S_T[4])
+        p.s_addc_u32(S_WNEXT[1], S_WCUR.sub(1), 0)
+        p.s_cmp("eq_u32", S_NEXTN0, 0)
+        p.s_cselect_b32(S_WNEXT[0], S_WBASE, S_WNEXT[0])
+        p.s_cselect_b32(S_WNEXT[1], S_WBASE_HI, S_WNEXT[1])
+
+    def barrier(self, kind, which):
+        """which = 0: after k-step 13 -- every read of the k-lo half retired (buffer 0 may be refilled), own pieces of this tile's k-hi half landed;
+        which = 1: after k-step 29 -- the same with the halves exchanged and the NEXT tile's k-lo half"""
+        p = self.p
+        tags = {f"{'dmaH' if which == 0 else 'dmaL'}{t}" for t in range(8)}
+        nv = self.vm.need(tags)
+        if "time" in self.dbg and which == 1:
+            p.s_memtime(s(0, 2))
+        p.s_waitcnt(vmcnt=nv if nv is not None else 0, lgkmcnt=0)
+        self.vm.wait(nv if nv is not None else 0)
+        self.lg.wait(0)
+        if "time" in self.dbg and which == 1:
+            if kind != "dummy":
+                ki = {"first": 0, "mid": 1, "prelast": 1, "last": 2}[kind]
+                p.s_sub_u32(s(3), s(0), s(28))
+                p.s_add_u32(s(29 + ki), s(29 + ki), s(3))
+                p.s_add_u32(s(32 + ki), s(32 + ki), 1)
+            p.s_mov_b32(s(28), s(0))
+        p.s_barrier()
+
+    def step_tail_scalars(self):
+        p = self.p
+        p.s_lshl_b32(S_NE2, S_N0, 1)
+        p.s_mov_b32(S_N0, S_NEXTN0)
+        p.s_mov_b32(S_WCUR.sub(0), S_WNEXT[0])
+        p.s_mov_b32(S_WCUR.sub(1), S_WNEXT[1])
+
+    # ------------------------------------------------------------------ epilogue of one n-step (previous step's accumulators)
+    def epi_stream(self, st, masked, earliest, late=None):
+        """list of (earliest_gap, [thunks]): the epilogue of accumulator set st, stores optionally under S_STMASK.  Order (epi_order 1):
+        convert + stage slab 0, read it back, convert + stage slab 1 (LDS operations of a wave execute in order: the writes follow the
+        reads), store slab 0, read slab 1 back, [late: groups of the caller, e.g. the next step's bias reads], store slab 1 -- no store waits
+        for a read-back issued just ahead of it."""
+        p = self.p
+        items = []
+
+        def add(*ths, e=earliest):
+            items.append((e, list(ths)))
+        add(lambda: p.v_add_u32(V_CSTEP, S_NE2, V_COFF))
+
+        C1 = 0x9E3779B1
+        F = V_F
+        VS, X, TT, MSK, A1, OBW = F[0:4], F[4], F[5], F[6], F[7], [F[8], F[9]]      # OBW: an even-aligned pair (one 8-byte store)
+        U, U2 = F[10], F[11]
+        BS = [F[6], F[7]]
+        par = st          # accumulator set whose epilogue this is = parity of the sign-bit words prefetched for it
+
+        def step_scalars():
+            # per-step scalars of the epilogue's slabs: dropout pair offsets, sign-bit slab offsets
+            if self.drop:
+                p.s_lshr_b32(S_T[0], S_NE2, 2)
+                p.s_add_u32(S_T[0], S_T[0], S_PPE)
+                p.s_add_u32(S_T[1], S_T[0], S_RN32)
+            if self.bits_out:
+                p.s_lshl_b32(S_T[2], S_NE2, 1)
+                p.s_add_u32(S_T[3], S_T[2], S_BROW[1])
+                p.s_add_u32(S_T[2], S_T[2], S_BROW[0])
+        if self.drop or self.bits_out:
+            add(step_scalars)
+
+        def convert(mb):
+            if self.drop:
+                # A1 = pair index of (this lane's row, column n0 + 4 h) times C1; pair c of the slab row: (A1 + c C1) ^ key -> drop_mix
+                add(lambda mb=mb: p.v_add_u32(A1, S_T[mb], V_L0))
+                add(lambda: p.v_mul_lo_u32(A1, A1, S_C1))
+            if self.bits_in:
+                def shift(mb=mb):
+                    self.wait_for(vm_tags=[f"bw{par}_{mb}"])
+                    for nb in range(2):
+                        p.v_lshrrev_b32(BS[nb], V_H4, BW(par, mb).sub(nb))      # bit 8 rg + e = the sign bit of column nb*32 + 8 rg + 4 h + e
+                add(shift)
+            for nb in range(2):
+                for rg in range(4):
+                    gi = nb * 4 + rg
+                    acc = ACC(st, nb, mb)
+                    pk = V_PK[gi % 4]
+                    for pr in range(2):
+                        src = [acc.sub(4 * rg + 2 * pr), acc.sub(4 * rg + 2 * pr + 1)]
+                        if self.bits_in:
+                            def masked_pair(src=src, pr=pr, nb=nb, rg=rg, pk=pk):
+                                for e in range(2):
+                                    p.v_bfe_i32(TT, BS[nb], 8 * rg + 2 * pr + e, 1)
+                                    p.v_mul_f32(VS[e], S_ALPHA, src[e])
+                                    p.v_and_b32(VS[e], TT, VS[e])
+                                p.v_cvt_pk_bf16_f32(pk.sub(pr), VS[0], VS[1])
+                            add(masked_pair)
+                            continue
+                        if self.drop:
+                            c = nb * 16 + rg * 4 + pr
+
+                            def hash_pair(c=c):
+                                p.v_add_u32(X, (c * C1) & 0xffffffff, A1)
+                                p.v_xor_b32(X, S_KEY, X)
+                                p.v_lshrrev_b32(TT, 16, X)
+                                p.v_xor_b32(X, TT, X)
+                                p.v_mul_u32_u24(X, 0xEB352D, X)
+                                p.v_lshrrev_b32(TT, 13, X)
+                                p.v_xor_b32(X, TT, X)
+                                p.v_mul_u32_u24(X, 0x6CA68B, X)
+                                p.v_lshrrev_b32(TT, 16, X)
+                                p.v_xor_b32(X, TT, X)
+                            add(hash_pair)
+
+                            def keep_mask():
+                                # per 16-bit half: all ones where the half >= thr (kept): sat(half - (thr - 1)) != 0
+                                p.v_pk_sub_u16(MSK, X, S_THR1, clamp=True)
+                                p.v_pk_min_u16(MSK, MSK, S_ONE1)
+                                p.v_pk_sub_u16(MSK, 0, MSK)
+                            add(keep_mask)
+
+                            def scaled(src=src, pr=pr, pk=pk):
+                                p.v_mul_f32(VS[0], S_SCALE, src[0])
+                                p.v_mul_f32(VS[1], S_SCALE, src[1])
+                                p.v_cvt_pk_bf16_f32(pk.sub(pr), VS[0], VS[1])
+                            add(scaled)
+                            add(lambda pk=pk, pr=pr: (p.v_pk_max_i16(pk.sub(pr), pk.sub(pr), 0), p.v_and_b32(pk.sub(pr), MSK, pk.sub(pr))))
+                        else:
+                            add(lambda src=src, pk=pk, pr=pr: p.v_cvt_pk_bf16_f32(pk.sub(pr), src[0], src[1]))
+                            if self.relu:
+                                add(lambda pk=pk, pr=pr: p.v_pk_max_i16(pk.sub(pr), pk.sub(pr), 0))      # negative halves (and -0) -> +0
+                    if self.bits_out:
+                        def signbits(pk=pk, nb=nb, rg=rg):
+                            # outputs are >= +0: min(half, 1) per half, the four bits folded into a nibble at bit 8 rg of the slab row's word
+                            p.v_pk_min_u16(U, pk.sub(0), S_ONE1)
+                            p.v_pk_min_u16(U2, pk.sub(1), S_ONE1)
+                            p.v_lshl_or_b32(U, U2, 2, U)
+                            p.v_lshrrev_b32(U2, 15, U)
+                            p.v_or_b32(U, U2, U)
+                            p.v_and_b32(U, 15, U)
+                            if rg == 0:
+                                p.v_mov_b32(OBW[nb], U)
+                            else:
+                                p.v_lshl_or_b32(OBW[nb], U, 8 * rg, OBW[nb])
+                        add(signbits)
+                    add(lambda gi=gi: p.v_xor_b32(V_STWX, gi << 4, V_STW))
+                    add(lambda pk=pk: self.ds_write(V_STWX, pk))
+            if self.bits_out:
+                def bits_store(mb=mb):
+                    # lanes c and c + 32 hold the two interleaved nibble sets of row c: shift into place, merge, ONE 8-byte store per row
+                    for nb in range(2):
+                        p.v_lshlrev_b32(OBW[nb], V_H4, OBW[nb])
+                        p.v_mov_b32(U, OBW[nb])
+                        p.v_permlane32_swap(OBW[nb], U)
+                        p.v_or_b32(OBW[nb], U, OBW[nb])      # lanes 0..31: own | partner's
+                    if "nostore" in self.dbg:
+                        return
+                    if masked:
+                        p.s_and_b64(EXEC, S_STMASK, S_LO32)
+                    else:
+                        p.s_mov_b64(EXEC, S_LO32)
+                    p.buffer_store(v(OBW[0].idx, 2), V_C8, SRD_B, S_T[2 + mb])
+                    self.vm.issue(self.tag("stb"))
+                    p.s_mov_b64(EXEC, -1)
+                add(bits_store)
+
+        def readback(mb):
+            tags = []
+            for it in range(4):
+                tg = self.tag(f"rb{mb}_{it}")
+                tags.append(tg)
+                add(lambda it=it, tg=tg, mb=mb: self.ds_read(V_RB[mb][it], V_STRD, it * 1024, tg))
+            return tags
+
+        def stores(mb, tags):
+            for it in range(4):
+                def st_(it=it, mb=mb, tags=tags):
+                    self.wait_for(lg_tags=[tags[it]])
+                    if "nostore" in self.dbg:
+                        return
+                    if masked:
+                        p.s_mov_b64(EXEC, S_STMASK)
+                    p.buffer_store(V_RB[mb][it], V_CSTEP, SRD_C, S_CROW[mb * 4 + it], nt=self.store_nt)
+                    self.vm.issue(self.tag("st"))
+                    if masked:
+                        p.s_mov_b64(EXEC, -1)
+                add(st_)
+        if self.epi_order == 0:
+            for mb in range(2):
+                convert(mb)
+                stores(mb, readback(mb))
+            items += late or []
+        else:
+            convert(0)
+            t0 = readback(0)
+            convert(1)
+            stores(0, t0)
+            t1 = readback(1)
+            items += late or []
+            stores(1, t1)
+        return items
+
+    # ------------------------------------------------------------------ one n-step body
+    def body(self, kind, st):
+        """kind: 'first' | 'mid' | 'prelast' | 'last' step of this wave's sweep over a panel; st: accumulator set of this step"""
+        p = self.p
+        NG = 4 * KS
+        B0, B1 = self.BAR0, self.BAR_GAP
+        fixed = [[] for _ in range(NG)]
+        pre = [[] for _ in range(NG)]
+
+        # ---- W fragment reads, ring of 4 k-steps: (ks + 3, nb) right after the MFMA (ks, nb, mb = 0).  The first three k-steps of a W half
+        # (k-steps 16..18, and 0..2 of the next tile) are read behind the barrier that publishes it, at gaps B + 1 .. B + 6.
+        for ks in range(KS):
+            k3 = ks + 3
+            for nb in range(2):
+                if k3 in (16, 17, 18):
+                    g = B0 + 1 + 2 * (k3 - 16) + nb
+                elif k3 >= KS:
+                    g = B1 + 1 + 2 * (k3 - KS) + nb
+                else:
+                    g = 4 * ks + 2 * nb + 1
+                fixed[g].append(lambda k3=k3 % KS, nb=nb: self.wread(k3, nb))
+        fixed[B0].append(lambda: self.barrier(kind, 0))
+        fixed[B1].append(lambda: self.barrier(kind, 1))
+
+        # ---- LDS-DMA: this tile's k-hi half into buffer 1 (freed by the previous step's second barrier), the next tile's k-lo half into buffer 0
+        # (freed by this step's first barrier)
+        self.step_head()
+        streams = [[(1, grp) for grp in self.wdma_groups(1, S_WCUR, "dmaH")], [(B0 + 1, grp) for grp in self.wdma_groups(0, S_WNEXT, "dmaL")]]
+        windows = [(1, self.WA_END), (B0 + 2, self.WB_END)]
+        flush = [B0 - 1, B1 - 1]
+
+        if kind == "prelast":
+            # ---- the step before the panel switch: this wave's rows of the next panel -> staging (64 KiB: during these two steps it is this wave's)
+            p.s_add_u32(S_PN, S_P, S_GRID)
+            p.s_sub_u32(S_T[7], S_NPANELS, 1)
+            p.s_min_u32(S_PN, S_PN, S_T[7])          # past the end: stage the last panel again (never used)
+            p.s_lshl_b32(S_T[5], S_PN, 8)
+            p.s_lshl_b32(S_T[6], S_WID, 6)
+            p.s_add_u32(S_T[5], S_T[5], S_T[6])      # row pn * 256 + w * 64
+            p.s_mul_hi_u32(S_T[6], S_T[5], S_LDA2)
+            p.s_mul_i32(S_T[5], S_T[5], S_LDA2)
+            p.s_add_u32(S_XB.sub(0), S_A.sub(0), S_T[5])
+            p.s_addc_u32(S_XB.sub(1), S_A.sub(1), S_T[6])
+            # VM operations retire in order: a staging DMA (HBM latency) OLDER than a W DMA (L2 latency) makes the barrier's wait for the W half
+            # wait out the HBM round trip (measured: every panel switch cost ~4.4 k cycles whichever way the panel was fetched).  So in each barrier
+            # interval the W DMAs go first and the staging DMAs behind them: they may stay outstanding across the interval's barrier and have
+            # ~1.8 intervals before the next W wait needs them retired.
+            xg = self.xdma_groups()
+            half = len(xg) // 2
+            streams.append([(self.WA_END + 1, grp) for grp in xg[:half]])
+            windows.append((self.WA_END + 1, self.XA_END))
+            flush.append(B0 - 1)
+            streams.append([(self.WB_END + 1, grp) for grp in xg[half:]])
+            windows.append((self.WB_END + 1, B1 - 2))
+            flush.append(B1 - 1)
+        if kind == "last":
+            # ---- panel switch: the next panel's fragments move staging -> AGPRs as their last MFMA has been issued (the staged slice landed:
+            # own DMA, counted vmcnt -- no barrier, the staging is this wave's)
+            for ks in range(KS):
+                def xr(ks=ks):
+                    ksg, kk = divmod(ks, 4)
+                    if kk == 0:
+                        self.wait_for(vm_tags=[f"xd{ksg}"])
+                    if "nox" in self.dbg:
+                        return
+                    for mb in range(2):
+                        self.ds_read(XFRAG(mb, ks), V_XP[kk], ksg * 8192 + mb * 4096, f"xr{ks}")
+                fixed[4 * ks + 3].append(xr)
+        if kind == "first":
+            for ks in range(KS):
+                pre[4 * ks].append(("lg", f"xr{ks}"))
+        if self.bits_in:
+            if kind == "first":
+                self.bits_srd(S_P)
+
+            def prefetch_bits():
+                for mb in range(2):
+                    p.s_lshl_b32(S_T[4], S_N0, 2)
+                    p.s_add_u32(S_T[4], S_T[4], S_BROW[mb])
+                    p.buffer_load(BW(st, mb), V_C8, SRD_B, S_T[4])
+                    self.vm.issue(f"bw{st}_{mb}")
+            fixed[self.PF_GAP].append(prefetch_bits)
+
+        # ---- epilogue of the previous step, bias registers of the next step, then the bookkeeping that must follow the epilogue
+        late = []
+        if self.bias:
+            late.append((16, [lambda: p.v_add_u32(V_BIASSTEP, S_NB4, V_BIASRD)]))
+            for nb in range(2):
+                for rg in range(4):
+                    late.append((16, [lambda nb=nb, rg=rg: self.ds_read(BIASR(nb).sub(4 * rg, 4), V_BIASSTEP, nb * 128 + rg * 32, self.tag("bias"))]))
+        epi = self.epi_stream(st ^ 1, masked=(kind == "first"), earliest=8, late=late) if "noepi" not in self.dbg else late
+        epi.append((B0 + 8, [self.step_tail_scalars]))          # after the second DMA window has read S_WNEXT
+        if kind == "first":
+            def first_tail():
+                p.s_mov_b64(S_STMASK, -1)
+                self.panel_srd(SRD_C, S_C, S_P, S_LDC2)
+                self.flavour_panel_scalars()
+                p.s_lshr_b32(S_LOOP, S_N, 7)
+                p.s_sub_u32(S_LOOP, S_LOOP, 2)
+            epi.append((16, [first_tail]))
+        streams.append(epi)
+        windows.append((8, B1 - 1))
+        flush.append(B1 - 1)
+
+        # ---- emit: every stream is paced over its window of gaps (group k of n due at first + k * span / n); a stream is flushed at its deadline
+        pos = [0] * len(streams)
+        nfill = 0
+        for g in range(NG):
+            ks, i = divmod(g, 4)
+            nb, mb = divmod(i, 2)
+            lg_tags = [f"w{ks}_{nb}"] + [t for (q, t) in pre[g] if q == "lg"]
+            if ks == 0:
+                lg_tags += [t for t in self.lg.q if t.startswith("bias")]
+            self.wait_for(lg_tags=lg_tags)
+            c = (BIASR(nb) if self.bias else 0) if ks == 0 else ACC(st, nb, mb)
+            p.v_mfma_f32_32x32x16_bf16(ACC(st, nb, mb), WFRAG(ks, nb), XFRAG(mb, ks), c)
+            for si, sm in enumerate(streams):
+                if g > flush[si]:
+                    continue
+                g0, g1 = windows[si]
+                due = len(sm) if (g >= g1 or g == flush[si]) else (0 if g < g0 else (len(sm) * (g - g0 + 1) + (g1 - g0)) // (g1 - g0 + 1))
+                n = 0
+                while pos[si] < due and (sm[pos[si]][0] <= g or g == flush[si]) and (n < self.CAP or g == flush[si]):
+                    for th in sm[pos[si]][1]:
+                        th()
+                    pos[si] += 1
+                    n += 1
+                    nfill += 1
+            for th in fixed[g]:
+                th()
+        for si, sm in enumerate(streams):
+            assert pos[si] == len(sm), (kind, si, pos[si], len(sm))
+        self.stats[(kind, st)] = nfill
+
+    def dummy_body(self):
+        """a step of a wave that has no panel in flight (before its first / after its last): its share of both W DMA windows, the two barriers,
+        the fragment reads behind the second (never consumed: they keep the LGKM state every step starts with), no MFMA, no epilogue"""
+        p = self.p
+        p.s_waitcnt(lgkmcnt=0)          # the fragment / bias reads the previous step left in flight: nobody consumes them here
+        self.lg.wait(0)
+        self.step_head()
+        for grp in self.wdma_groups(1, S_WCUR, "dmaH"):
+            for th in grp:
+                th()
+        self.barrier("dummy", 0)
+        for grp in self.wdma_groups(0, S_WNEXT, "dmaL"):
+            for th in grp:
+                th()
+        if self.bias:
+            p.v_add_u32(V_BIASSTEP, S_NB4, V_BIASRD)          # the next step may be this wave's first real one: its accumulator initialiser
+            for nb in range(2):
+                for rg in range(4):
+                    self.ds_read(BIASR(nb).sub(4 * rg, 4), V_BIASSTEP, nb * 128 + rg * 32, self.tag("bias"))
+        self.barrier("dummy", 1)
+        for k in range(3):
+            for nb in range(2):
+                self.wread(k, nb)
+        self.step_tail_scalars()
+
+    # ------------------------------------------------------------------ whole kernel
+    def build(self):
+        p = self.p
+        self.prologue()
+        p.label("L_DUMA")
+        # FIRST's counted waits assume the LGKM queue its run-time predecessor LAST leaves behind (fragment reads interleaved with the staging
+        # reads of the panel switch); entered from here, everything must simply have retired
+        p.s_waitcnt(lgkmcnt=0)
+        self.lg.wait(0)
+        p.s_cmp("eq_u32", S_DUM, 0)
+        p.s_cbranch_scc1("L_FIRST")
+        self.dummy_body()
+        p.s_sub_u32(S_DUM, S_DUM, 1)
+        p.s_branch("L_DUMA")
+        # the first generated body (LAST) is entered from a PRELAST step at run time: seed the queue models with what MID + PRELAST leave behind
+        real, self.p = self.p, Prog("scratch")
+        self.body("mid", 1)
+        self.body("prelast", 0)
+        self.p = real
+        p.label("L_LAST")
+        self.body("last", 1)
+        p.s_add_u32(S_P, S_P, S_GRID)
+        p.s_cmp("ge_u32", S_P, S_NPANELS)
+        p.s_cbranch_scc1("L_DRAIN")
+        p.label("L_FIRST")
+        self.body("first", 0)
+        self.body("mid", 1)
+        p.s_cmp("eq_u32", S_LOOP, 0)
+        p.s_cbranch_scc1("L_PRE")
+        p.label("L_MID")
+        self.body("mid", 0)
+        self.body("mid", 1)
+        p.s_sub_u32(S_LOOP, S_LOOP, 1)
+        p.s_cmp("lg_u32", S_LOOP, 0)
+        p.s_cbranch_scc1("L_MID")
+        p.label("L_PRE")
+        self.body("prelast", 0)
+        p.s_branch("L_LAST")
+        p.label("L_DRAIN")
+        # the last step's epilogue (accumulator set 1), nothing to hide it under; the fragments prefetched for a non-existent next step drain
+        p.s_waitcnt(vmcnt=0, lgkmcnt=0)
+        self.vm.wait(0)
+        self.lg.wait(0)
+        for _, grp in self.epi_stream(1, masked=False, earliest=0):
+            for th in grp:
+                th()
+        # trailing dummy steps: (3 - w) * NS/4, so that every wave of the workgroup passes the same number of barriers
+        p.s_lshr_b32(S_T[0], S_N, 8)
+        p.s_sub_u32(S_T[1], 3, S_WID)
+        p.s_mul_i32(S_DUM, S_T[0], S_T[1])
+        p.label("L_DUMB")
+        p.s_cmp("eq_u32", S_DUM, 0)
+        p.s_cbranch_scc1("L_EXIT")
+        self.dummy_body()
+        p.s_sub_u32(S_DUM, S_DUM, 1)
+        p.s_branch("L_DUMB")
+        p.label("L_EXIT")
+        p.s_waitcnt(vmcnt=0, lgkmcnt=0)
+        if "time" in self.dbg:
+            p.s_mov_b32(SRD_T.sub(0), S_BITS.sub(0))
+            p.s_and_b32(SRD_T.sub(1), S_BITS.sub(1), 0xffff)
+            p.s_mov_b32(SRD_T.sub(2), 0xffffffff)
+            p.s_lshl_b32(S_T[0], s(2), 2)
+            p.s_add_u32(S_T[0], S_T[0], S_WID)
+            p.s_lshl_b32(S_T[0], S_T[0], 5)
+            p.v_mov_b32(V_TMP[0], 0)
+            p.s_mov_b64(EXEC, 1)
+            for i in range(6):
+                p.v_mov_b32(V_TMP[1], s(29 + i))
+                p.buffer_store(V_TMP[1], V_TMP[0], SRD_T, S_T[0], 4 * i)
+            p.s_waitcnt(vmcnt=0)
+        p.s_endpgm()
+        return self
+
+    # ------------------------------------------------------------------ assembly text
+    def asm_text(self):
+        body = self.p.text()
+        name = self.name
+        return f"""// GENERATED by safevla_amd/asmgen/nt_as_gen.py -- do not edit.
+\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
+\t.text
+\t.protected {name}
+\t.globl {name}
+\t.p2align 8
+\t.type {name},@function
+{name}:
+{body}
+.L{name}_end:
+\t.size {name}, .L{name}_end-{name}
+
+\t.rodata
+\t.p2align 6
+\t.amdhsa_kernel {name}
+\t\t.amdhsa_group_segment_fixed_size {LDS_BYTES}
+\t\t.amdhsa_private_segment_fixed_size 0
+\t\t.amdhsa_kernarg_size {KARG_BYTES}
+\t\t.amdhsa_user_sgpr_count 2
+\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1
+\t\t.amdhsa_system_sgpr_workgroup_id_x 1
+\t\t.amdhsa_system_sgpr_workgroup_id_y 0
+\t\t.amdhsa_system_sgpr_workgroup_id_z 0
+\t\t.amdhsa_system_vgpr_workitem_id 0
+\t\t.amdhsa_next_free_vgpr 512
+\t\t.amdhsa_next_free_sgpr {N_SGPR}
+\t\t.amdhsa_accum_offset 256
+\t\t.amdhsa_reserve_vcc 1
+\t\t.amdhsa_float_round_mode_32 0
+\t\t.amdhsa_float_round_mode_16_64 0
+\t\t.amdhsa_float_denorm_mode_32 3
+\t\t.amdhsa_float_denorm_mode_16_64 3
+\t\t.amdhsa_dx10_clamp 1
+\t\t.amdhsa_ieee_mode 1
+\t.end_amdhsa_kernel
+
+\t.amdgpu_metadata
+---
+amdhsa.version: [ 1, 2 ]
+amdhsa.target: amdgcn-amd-amdhsa--gfx950
+amdhsa.kernels:
+  - .name: {name}
+    .symbol: {name}.kd
+    .kernarg_segment_size: {KARG_BYTES}
+    .group_segment_fixed_size: {LDS_BYTES}
+    .private_segment_fixed_size: 0
+    .kernarg_segment_align: 8
+    .wavefront_size: 64
+    .sgpr_count: {N_SGPR + 6}
+    .vgpr_count: 512
+    .agpr_count: 256
+    .max_flat_workgroup_size: 256
+    .args:
+      - {{ .size: {KARG_BYTES}, .offset: 0, .value_kind: by_value }}
+...
+\t.end_amdgpu_metadata
+"""
+
+
+# flavour -> generator options (the C dispatcher nt_as_try of csrc/gemm.hip picks by name)
+FLAVOURS = {
+    "f0": dict(),                                               # bias (or none): in_proj forward, out_proj input gradient
+    "f1d": dict(relu=True, bits_out=True, drop=True),           # bias, ReLU, dropout, sign bits out: linear1 forward in train mode
+    "f1": dict(relu=True, bits_out=True),                       # ... eval mode / visual compressor
+    "f3": dict(bits_in=True),                                   # alpha * product under the ReLU sign bits: input gradient through linear2 (+ dropout scale)
+}
+if _os.environ.get("SVLA_ASM_DEBUG_VARIANTS"):      # timing-only builds (tools/time_nt_as.py)
+    for _d in ("time", "time,nox", "time,nostore", "time,nodma", "time,noepi,nodma,nox"):
+        FLAVOURS["f0_" + _d.replace(",", "_")] = dict(dbg=_d)
+    for _k, _o in (("w16", dict(wa_end=16, wb_end=76)), ("w40", dict(wa_end=40, wb_end=104))):
+        FLAVOURS["f0_" + _k] = _o
+
+
+def generate(flavour="f0"):
+    g = NtAsGen(name=f"svla_nt_as2_{flavour}", **FLAVOURS[flavour])
+    g.build()
+    return g

@@ -5,6 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from safevla_amd import ops
+from safevla_amd._lib import lib
 M = int(os.environ.get("AB_ROWS", 16384)) * 181
 variants = (sys.argv[1] if len(sys.argv) > 1 else "time,time_nostore,time_nodma,time_noepi,time_nox,time_nobarwait,time_noepi_nodma_nox").split(",")
 dbg = torch.zeros(256 * 4 * 8, device="cuda", dtype=torch.int32)
@@ -13,7 +14,8 @@ for n in (512, 2048):
     A = torch.randn(M, 512, device="cuda").to(torch.bfloat16); B = (torch.randn(n, 512, device="cuda") * 0.05).to(torch.bfloat16)
     bias = torch.randn(n, device="cuda"); out = torch.empty(M, n, device="cuda", dtype=torch.bfloat16)
     for var in variants:
-        os.environ["SVLA_NT_AS_VARIANT"] = var
+        os.environ["SVLA_NT_AS_VARIANT"] = var.replace("v1:", "")
+        lib().call("svla_gemm_force_small_tile", 10 + (16384 if var.startswith("v1:") else 0))
         ts = []
         for rep in range(3):
             dbg.zero_()
