@@ -132,7 +132,7 @@ class NtAsGen:
     DMA_END = 72       # the last LDS-DMA piece of the next tile is issued by this gap (~1.5 k cycles before the barrier)
     BAR_GAP = 119      # the barrier follows MFMA 119 (k-step 29); the last fragment reads of the tile are issued at gaps 113 / 115
 
-    def __init__(self, name="svla_nt_as_f0", relu=False, drop=False, bits_out=False, bits_in=False, cap=None, dbg="", stagger=0, epi_order=1, dma_end=None, store_nt=True, load_nt=False):
+    def __init__(self, name="svla_nt_as_f0", relu=False, drop=False, bits_out=False, bits_in=False, cap=None, dbg="", stagger=0, epi_order=1, dma_end=None, store_nt=True, load_nt=False, xstart=0):
         self.name = name
         # epilogue flavour: relu (+ bits_out: the output's sign bits, + drop: train-mode dropout after the activation) | bits_in: alpha * product,
         # zeroed where the ReLU sign bit of the forward activation is 0 (no bias) | none of them: + bias
@@ -142,7 +142,7 @@ class NtAsGen:
         self.dbg = set(dbg.split(",")) if dbg else set()      # timing-only / bisection builds (tools/): time, nostore, nodma, nox, noepi, ...
         if cap is not None:
             self.CAP = cap
-        self.stagger, self.epi_order, self.store_nt, self.load_nt = stagger, epi_order, store_nt, load_nt
+        self.stagger, self.epi_order, self.store_nt, self.load_nt, self.xstart = stagger, epi_order, store_nt, load_nt, xstart
         if dma_end is not None:
             self.DMA_END = dma_end
         self.p = Prog(name)
@@ -689,7 +689,7 @@ class NtAsGen:
                             return
                         p.buffer_load(XFRAG(mb, ks), V_XOFF[mb], SRD_X, S_XROW, ks * 32, nt=self.load_nt)
                         self.vm.issue(f"x{ks}")
-                    fixed[4 * ks + 3].append(xl)
+                    fixed[max(4 * ks + 3, self.xstart + (2 * ks + mb) // 2 if self.xstart else 0)].append(xl)
         if kind == "first":
             for ks in range(KS):
                 pre[4 * ks].append(("vm", f"x{ks}"))
@@ -918,7 +918,7 @@ FLAVOURS = {
 if _os.environ.get("SVLA_ASM_DEBUG_VARIANTS"):      # timing-only / bisection builds (tools/time_nt_as.py)
     for _d in ("time", "time,nostore", "time,nodma", "time,noepi", "time,nox", "time,nobarwait", "time,noepi,nodma,nox"):
         FLAVOURS["f0_" + _d.replace(",", "_")] = dict(dbg=_d)
-    for _k, _o in (("nost", dict(store_nt=False)), ("lnt", dict(load_nt=True))):
+    for _k, _o in (("x41", dict(dma_end=40, xstart=41)), ("x73", dict(xstart=73)), ("x57", dict(dma_end=56, xstart=57))):
         FLAVOURS["f0_" + _k] = _o
     for _k in ("f1d", "f1", "f3"):
         FLAVOURS[_k + "_time"] = dict(FLAVOURS[_k], dbg="time") if _k != "f1d" else FLAVOURS[_k]
