@@ -10,7 +10,7 @@ for path in dbs:
     cur = sqlite3.connect(path).cursor()
     for name, ctr, val, cnt, dur in cur.execute("select kernel_name, counter_name, avg(value), count(*), avg(duration) from counters_collection "
                                                  "group by kernel_name, counter_name"):
-        if not any(k in name for k in ("gemm", "attn", "norm")):
+        if not any(k in name for k in ("gemm", "attn", "norm", "svla_")):
             continue
         k = name.split("(")[0]
         d = acc.setdefault(k, {"launches": cnt, "avg_duration_us_profiled": dur / 1e3})
