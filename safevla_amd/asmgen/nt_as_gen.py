@@ -132,7 +132,7 @@ class NtAsGen:
     DMA_END = 72       # the last LDS-DMA piece of the next tile is issued by this gap (~1.5 k cycles before the barrier)
     BAR_GAP = 119      # the barrier follows MFMA 119 (k-step 29); the last fragment reads of the tile are issued at gaps 113 / 115
 
-    def __init__(self, name="svla_nt_as_f0", relu=False, drop=False, bits_out=False, bits_in=False, cap=None, dbg="", stagger=0, epi_order=1, dma_end=None, store_nt=True, load_nt=False, xstart=0):
+    def __init__(self, name="svla_nt_as_f0", relu=False, drop=False, bits_out=False, bits_in=False, cap=None, dbg="", stagger=0, epi_order=1, dma_end=None, store_nt=True, load_nt=False, xstart=0, wphases=4, xburst=2):
         self.name = name
         # epilogue flavour: relu (+ bits_out: the output's sign bits, + drop: train-mode dropout after the activation) | bits_in: alpha * product,
         # zeroed where the ReLU sign bit of the forward activation is 0 (no bias) | none of them: + bias
@@ -143,6 +143,12 @@ class NtAsGen:
         if cap is not None:
             self.CAP = cap
         self.stagger, self.epi_order, self.store_nt, self.load_nt, self.xstart = stagger, epi_order, store_nt, load_nt, xstart
+        # panel switch: the 4 fragment loads (k-steps 4j .. 4j+3 of one row block) that share a 128-byte line of A are issued back to back (2; 1: row blocks
+        # interleaved, 3: two lines per burst, 4: row blocks half a period apart, 0: each load as soon as its register is free).  Measured (profiles/
+        # r04_nt_as_step_timing.txt): 2 = 4 > 3 > 0 > 1 -- a fragment-shaped load touches 32 bytes of 32 lines, and the L1 does not keep a line for the 600 cycles
+        # until the next k-step's load comes for its next 32 bytes
+        self.xburst = xburst
+        self.wphases = wphases      # 4: every wave of a workgroup switches panels in its own step; 2: in pairs; 1: all in the same step
         if dma_end is not None:
             self.DMA_END = dma_end
         self.p = Prog(name)
@@ -292,8 +298,13 @@ class NtAsGen:
         if self.bias:
             self.bias_table()
         # ---- phase of this wave: phi = w * NS/4 + (workgroup & cmask) dummy steps before its first panel, (3 - w) * NS/4 after its last
-        p.s_lshr_b32(S_T[0], S_N, 8)                # NS / 4
-        p.s_mul_i32(S_DUM, S_WID, S_T[0])
+        sh = {4: 0, 2: 1, 1: 2}[self.wphases]
+        p.s_lshr_b32(S_T[0], S_N, 8 - sh)           # NS / wphases
+        p.s_lshr_b32(S_T[1], S_WID, sh)             # phase index of this wave
+        p.s_mul_i32(S_DUM, S_T[1], S_T[0])
+        if sh:
+            p.s_lshl_b32(S_CMASK, S_CMASK, sh)      # the workgroups spread over NS / wphases steps
+            p.s_or_b32(S_CMASK, S_CMASK, (1 << sh) - 1)
         p.s_and_b32(S_T[1], s(2), S_CMASK)
         p.s_add_u32(S_DUM, S_DUM, S_T[1])
         # ---- first panel
@@ -689,7 +700,33 @@ class NtAsGen:
                             return
                         p.buffer_load(XFRAG(mb, ks), V_XOFF[mb], SRD_X, S_XROW, ks * 32, nt=self.load_nt)
                         self.vm.issue(f"x{ks}")
+                    if self.xburst:
+                        continue
                     fixed[max(4 * ks + 3, self.xstart + (2 * ks + mb) // 2 if self.xstart else 0)].append(xl)
+            if self.xburst:
+                def xl2(ks, mb):
+                    def f():
+                        if "nox" in self.dbg:
+                            return
+                        p.buffer_load(XFRAG(mb, ks), V_XOFF[mb], SRD_X, S_XROW, ks * 32, nt=self.load_nt)
+                        self.vm.issue(f"x{ks}")
+                    return f
+                if self.xburst == 3:          # two lines (8 k-steps) per burst
+                    for j in range(KS // 8):
+                        for mb in range(2):
+                            for ks in range(8 * j, 8 * j + 8):
+                                fixed[32 * j + 31].append(xl2(ks, mb))
+                elif self.xburst == 4:        # the two row blocks half a line period apart
+                    for j in range(KS // 4):
+                        for mb in range(2):
+                            for ks in range(4 * j, 4 * j + 4):
+                                fixed[min(16 * j + 15 + 8 * mb, 4 * KS - 1)].append(xl2(ks, mb))
+                else:
+                    for j in range(KS // 4):
+                        order = [(ks, mb) for ks in range(4 * j, 4 * j + 4) for mb in range(2)] if self.xburst == 1 else \
+                                [(ks, mb) for mb in range(2) for ks in range(4 * j, 4 * j + 4)]
+                        for ks, mb in order:
+                            fixed[16 * j + 15].append(xl2(ks, mb))
         if kind == "first":
             for ks in range(KS):
                 pre[4 * ks].append(("vm", f"x{ks}"))
@@ -816,8 +853,10 @@ class NtAsGen:
             for th in grp:
                 th()
         # trailing dummy steps: (3 - w) * NS/4, so that every wave of the workgroup passes the same number of barriers
-        p.s_lshr_b32(S_T[0], S_N, 8)
-        p.s_sub_u32(S_T[1], 3, S_WID)
+        sh = {4: 0, 2: 1, 1: 2}[self.wphases]
+        p.s_lshr_b32(S_T[0], S_N, 8 - sh)
+        p.s_lshr_b32(S_T[1], S_WID, sh)
+        p.s_sub_u32(S_T[1], self.wphases - 1, S_T[1])
         p.s_mul_i32(S_DUM, S_T[0], S_T[1])
         p.label("L_DUMB")
         p.s_cmp("eq_u32", S_DUM, 0)
@@ -918,7 +957,7 @@ FLAVOURS = {
 if _os.environ.get("SVLA_ASM_DEBUG_VARIANTS"):      # timing-only / bisection builds (tools/time_nt_as.py)
     for _d in ("time", "time,nostore", "time,nodma", "time,noepi", "time,nox", "time,nobarwait", "time,noepi,nodma,nox"):
         FLAVOURS["f0_" + _d.replace(",", "_")] = dict(dbg=_d)
-    for _k, _o in (("x41", dict(dma_end=40, xstart=41)), ("x73", dict(xstart=73)), ("x57", dict(dma_end=56, xstart=57))):
+    for _k, _o in (("xb0", dict(xburst=0)), ("xb3", dict(xburst=3)), ("wp1", dict(wphases=1)), ("wp2", dict(wphases=2))):
         FLAVOURS["f0_" + _k] = _o
     for _k in ("f1d", "f1", "f3"):
         FLAVOURS[_k + "_time"] = dict(FLAVOURS[_k], dbg="time") if _k != "f1d" else FLAVOURS[_k]

@@ -877,6 +877,9 @@ __device__ __forceinline__ AttDrop att_drop_head(const AttnArgs& p, int r, int h
 template <int NKT, bool DROP>
 __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_fused_exact_kernel(AttnArgs p) {
     if (DROP) p.drop = drop_resolve(p.drop);
+#ifdef ATT_TIMING
+    const long long tm0 = __builtin_readcyclecounter();
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16, MAXT = (NKT + 3) / 4, IT = SP * 8 / ATT_THREADS;
     constexpr bool EARLY_TR = ATT_EARLY_TR && NKT <= 12;
@@ -931,6 +934,9 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_fused
     for (int i = tid; i < SP; i += ATT_THREADS)
         nl_s[i] = i < Sq ? -p.LSE[((size_t)r * p.H + h) * Sq + i] * LOG2E : -INFINITY;
     __syncthreads();
+#ifdef ATT_TIMING
+    const long long tm1 = __builtin_readcyclecounter();
+#endif
     const float sl2 = p.scale * LOG2E;
     const float dsc = DROP ? p.drop.scale : 1.f, scd = p.scale * dsc;
     const f32x4 sl4 = {sl2, sl2, sl2, sl2}, scd4 = {scd, scd, scd, scd}, dsc4 = {dsc, dsc, dsc, dsc};
@@ -1039,6 +1045,9 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_fused
     }
     // ---- this wave's query tiles: Q / dO row fragments, -lse and -D*scale move to registers before K, V replace Q, dO in LDS
     __builtin_amdgcn_sched_barrier(0);
+#ifdef ATT_TIMING
+    const long long tm2 = __builtin_readcyclecounter();
+#endif
     bf16x8 qall[MAXT][4];
     float dall[MAXT], lall[MAXT];
 #pragma unroll
@@ -1070,6 +1079,9 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_fused
         stage_head<SP>(Bs, p.V + tok0 * p.ld + h * HD, p.ld, S, tid);
     }
     __syncthreads();
+#ifdef ATT_TIMING
+    const long long tm3 = __builtin_readcyclecounter();
+#endif
     // ---- dQ: waves own query tiles; As = K, Bs = V
     {
         const int ntile = (Sq + 15) / 16;
@@ -1136,6 +1148,14 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_fused
             }
         }
     }
+#ifdef ATT_TIMING
+    if (p.kvalid && lane == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        const long long tm4 = __builtin_readcyclecounter();
+        unsigned* d = (unsigned*)p.kvalid + ((size_t)blockIdx.x * 4 + wid) * 4;
+        d[0] = (unsigned)(tm1 - tm0); d[1] = (unsigned)(tm2 - tm1); d[2] = (unsigned)(tm3 - tm2); d[3] = (unsigned)(tm4 - tm3);
+    }
+#endif
 }
 
 template <int NKT>
@@ -1210,6 +1230,10 @@ static int launch_bwd(const AttnArgs& p, int rows, hipStream_t st) {
             hipLaunchKernelGGL((attn_bwd_dq_exact_kernel<NKT>), dim3(rows * p.H), dim3(ATT_THREADS), le_q, st, p);
             hipLaunchKernelGGL((attn_bwd_dkv_exact_kernel<NKT>), dim3(rows * p.H), dim3(ATT_THREADS), le_kv, st, p);
         } else {
+#ifdef ATT_TIMING
+            AttnArgs pt = p; if (getenv("SVLA_ATTN_DBGBUF")) pt.kvalid = (const unsigned char*)strtoull(getenv("SVLA_ATTN_DBGBUF"), nullptr, 16);
+            if (p.drop.thr) { hipLaunchKernelGGL((attn_bwd_fused_exact_kernel<NKT, true>), dim3(rows * p.H), dim3(ATT_THREADS), le_kv, st, pt); return svla_launch_status(); }
+#endif
             if (p.drop.thr) hipLaunchKernelGGL((attn_bwd_fused_exact_kernel<NKT, true>), dim3(rows * p.H), dim3(ATT_THREADS), le_kv, st, p);
             else hipLaunchKernelGGL((attn_bwd_fused_exact_kernel<NKT, false>), dim3(rows * p.H), dim3(ATT_THREADS), le_kv, st, p);
         }
