@@ -102,6 +102,9 @@ class Wave:
         self.done = False
         self.at_barrier = False
         self.counts = {}
+        self.nstep = 0       # instructions (wait states) executed
+        self.dotw = {}       # VGPR index -> nstep of the DOT instruction that wrote it (its result is not forwarded to other VALU operations)
+        self.in_dot = False
         # random garbage in the register files: uninitialised reads must not pass by luck
         rs = np.random.RandomState(1234 + wid)
         self.V[:] = rs.randint(0, 2**32, size=self.V.shape, dtype=np.uint64).astype(np.uint32)
@@ -121,6 +124,12 @@ class Wave:
         if isinstance(x, Reg):
             if x.kind == "v":
                 self._chk(x.sub(i), "read")
+                # gfx940-family hazard the hardware does not interlock (found on an MI355X, LLVM: DotWriteDifferentVALURead = 3 wait states):
+                # the result of a DOT instruction read by anything but another DOT less than 4 instructions later is the OLD value
+                t = self.dotw.get(x.idx + i)
+                if t is not None and not self.in_dot and self.nstep - t < 4:
+                    raise EmuError(f"wave {self.wid} pc {self.pc}: v{x.idx + i} written by a DOT instruction {self.nstep - t} instruction(s) ago is read by "
+                                   f"a non-DOT instruction (3 wait states required): {self.emu.prog.ops[self.pc].text}")
                 return self.V[x.idx + i].copy()
             if x.kind == "a":
                 self._chk(x.sub(i), "read")
@@ -380,7 +389,9 @@ class Prog:
         self._add("s_barrier", fn, "barrier")
 
     def s_nop(self, n=0):
-        self._salu(f"s_nop {n}", lambda w: None)
+        def fn(w):
+            w.nstep += n          # n + 1 wait states
+        self._salu(f"s_nop {n}", fn)
 
     def s_setprio(self, n):
         self._salu(f"s_setprio {n}", lambda w: None)
@@ -603,11 +614,14 @@ class Prog:
     def v_dot2c_f32_bf16(self, d, x, y):
         """d += x.bf16[0] * y.bf16[0] + x.bf16[1] * y.bf16[1] (fp32)"""
         def fn(w):
+            w.in_dot = True
             p, q = w.rd(x), w.rd(y)
             acc = w.rd(d).view(np.float32).astype(np.float64)
+            w.in_dot = False
             for sh in (0, 16):
                 acc = acc + bf16_to_f32(((p >> sh) & 0xffff).astype(np.uint16)).astype(np.float64) * bf16_to_f32(((q >> sh) & 0xffff).astype(np.uint16)).astype(np.float64)
             w.wr(d, acc.astype(np.float32).view(np.uint32))
+            w.dotw[d.idx] = w.nstep
         self._valu(f"v_dot2c_f32_bf16 {_txt(d)}, {_txt(x)}, {_txt(y)}", fn)
 
     def v_cmp_u32(self, op, d, x, y):
@@ -803,7 +817,7 @@ class Prog:
             w.retire(w.vmq, 63)          # 6-bit counter: the hardware stalls the issue until an older operation has returned
         self._add(f"buffer_load_dwordx4 {_txt(vaddr)}, {_txt(srd)}, {_txt(soff)} offen lds", fn, "vmem")
 
-    def global_load_lds_x4(self, voff, sbase):
+    def global_load_lds_x4(self, voff, sbase, mods=""):
         """global_load_lds_dwordx4 voff, s[base:base+1]: lane i fetches 16 bytes at sbase + voff[i] and they land at LDS[M0 + 16 i] when this
         wave retires the operation (the form the HIP kernels of csrc/gemm.hip use through __builtin_amdgcn_global_load_lds)."""
         def fn(w):
@@ -827,7 +841,7 @@ class Prog:
                     lds[dst0 + 16 * l: dst0 + 16 * l + 16] = data[l]
             w.vmq.append(land)
             w.retire(w.vmq, 63)
-        self._add(f"global_load_lds_dwordx4 {_txt(voff)}, {_txt(sbase)}", fn, "vmem")
+        self._add(f"global_load_lds_dwordx4 {_txt(voff)}, {_txt(sbase)}" + (f" {mods}" if mods else ""), fn, "vmem")
 
     def buffer_atomic_add_f32(self, src, vaddr, srd, soff, off=0):
         """no-return fp32 atomic add of src (one dword per lane)"""
@@ -931,6 +945,7 @@ class Emu:
                 while not w.done and not w.at_barrier:
                     op = ops[w.pc]
                     if op.fn is not None:
+                        w.nstep += 1
                         op.fn(w)
                         w.counts[op.kind] = w.counts.get(op.kind, 0) + 1
                     w.pc += 1

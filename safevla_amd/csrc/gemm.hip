@@ -1044,6 +1044,57 @@ static int nt_as_try(const GemmNtArgs& p, hipStream_t stream) {
     return SVLA_OK;
 }
 
+// ---- output-stationary assembly kernels (asmgen/nt_os_gen.py): K > 512 (or K = 512 with a residual), bias / residual epilogues without dropout, N % 256 == 0,
+// K % 128 == 0, full 256-row tiles; the M % 256 tail rows run on the 128-tile kernel.  g_dbg & 16384 = off (A/B: tools/ab_nt_os.py).
+struct NtOsKarg {      // = asmgen/nt_os_gen.py KARG
+    const void* A; long lda; const void* B; long ldb; const float* bias; const void* res; long ldr; void* C; long ldc;
+    int M, N, K, ntn, ntiles, grid;
+};
+static_assert(sizeof(NtOsKarg) == 96, "kernarg layout of the nt_os kernels");
+static int nt_os_try(const GemmNtArgs& p, hipStream_t stream) {
+    if (p.out_f32 || (p.N % 256) || p.N > 4096 || (p.K % 128) || p.K < 384 || (p.dbg & (8192 | 16384)) || g_force_small_tile == 1) return NT_AS_NOT_TAKEN;
+    if (p.relu_mask || p.bits_in || p.bits_out || p.drop.thr || p.act != ACT_NONE || p.alpha != 1.f) return NT_AS_NOT_TAKEN;
+    const int mtiles = p.M / 256, ntn = p.N / 256;
+    if ((long)mtiles * ntn < 1024 && g_force_small_tile != 2) return NT_AS_NOT_TAKEN;      // fewer than four tiles per CU: the two-workgroup-per-CU tile kernel balances better
+    if (mtiles < 1) return NT_AS_NOT_TAKEN;
+    const char* name = p.bias ? (p.residual ? "svla_nt_os_br" : "svla_nt_os_b") : (p.residual ? "svla_nt_os_r" : "svla_nt_os_p");
+    static char dbg_name[96];
+    if (getenv("SVLA_NT_OS_VARIANT")) {      // timing-only builds of tools/var_nt_os.py: svla_nt_os_r_<variant>
+        snprintf(dbg_name, sizeof(dbg_name), "%s_%s", name, getenv("SVLA_NT_OS_VARIANT"));
+        name = dbg_name;
+    }
+    if (!svla_asm_has(name)) return NT_AS_NOT_TAKEN;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        HIP_CHECK_RET(hipGetDevice(&dev));
+        HIP_CHECK_RET(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    NtOsKarg k;
+    memset(&k, 0, sizeof(k));
+    k.A = p.A; k.lda = p.lda; k.B = p.B; k.ldb = p.ldb; k.bias = p.bias; k.res = p.residual; k.ldr = p.ldr; k.C = p.C; k.ldc = p.ldc;
+    k.M = mtiles * 256; k.N = p.N; k.K = p.K; k.ntn = ntn; k.ntiles = mtiles * ntn; k.grid = k.ntiles < n_cu ? k.ntiles : n_cu;
+    gemm_log(name, k.M, p.N, p.K);
+    const int rc = svla_asm_launch(name, &k, sizeof(k), k.grid, 256, stream);
+    if (rc) return rc;
+    const int tail = p.M - mtiles * 256;
+    if (tail > 0) {
+        GemmNtArgs q = p;
+        const size_t r0 = (size_t)mtiles * 256;
+        q.A = p.A + r0 * p.lda;
+        q.C = (void*)((bf16_t*)p.C + r0 * p.ldc);
+        if (p.residual) q.residual = p.residual + r0 * p.ldr;
+        q.M = tail;
+        q.row0 = (int)r0;
+        const int mt = (tail + BM - 1) / BM, nt = p.N / BN;
+        const size_t lds = BM * (BN + 4) * sizeof(float);
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(mt * nt), dim3(NTHREADS), lds, stream, q);
+        return svla_launch_status();
+    }
+    return SVLA_OK;
+}
+
 extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, long ldb, const float* bias,
                                  const bf16_t* residual, long ldr, const bf16_t* relu_mask, long ldm, void* C, long ldc,
                                  int M, int N, int K, int act, int out_f32, float alpha, unsigned char* relu_bits_out,
@@ -1055,6 +1106,10 @@ extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, lon
     GemmNtArgs p{A, lda, B, ldb, bias, residual, ldr, relu_mask, ldm, C, ldc, M, N, K, act, out_f32, alpha, relu_bits_out, relu_bits, drop_cfg(drop), 0, g_dbg};
     {
         const int rc = nt_as_try(p, (hipStream_t)stream);      // K = 512 row-streaming GEMMs: the A-stationary assembly kernels
+        if (rc != NT_AS_NOT_TAKEN) return rc;
+    }
+    {
+        const int rc = nt_os_try(p, (hipStream_t)stream);      // K > 512 without dropout: the output-stationary assembly kernels
         if (rc != NT_AS_NOT_TAKEN) return rc;
     }
     // N % 256 == 128 with N >= 384 (the ViT-S widths 384 and 1152): the last n-tile is a half tile (75 % / 90 % of the MFMA work useful) --

@@ -157,3 +157,45 @@ def test_tn_os_two_k_tiles_share_the_bias_turns():
     dW, rW, db, rb = run_tn(160, 256, 512, 160, 2)
     assert np.abs(dW - rW).max() < 2e-3 * np.abs(rW).max()
     assert np.abs(db - rb).max() < 2e-3 * max(1.0, np.abs(rb).max())
+
+
+def run_nt_os(flavour, M, N, Kc, grid, order=None, seed=0):
+    from safevla_amd.asmgen import nt_os_gen as O
+    g = O.generate(flavour)
+    rs = np.random.RandomState(seed)
+    X = _bf16(rs.standard_normal((M, Kc)))
+    W = _bf16(rs.standard_normal((N, Kc)) * 0.05)
+    bias = rs.standard_normal(N).astype(np.float32)
+    R = _bf16(rs.standard_normal((M, N)))
+    C = np.full((M, N), 0x7fc0, dtype=np.uint16)
+    ntn, ntiles = N // 256, (M // 256) * (N // 256)
+    grid = min(grid, ntiles)
+    for wg in range(grid):
+        emu = Emu(g.p)
+        aX, aW, aB, aR, aC = emu.alloc(X), emu.alloc(W), emu.alloc(bias), emu.alloc(R), emu.alloc(C, writable=True)
+        ka = bytearray(O.KARG_BYTES)
+
+        def put(name, fmt, val):
+            struct.pack_into(fmt, ka, O.KARG[name], val)
+        put("A", "<Q", aX); put("lda", "<q", Kc); put("B", "<Q", aW); put("ldb", "<q", Kc); put("bias", "<Q", aB); put("res", "<Q", aR); put("ldr", "<q", N)
+        put("C", "<Q", aC); put("ldc", "<q", N); put("M", "<i", M); put("N", "<i", N); put("K", "<i", Kc); put("ntn", "<i", ntn)
+        put("ntiles", "<i", ntiles); put("grid", "<i", grid)
+        emu.run(ka, wg, order=order)
+    ref = (bf16_to_f32(X).astype(np.float64) @ bf16_to_f32(W).astype(np.float64).T).astype(np.float32)
+    if g.bias:
+        ref = ref + bias
+    if g.res:
+        ref = ref + bf16_to_f32(R)
+    return bf16_to_f32(C), ref
+
+
+@pytest.mark.parametrize("flavour,M,N,Kc,grid,order", [
+    ("p", 256, 256, 384, 1, None),               # one tile, one pass of the pair loop
+    ("br", 512, 512, 384, 2, [3, 2, 1, 0]),      # two tiles per workgroup (deferred stores under the next tile's K-tiles), other wave order
+    ("r", 768, 256, 640, 3, None),               # three workgroups, two passes of the pair loop, residual prefetch behind the draining slabs
+    ("b", 256, 512, 512, 2, None),
+])
+def test_nt_os_output_stationary_kernel(flavour, M, N, Kc, grid, order):
+    """svla_nt_os_* (asmgen/nt_os_gen.py): ring of released-one-by-one units, counted waits, exposed pack + deferred stores, DOT-result hazard"""
+    out, ref = run_nt_os(flavour, M, N, Kc, grid, order=order)
+    check(out, ref)

@@ -744,6 +744,47 @@ def test_gemm_nt_assembly_kernels(ops, N, flavour):
         assert torch.equal(chk, b1), "sign bits are not (output > 0)"
 
 
+@pytest.mark.parametrize("N,K", [(512, 2048), (512, 1536), (1024, 384), (512, 512)])
+@pytest.mark.parametrize("flavour", ["plain", "bias", "res", "bias_res"])
+def test_gemm_nt_output_stationary_assembly_kernels(ops, N, K, flavour):
+    """The output-stationary assembly kernels (svla_nt_os_*, asmgen/nt_os_gen.py; K >= 384, no dropout) behind svla_gemm_nt_bf16 -- the input-gradient GEMMs
+    through linear1 / in_proj of the fusion encoder (allenact_dino_transformer.py:545-552): against fp32 torch, against the 8-phase HIP kernel
+    they replace (flag 8192 = assembly off; bit for bit without a residual), identical from run to run, ragged M (tail rows on the 128-tile kernel)."""
+    if K == 512 and "res" not in flavour:
+        pytest.skip("K = 512 without a residual runs on the A-stationary kernels")
+    M = 256 * (520 if N == 512 else 260) + 77
+    A = bf(rnd(M, K, seed=51)).to(DEV).bfloat16(); B = bf(rnd(N, K, seed=52, scale=0.05)).to(DEV).bfloat16()
+    kw = {}
+    want = A.float() @ B.float().t()
+    if "bias" in flavour:
+        kw["bias"] = rnd(N, seed=53, scale=0.5).to(DEV)
+        want = want + kw["bias"]
+    if "res" in flavour:
+        kw["residual"] = bf(rnd(M, N, seed=54)).to(DEV).bfloat16()
+        want = want + kw["residual"].float()
+    outs = {}
+    try:
+        for off in (True, False, False):
+            _asm_off(ops, off)
+            y = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+            ops.gemm_nt(A, B, M, N, K, out=y, **kw)
+            torch.cuda.synchronize()
+            outs.setdefault(off, []).append(y)
+    finally:
+        _asm_off(ops, False)
+    hip, a1, a2 = outs[True][0], outs[False][0], outs[False][1]
+    assert torch.equal(a1.view(torch.int16), a2.view(torch.int16)), "assembly kernel differs from run to run"
+    close(a1.float(), want, 1e-2, 2e-2, f"asm {flavour} vs fp32 torch")
+    if "res" in flavour:
+        # the residual is added by v_dot2c_f32_bf16 (one instruction per element instead of unpack + add): the DOT unit's fp32 sum is not always the
+        # correctly rounded one, so ~1e-5 of the elements land on the other side of a bf16 rounding boundary (measured: 99.9996 % identical)
+        d = (a1.float() - hip.float()).abs()
+        assert (d <= hip.float().abs() * 2.0 ** -7 + 1e-6).all(), f"asm vs HIP kernel: max {d.max().item()}"
+        assert (a1.view(torch.int16) != hip.view(torch.int16)).float().mean().item() < 1e-4
+    else:
+        assert torch.equal(a1.view(torch.int16), hip.view(torch.int16)), f"asm vs HIP kernel: max {(a1.float() - hip.float()).abs().max().item()}"
+
+
 @pytest.mark.parametrize("N,K", [(512, 512), (1536, 512), (512, 2048)])
 def test_gemm_tn_assembly_kernel(ops, N, K):
     """The output-stationary assembly weight-gradient kernel (svla_tn_os, asmgen/tn_os_gen.py) behind svla_gemm_tn_f32acc: accumulation into a
