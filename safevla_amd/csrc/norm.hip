@@ -9,6 +9,7 @@
 // adapter LayerNorm write straight into (and its backward read straight out of) the token slice of the
 // fusion-transformer input [R, S, D] without a concat/split copy.
 #include "common.h"
+#include <cstdlib>
 #ifndef NORM_NT
 #define NORM_NT 1
 #endif
@@ -95,7 +96,10 @@ __global__ void norm_fwd_kernel(const T* __restrict__ x, RowMap xmap, const floa
         }
         store_row<VPL>(y + map_row(ymap, m) * D + lane * VPL, v);
     };
-    constexpr int RPT = 2;
+#ifndef NORM_RPT
+#define NORM_RPT 2
+#endif
+    constexpr int RPT = NORM_RPT;
     for (int m = RPT * wave; m < rows; m += RPT * nw) {
         float v[RPT][VPL];
 #pragma unroll
@@ -198,7 +202,9 @@ __global__ void norm_bwd_kernel(const T* __restrict__ dy, RowMap dymap, const T*
 
 static inline int norm_grid(int rows) {
     int blocks = (rows + 7) / 8;      // 4 waves x 2 rows per trip
-    return blocks > 2048 ? 2048 : (blocks < 1 ? 1 : blocks);
+    static int cap = 0;
+    if (!cap) { const char* e = getenv("SVLA_NORM_GRID"); cap = e ? atoi(e) : 2048; }      // (tools/norm_bw.py: grid sweep)
+    return blocks > cap ? cap : (blocks < 1 ? 1 : blocks);
 }
 
 template <typename T>
@@ -228,7 +234,7 @@ static int norm_bwd_launch(const T* dy, int dyG, int dyGS, int dyOFF, const T* x
     if (dtok && tok_group <= 0) return SVLA_EINVAL;
     RowMap dym{dyG, dyGS, dyOFF}, xm{xG, xGS, xOFF}, dxm{dxG, dxGS, dxOFF};
     int blocks = norm_grid(rows);
-    if (blocks > 1024) blocks = 1024;  // 4 workgroups per CU (<= 128 VGPRs); each ends with up to 4*D atomics
+    if (blocks > 1024 && !getenv("SVLA_NORM_GRID")) blocks = 1024;  // 4 workgroups per CU (<= 128 VGPRs); each ends with up to 4*D atomics
     hipLaunchKernelGGL((norm_bwd_kernel<T, 512>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, dym, x, xm, gamma, beta, mean,
                        rstd, rows, rms, relu, tok_group > 0 ? tok_group : 1, dres, dx, dxm, dgamma, dbeta, dtok, dx_drop, drop_cfg(drop), g_svla_det);
     return svla_launch_status();
