@@ -446,6 +446,13 @@ class Prog:
     def v_mov_b32(self, d, x):
         self._valu(f"v_mov_b32 {_txt(d)}, {_txt(x)}", lambda w: w.wr(d, w.rd(x)))
 
+    def v_swap_b32(self, x, y):
+        def fn(w):
+            a_, b_ = w.rd(x), w.rd(y)
+            w.wr(x, b_)
+            w.wr(y, a_)
+        self._valu(f"v_swap_b32 {_txt(x)}, {_txt(y)}", fn)
+
     def v_accvgpr_write_b32(self, d, x):
         self._valu(f"v_accvgpr_write_b32 {_txt(d)}, {_txt(x)}", lambda w: w.wr(d, w.rd(x)))
 

@@ -243,15 +243,23 @@ class NtAsGen:
         p.v_and_b32(T[7], 7, T[0])                  # lane & 7
         p.v_mul_lo_u32(T[8], T[6], S_LDC2)
         p.v_lshl_add_u32(V_COFF, T[7], 4, T[8])
-        # staging (wave-private 4 KiB at LDS_STG + w * 4096): [32 rows][128 B], 16-byte chunk q of row r stored at chunk q ^ (r & 7)
+        # staging (wave-private 4 KiB at LDS_STG + w * 4096): [32 rows][128 B], 16-byte chunk q of row r stored at chunk q ^ ((r >> 1) & 7), and in
+        # rows 16-31 the two 8-byte halves of a chunk are swapped: the 32 lanes of an accumulator-layout write (8 bytes each, rows 0-31, one chunk) then
+        # cover 32 different 8-byte slots of the 256 bytes the LDS serves per clock (with q ^ (r & 7), rows r, r + 8, r + 16, r + 24 met in one slot:
+        # 13-15 % of the LDS cycles were bank conflicts).  Row-major side: row R = (lane >> 3) + 8 it -> (R >> 1) & 7 = ((lane >> 4) + 4 it) & 7: the
+        # address of odd it is V_STRD ^ 64
         p.s_lshl_b32(S_T[2], S_WID, 12)
         p.s_add_u32(S_T[2], S_T[2], LDS_STG)
-        p.v_and_b32(T[8], 7, T[2])                  # c & 7
+        p.v_lshrrev_b32(T[8], 1, T[2])
+        p.v_and_b32(T[8], 7, T[8])                  # (c >> 1) & 7
         p.v_lshlrev_b32(T[9], 7, T[2])              # c * 128
         p.v_lshl_add_u32(T[9], T[8], 4, T[9])
-        p.v_lshl_add_u32(T[9], T[3], 3, T[9])       # + h * 8
+        p.v_lshrrev_b32(T[8], 4, T[2])              # c >> 4
+        p.v_xor_b32(T[8], T[8], T[3])               # half: h ^ (c >> 4)
+        p.v_lshl_add_u32(T[9], T[8], 3, T[9])
         p.v_add_u32(V_STW, S_T[2], T[9])
-        p.v_xor_b32(T[8], T[7], T[6])               # (lane & 7) ^ (lane >> 3)
+        p.v_lshrrev_b32(T[8], 4, T[0])              # lane >> 4
+        p.v_xor_b32(T[8], T[7], T[8])               # (lane & 7) ^ (lane >> 4)
         p.v_lshlrev_b32(T[9], 7, T[6])
         p.v_lshl_add_u32(T[9], T[8], 4, T[9])
         p.v_add_u32(V_STRD, S_T[2], T[9])
@@ -613,13 +621,20 @@ class NtAsGen:
             for it in range(4):
                 tg = self.tag(f"rb{mb}_{it}")
                 tags.append(tg)
-                add(lambda it=it, tg=tg, mb=mb: self.ds_read(V_RB[mb][it], V_STRD, it * 1024, tg))
+                def rb(it=it, tg=tg, mb=mb):
+                    if it & 1:
+                        p.v_xor_b32(V_F[16], 64, V_STRD)
+                    self.ds_read(V_RB[mb][it], V_F[16] if it & 1 else V_STRD, it * 1024, tg)
+                add(rb)
             return tags
 
         def stores(mb, tags):
             for it in range(4):
                 def st_(it=it, mb=mb, tags=tags):
                     self.wait_for(lg_tags=[tags[it]])
+                    if it >= 2:         # rows 16-31 come back with the halves of every chunk swapped
+                        p.v_swap_b32(V_RB[mb][it].sub(0), V_RB[mb][it].sub(2))
+                        p.v_swap_b32(V_RB[mb][it].sub(1), V_RB[mb][it].sub(3))
                     if "nostore" in self.dbg:
                         return
                     if masked:

@@ -64,7 +64,8 @@ def XF(st, ks):
 
 V_RDX = [[v(96 + par * 4 + ks) for ks in range(4)] for par in range(2)]
 V_RDW = [[v(104 + par * 4 + ks) for ks in range(4)] for par in range(2)]
-V_SX, V_SW, V_LANE, V_COFF, V_ROFF, V_STRD, V_BIASRD, V_BIASN = v(112), v(113), v(114), v(115), v(116), v(117), v(118), v(119)
+V_SX, V_SW, V_LANE, V_COFF, V_ROFF, _V_STRD0, V_BIASRD, V_BIASN = v(112), v(113), v(114), v(115), v(116), v(117), v(118), v(119)
+V_STRD = [_V_STRD0, V_LANE]                           # row-major staging addresses, it even / odd (the lane id is dead after the prologue; set last)
 V_STWA = [v(120 + gi) for gi in range(8)]              # staging addresses of the eight 8-byte pieces of a slab row (accumulator layout)
 
 
@@ -295,13 +296,22 @@ class NtOsGen:
         p.v_lshl_add_u32(V_ROFF, T[7], 4, T[5])
         p.s_lshl_b32(S_T[3], S_WID, 12)
         p.s_add_u32(S_T[3], S_T[3], LDS_STG)
-        p.v_xor_b32(T[5], T[7], T[6])
-        p.v_lshlrev_b32(T[4], 7, T[6])
-        p.v_lshl_add_u32(T[4], T[5], 4, T[4])
-        p.v_add_u32(V_STRD, S_T[3], T[4])
-        p.v_and_b32(T[4], 7, T[2])                  # c & 7
+        # staging swizzle: the 16-byte chunk q of row r sits at chunk q ^ ((r >> 1) & 7), and in rows 16-31 the two 8-byte halves of a chunk are
+        # swapped: the 32 lanes of an accumulator-layout access (8 bytes each, rows 0-31, one chunk) then cover 32 different 8-byte slots of the 256
+        # bytes the LDS serves per clock (with q ^ (r & 7) alone, rows r, r + 8, r + 16, r + 24 met in one slot: 13 % of the LDS cycles were conflicts)
+        p.v_lshrrev_b32(T[4], 4, V_LANE)            # row-major side: row R = (lane >> 3) + 8 it: (R >> 1) & 7 = ((lane >> 4) + 4 it) & 7
+        for par in range(2):
+            p.v_add_u32(T[5], 4 * par, T[4])
+            p.v_xor_b32(T[5], T[7], T[5])
+            p.v_lshlrev_b32(T[1], 7, T[6])
+            p.v_lshl_add_u32(T[1], T[5], 4, T[1])
+            p.v_add_u32(V_STRD[par], S_T[3], T[1])
+        p.v_lshrrev_b32(T[4], 1, T[2])
+        p.v_and_b32(T[4], 7, T[4])                  # (c >> 1) & 7
+        p.v_lshrrev_b32(T[1], 4, T[2])              # c >> 4
+        p.v_xor_b32(T[1], T[1], T[3])               # half: h ^ (c >> 4)
         p.v_lshlrev_b32(T[5], 7, T[2])              # c * 128
-        p.v_lshl_add_u32(T[5], T[3], 3, T[5])       # + 8 h
+        p.v_lshl_add_u32(T[5], T[1], 3, T[5])
         p.v_add_u32(T[5], S_T[3], T[5])
         for gi in range(8):
             p.v_xor_b32(T[6], gi, T[4])
@@ -405,7 +415,10 @@ class NtOsGen:
         def w():
             for it in range(4):
                 self.wait_for(vm_tags=[f"rs{slab}_{it}"])
-                self.ds_write(V_STRD, OUTQ(slab, it), it * 1024)
+                if it >= 2:         # rows 16-31 keep the halves of a chunk swapped
+                    self.p.v_swap_b32(OUTQ(slab, it).sub(0), OUTQ(slab, it).sub(2))
+                    self.p.v_swap_b32(OUTQ(slab, it).sub(1), OUTQ(slab, it).sub(3))
+                self.ds_write(V_STRD[it & 1], OUTQ(slab, it), it * 1024)
 
         def r(g0):
             def f():
@@ -428,11 +441,14 @@ class NtOsGen:
         for i0 in range(0, 4, 2):
             def r(i0=i0):
                 for it in (i0, i0 + 1):
-                    self.ds_read(OUTQ(slab, it), V_STRD, it * 1024, f"rb{slab}_{it}")
+                    self.ds_read(OUTQ(slab, it), V_STRD[it & 1], it * 1024, f"rb{slab}_{it}")
             groups.append(r)
         for it in range(4):
             def st(it=it):
                 self.wait_for(lg_tags=[f"rb{slab}_{it}"])
+                if it >= 2:
+                    p.v_swap_b32(OUTQ(slab, it).sub(0), OUTQ(slab, it).sub(2))
+                    p.v_swap_b32(OUTQ(slab, it).sub(1), OUTQ(slab, it).sub(3))
                 p.s_mul_i32(S_T[5], S_LDC2, mb * 32 + 8 * it)
                 if "nostore" not in self.dbg:
                     p.buffer_store(OUTQ(slab, it), V_COFF, SRD_P, S_T[5], j * 128, nt=True)
