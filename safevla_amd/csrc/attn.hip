@@ -260,6 +260,22 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs p) {
     }
 }
 
+// per-(row, head) constants of the incremental dropout hash (used by the persistent forward and the single-pass backward)
+struct AttDrop {               // per (row, head): hash of pair index P0 + delta, delta < 2^16
+    unsigned a0;               // lo(P0) * C1
+    unsigned hb;               // (hi(P0) * C2) ^ key
+    bool wrap;                 // lo(P0) + delta may carry into hi(P): take the generic path (never for < 2^33 probabilities per tensor)
+    unsigned long long p0;
+};
+__device__ __forceinline__ AttDrop att_drop_head(const AttnArgs& p, int r, int h) {
+    AttDrop d;
+    d.p0 = att_drop_row(p, r, h, 0) >> 1;
+    d.a0 = (unsigned)d.p0 * 0x9E3779B1u;
+    d.hb = ((unsigned)(d.p0 >> 32) * 0x85EBCA77u) ^ p.drop.key;
+    d.wrap = (unsigned)d.p0 > 0xFFFF0000u;
+    return d;
+}
+
 // ------------------------------------------------------------------------------------------------ persistent forward
 // The one-item-per-workgroup kernel above is latency-bound (stage -> barrier -> compute -> store; 1 -> 2 workgroups per CU
 // = 1.74x).  For the shape that carries > 99 % of the attention work (no mask / bias, S <= 192) a workgroup walks a list of
@@ -360,12 +376,31 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_persist_kernel(AttnAr
             lsum += __shfl_xor(lsum, 16, 64);
             lsum += __shfl_xor(lsum, 32, 64);
             if (p.drop.thr) {      // wave-uniform; dropout on the normalised probabilities (scale folded into ``inv``)
-                const unsigned long long rb = att_drop_row(p, r, h, q < Sq ? q : 0);
+                // a lane holds 4 consecutive keys (kt*16 + 4g + e) of one query = two RNG words; the pair index P0 + q*(S4/2) + key/2 is linear in (q, key):
+                // lo(P)*C1 = lane constant + wave-uniform term (the single-pass backward regenerates the same words the same way)
+                const AttDrop dh = att_drop_head(p, r, h);
+                const int S4 = (S + 3) & ~3, hS = S4 >> 1;
+                const unsigned thr = p.drop.thr;
+                if (!dh.wrap) {
+                    const unsigned al = dh.a0 + (unsigned)(ql * hS + 2 * g) * 0x9E3779B1u;
+                    const unsigned uq = (unsigned)(qt * 16 * hS) * 0x9E3779B1u;
 #pragma unroll
-                for (int kt = 0; kt < NKT; ++kt) {
-                    const unsigned keep = drop_keep4(p.drop, rb + kt * 16 + 4 * g);
+                    for (int kt = 0; kt < NKT; ++kt) {
+                        const unsigned ub = uq + (unsigned)(kt * 8) * 0x9E3779B1u;
+                        const unsigned r0 = drop_mix((al + ub) ^ dh.hb), r1 = drop_mix((al + ub + 0x9E3779B1u) ^ dh.hb);
+                        if ((r0 & 0xffffu) < thr) sc[kt][0] = 0.f;
+                        if ((r0 >> 16) < thr) sc[kt][1] = 0.f;
+                        if ((r1 & 0xffffu) < thr) sc[kt][2] = 0.f;
+                        if ((r1 >> 16) < thr) sc[kt][3] = 0.f;
+                    }
+                } else {
+                    const unsigned long long rb = att_drop_row(p, r, h, q < Sq ? q : 0);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (!((keep >> e) & 1u)) sc[kt][e] = 0.f;
+                    for (int kt = 0; kt < NKT; ++kt) {
+                        const unsigned keep = drop_keep4(p.drop, rb + kt * 16 + 4 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (!((keep >> e) & 1u)) sc[kt][e] = 0.f;
+                    }
                 }
             }
             f32x4 o[4];
@@ -858,21 +893,6 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_dkv_e
 // two packed FMAs per element pair (-lse*log2e and -D*scale are what LDS holds) and the dropout hash is evaluated incrementally:
 // the element-pair index P = P0 + q*(S4/2) + (key >> 1) is linear in (q, key), so lo(P)*C1 = lane constant + wave-uniform term.
 __device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
-
-struct AttDrop {               // per (row, head): hash of pair index P0 + delta, delta < 2^16
-    unsigned a0;               // lo(P0) * C1
-    unsigned hb;               // (hi(P0) * C2) ^ key
-    bool wrap;                 // lo(P0) + delta may carry into hi(P): take the generic path (never for < 2^33 probabilities per tensor)
-    unsigned long long p0;
-};
-__device__ __forceinline__ AttDrop att_drop_head(const AttnArgs& p, int r, int h) {
-    AttDrop d;
-    d.p0 = att_drop_row(p, r, h, 0) >> 1;
-    d.a0 = (unsigned)d.p0 * 0x9E3779B1u;
-    d.hb = ((unsigned)(d.p0 >> 32) * 0x85EBCA77u) ^ p.drop.key;
-    d.wrap = (unsigned)d.p0 > 0xFFFF0000u;
-    return d;
-}
 
 template <int NKT, bool DROP>
 __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_fused_exact_kernel(AttnArgs p) {
