@@ -96,7 +96,12 @@ int svla_gemm_nt_bf16(const svla_bf16* A, long lda, const svla_bf16* B, long ldb
                       long ldr, const svla_bf16* relu_mask, long ldm, void* C, long ldc, int M, int N, int K, int act,
                       int out_f32, float alpha, unsigned char* relu_bits_out, const unsigned char* relu_bits,
                       const svla_dropout* drop, void* stream);
-/* Test hook: force the 128x128-tile kernel even where the 256x256 one would be chosen (same cited layers). */
+/* Kernel choice behind svla_gemm_nt_bf16 (all the same arithmetic; bf16 output, fp32 accumulation, one rounding): generated gfx950 assembly for the row-streaming
+ * shapes of the update -- K = 512 without a residual: A-stationary kernels (asmgen/nt_as_gen.py: bias / ReLU + sign bits [+ dropout] / sign-bit mask);
+ * K >= 384 (K % 128 == 0, N % 256 == 0) without dropout: output-stationary kernels (asmgen/nt_os_gen.py: bias and / or residual); both from ~4 tiles per CU up,
+ * M % 256 tail rows on the 128-tile kernel -- else the 8-phase 256-tile HIP kernel (>= 160 tiles), else the 128-tile HIP kernel.
+ * Test / A-B hook: on = 1 forces the 128x128-tile kernel, 2 the 256-tile / assembly kernels wherever their shape constraints hold, 0 = normal dispatch;
+ * on = 10 + flags: 8192 = every assembly kernel off, 16384 = the output-stationary ones off (tools/ab_*.py), smaller flags = timing-only ablations of the HIP kernels. */
 int svla_gemm_force_small_tile(int on);
 /* Tool / test hook: launch kernel `name` of the embedded gfx950 assembly code object (safevla_amd/asmgen/) with a raw kernarg block --
  * probes of the assembly builder's instruction semantics on hardware (tools/asm_probe.py); the GEMM entry points above dispatch to the

@@ -1095,6 +1095,13 @@ static int nt_os_try(const GemmNtArgs& p, hipStream_t stream) {
     return SVLA_OK;
 }
 
+// fewest 256x256 tiles for which the 256-tile kernel is chosen over the 128-tile one (SVLA_NT256_MIN_TILES: sweep of tools/acting_force_probe.py)
+static int nt256_min_tiles() {
+    static int v = 0;
+    if (!v) { const char* e = getenv("SVLA_NT256_MIN_TILES"); v = e ? atoi(e) : 160; }
+    return v;
+}
+
 extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, long ldb, const float* bias,
                                  const bf16_t* residual, long ldr, const bf16_t* relu_mask, long ldm, void* C, long ldc,
                                  int M, int N, int K, int act, int out_f32, float alpha, unsigned char* relu_bits_out,
@@ -1114,7 +1121,7 @@ extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, lon
     }
     // N % 256 == 128 with N >= 384 (the ViT-S widths 384 and 1152): the last n-tile is a half tile (75 % / 90 % of the MFMA work useful) --
     // still well ahead of the 128-tile kernel
-    if (!out_f32 && ((N % 256) == 0 || ((N % 128) == 0 && N >= 384)) && (K % BK64) == 0 && K >= 2 * BK64 && ((long)((M + 255) / 256) * ((N + 255) / 256) >= 160 || g_force_small_tile == 2) && g_force_small_tile != 1) {
+    if (!out_f32 && ((N % 256) == 0 || ((N % 128) == 0 && N >= 384)) && (K % BK64) == 0 && K >= 2 * BK64 && ((long)((M + 255) / 256) * ((N + 255) / 256) >= nt256_min_tiles() || g_force_small_tile == 2) && g_force_small_tile != 1) {
         static int n_cu = 0;
         if (!n_cu) {
             int dev = 0;

@@ -234,7 +234,8 @@ static int norm_bwd_launch(const T* dy, int dyG, int dyGS, int dyOFF, const T* x
     if (dtok && tok_group <= 0) return SVLA_EINVAL;
     RowMap dym{dyG, dyGS, dyOFF}, xm{xG, xGS, xOFF}, dxm{dxG, dxGS, dxOFF};
     int blocks = norm_grid(rows);
-    if (blocks > 1024 && !getenv("SVLA_NORM_GRID")) blocks = 1024;  // 4 workgroups per CU (<= 128 VGPRs); each ends with up to 4*D atomics
+    static const bool sweep = getenv("SVLA_NORM_GRID") != nullptr;
+    if (blocks > 1024 && !sweep) blocks = 1024;  // 4 workgroups per CU (<= 128 VGPRs); each ends with up to 4*D atomics
     hipLaunchKernelGGL((norm_bwd_kernel<T, 512>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, dym, x, xm, gamma, beta, mean,
                        rstd, rows, rms, relu, tok_group > 0 ? tok_group : 1, dres, dx, dxm, dgamma, dbeta, dtok, dx_drop, drop_cfg(drop), g_svla_det);
     return svla_launch_status();
