@@ -41,6 +41,7 @@ struct AttnArgs {
     long ldq, lddq;                       // token row strides of Q and dQ (the K/V tensors use ld / ldd)
     float* Dws;                           // [rows, H, Sq] rowsum(dO * O): written by the dQ kernel, read by the dK/dV kernel (or null)
     DropCfg drop;                         // dropout on the attention probabilities (thr == 0: off)
+    int xcd_rows;                         // single-pass backward: workgroup -> (row, head) so that every XCD walks whole rows (0: row-major items)
 };
 
 // element index of probability (row r, head h, query q, key k): ((r*H + h)*S + q) * SP4 + k with the key stride SP4 = S rounded
@@ -260,6 +261,13 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs p) {
     }
 }
 
+// item -> (row, head) with every XCD walking whole rows: item i is processed on XCD i % 8 (workgroup b on XCD b % 8; the persistent forward's grid is a multiple of 8),
+// so items 8 j + x, j = 8 g .. 8 g + 7, become the eight heads of row 8 g + x: the eight 128-byte head slices of a token's line group go through ONE L2
+__device__ __forceinline__ void att_xcd_item(const AttnArgs& p, int item, int nitems, int& r, int& h) {
+    if (!p.xcd_rows) return;
+    const int x = item & 7, j = item >> 3, nfull = (nitems / 64) * 8;
+    if ((j >> 3) * 8 + x < nfull) { r = (j >> 3) * 8 + x; h = j & 7; }
+}
 // per-(row, head) constants of the incremental dropout hash (used by the persistent forward and the single-pass backward)
 struct AttDrop {               // per (row, head): hash of pair index P0 + delta, delta < 2^16
     unsigned a0;               // lo(P0) * C1
@@ -294,7 +302,8 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_persist_kernel(AttnAr
     u32x4 kreg[IT], vreg[IT];
     bf16x8 qreg[MAXQT][2];
     auto fetch = [&](int item) {
-        const int r = item / p.H, h = item % p.H;
+        int r = item / p.H, h = item % p.H;
+        att_xcd_item(p, item, nitems, r, h);
         const bf16_t* kp = p.K + (size_t)r * p.kv_rows * p.ld + h * HD;
         const bf16_t* vp = p.V + (size_t)r * p.kv_rows * p.ld + h * HD;
 #pragma unroll
@@ -322,7 +331,8 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_persist_kernel(AttnAr
     const TrBase Vtr = att_tr_base(Vs, lane);
     const float sl2 = p.scale * LOG2E;      // scores are kept in the log2 domain: p = exp2(s*scale*log2e - max)
     for (; item < nitems; item += gridDim.x) {
-        const int r = item / p.H, h = item % p.H;
+        int r = item / p.H, h = item % p.H;
+        att_xcd_item(p, item, nitems, r, h);
         const size_t qtok0 = (size_t)r * Sq;
         __syncthreads();                     // every wave is done reading the previous item's K/V
 #pragma unroll
@@ -910,7 +920,8 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_fused
     float* nl_s = (float*)(Bs + SP * LDSROW);   // -lse * log2(e)   (-inf for padded queries: P = 0)
     float* nd_s = nl_s + SP;                    // -D * scale
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int r = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    int r = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    att_xcd_item(p, blockIdx.x, gridDim.x, r, h);
     const size_t tok0 = (size_t)r * p.S, qtok0 = (size_t)r * p.Sq;
     const int S = p.S, Sq = p.Sq;
     const int ql = lane & 15, g = lane >> 4;
@@ -1218,7 +1229,8 @@ static int launch_fwd(const AttnArgs& p, int rows, hipStream_t st) {
     return svla_launch_status();
 }
 static int g_attn_bwd_two_pass = 0;   // svla_attn_bwd_two_pass(1): the dQ + dK/dV kernel pair instead of the single-pass kernel (A/B, tests)
-extern "C" int svla_attn_bwd_two_pass(int on) { g_attn_bwd_two_pass = on; return 0; }
+static int g_attn_xcd_rows = 1;       // svla_attn_bwd_two_pass(2): single-pass kernel with row-major items (A/B of the XCD mapping)
+extern "C" int svla_attn_bwd_two_pass(int on) { g_attn_bwd_two_pass = on & 1; g_attn_xcd_rows = !(on & 2); return 0; }
 
 template <int NKT>
 static int launch_bwd(const AttnArgs& p, int rows, hipStream_t st) {
@@ -1282,6 +1294,7 @@ extern "C" int svla_attn_fwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t
     p.Sq = Sq > 0 ? Sq : S; p.ldq = Sq > 0 ? ldq : ld;
     p.kv_rows = kv_rows > 0 ? kv_rows : S;
     p.drop = drop_cfg(drop);
+    p.xcd_rows = 0;      // (measured on the persistent forward: +1.5 % time with whole rows per XCD -- its next-item prefetch already hides the fetch; -1.4 % on the backward)
     hipStream_t st = (hipStream_t)stream;
     if (S <= 64) return launch_fwd<4>(p, rows, st);
     if (S <= 128) return launch_fwd<8>(p, rows, st);
@@ -1304,6 +1317,7 @@ extern "C" int svla_attn_bwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t
     p.Q = Q; p.K = K; p.V = V; p.ld = ld; p.O = (bf16_t*)O; p.ldo = ldo; p.LSE = (float*)LSE; p.dO = dO; p.lddo = lddo;
     p.dQ = dQ; p.dK = dK; p.dV = dV; p.ldd = ldd; p.traj = traj; p.bias = bias; p.kvalid = kvalid;
     p.S = S; p.H = H; p.mask_mode = mask_mode; p.scale = scale; p.Dws = D_ws; p.drop = drop_cfg(drop);
+    p.xcd_rows = (g_attn_xcd_rows && H == 8) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     if (S <= 64) return launch_bwd<4>(p, rows, st);
     if (S <= 128) return launch_bwd<8>(p, rows, st);
