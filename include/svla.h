@@ -144,7 +144,8 @@ int svla_attn_bwd_bf16(const svla_bf16* Q, const svla_bf16* K, const svla_bf16* 
                        const unsigned char* kvalid, int Sq, long ldq, long lddq, float* D_ws, const svla_dropout* drop,
                        void* stream);
 /* Test / A-B hook: 1 = the two-kernel backward (dQ kernel + dK/dV kernel, 12 head slices of HBM traffic per (row, head))
- * instead of the single-pass kernel (8 slices) on the unmasked exact-tile shapes. */
+ * instead of the single-pass kernel (8 slices) on the unmasked exact-tile shapes; 2 = the single-pass kernel with its (row, head) items in row-major
+ * order instead of whole rows per XCD (tools/attn_bwd_once.py: the mapping is worth 1.4 %). */
 int svla_attn_bwd_two_pass(int on);
 
 /* ---- recorded launch sequences --------------------------------------------------------------------------------------------------
