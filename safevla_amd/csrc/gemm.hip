@@ -1088,7 +1088,11 @@ static int nt_os_try(const GemmNtArgs& p, hipStream_t stream) {
         q.row0 = (int)r0;
         const int mt = (tail + BM - 1) / BM, nt = p.N / BN;
         const size_t lds = BM * (BN + 4) * sizeof(float);
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
         hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(mt * nt), dim3(NTHREADS), lds, stream, q);
         return svla_launch_status();
     }
