@@ -194,6 +194,7 @@ def run_nt_os(flavour, M, N, Kc, grid, order=None, seed=0):
     ("br", 512, 512, 384, 2, [3, 2, 1, 0]),      # two tiles per workgroup (deferred stores under the next tile's K-tiles), other wave order
     ("r", 768, 256, 640, 3, None),               # three workgroups, two passes of the pair loop, residual prefetch behind the draining slabs
     ("b", 256, 512, 512, 2, None),
+    ("r", 512, 1024, 384, 3, None),              # 8 tiles on 3 workgroups, 4 n-tiles per row tile: the (row tile, n-tile) cursors carry (grid % ntn = 3)
 ])
 def test_nt_os_output_stationary_kernel(flavour, M, N, Kc, grid, order):
     """svla_nt_os_* (asmgen/nt_os_gen.py): ring of released-one-by-one units, counted waits, exposed pack + deferred stores, DOT-result hazard"""
