@@ -103,6 +103,10 @@ int svla_gemm_nt_bf16(const svla_bf16* A, long lda, const svla_bf16* B, long ldb
  * Test / A-B hook: on = 1 forces the 128x128-tile kernel, 2 the 256-tile / assembly kernels wherever their shape constraints hold, 0 = normal dispatch;
  * on = 10 + flags: 8192 = every assembly kernel off, 16384 = the output-stationary ones off (tools/ab_*.py), smaller flags = timing-only ablations of the HIP kernels. */
 int svla_gemm_force_small_tile(int on);
+/* Test hook: name (NUL-terminated, at most cap - 1 characters) and dispatched M, N, K (mnk[3], may be NULL) of the kernel that the last
+ * svla_gemm_nt_bf16 / svla_gemm_tn_f32acc call of this process launched for its main problem ("svla_nt_as_f0", "svla_nt_os_br", "svla_tn_os",
+ * "gemm_nt8p_bf16_kernel", "gemm_nt_bf16_kernel", ...): the kernel-choice tests assert the generated assembly really ran (same cited layers). */
+int svla_gemm_last_kernel(char* name, int cap, int* mnk);
 /* Tool / test hook: launch kernel `name` of the embedded gfx950 assembly code object (safevla_amd/asmgen/) with a raw kernarg block --
  * probes of the assembly builder's instruction semantics on hardware (tools/asm_probe.py); the GEMM entry points above dispatch to the
  * generated kernels themselves (same cited layers). */
@@ -167,7 +171,7 @@ int svla_replay_abi_stamp(unsigned long long* stamp);
  * allenact_dino_transformer.py:545-552, feeding the Adam step of training/online/dinov2_vits_tsfm_base.py:331-334) is accumulated across
  * workgroups with fp32 atomics, so its last bits depend on arrival order.  svla_det_config(slot, f32_base, i64_shadow, n) registers
  * an int64 shadow (zero-initialised, n elements) of the fp32 range [f32_base, f32_base + n): from then on every such accumulation
- * whose target lies in a registered range is added to the shadow as 64-bit fixed point (2^-52 resolution, |partial| < 2048; integer adds commute,
+ * whose target lies in a registered range is added to the shadow as 64-bit fixed point (2^-52 resolution; only partials with |partial| < 0.25 enter the shadow, so up to 8192 of them cannot wrap its +-2048 range -- larger or non-finite ones take the plain fp32 atomic and stay visible; integer adds commute,
  * so the sum is bitwise repeatable; each partial is rounded once to the grid, non-finite partials bypass the shadow) instead.
  * svla_det_finalize adds shadow * 2^-52 into the fp32 buffer and clears the shadow.  Repeatable are the GRADIENTS: the clip coefficient (fp64
  * atomics of the squared norm) and the three loss sums are still accumulated in arrival order.

@@ -932,8 +932,8 @@ class Emu:
             raise EmuError(f"write to read-only buffer at 0x{addr:x}")
         b[o:o + data.size] = data
 
-    def run(self, kernarg, wg_id, order=None, max_steps=50_000_000):
-        """kernarg: bytes.  s[0:1] = kernarg address, s2 = workgroup id, v0 = thread id in the workgroup."""
+    def run(self, kernarg, wg_id, order=None, max_steps=50_000_000, wg_id_y=0):
+        """kernarg: bytes.  s[0:1] = kernarg address, s2 = workgroup id x, s3 = workgroup id y (kernels that enable it), v0 = thread id in the workgroup."""
         ka = np.frombuffer(bytes(kernarg), dtype=np.uint8).copy()
         kaddr = self.alloc(ka)
         waves = [Wave(i, self) for i in range(self.nwaves)]
@@ -941,6 +941,7 @@ class Emu:
             w.S[0] = kaddr & 0xffffffff
             w.S[1] = kaddr >> 32
             w.S[2] = wg_id
+            w.S[3] = wg_id_y
             w.V[0] = (np.arange(64) + 64 * w.wid).astype(np.uint32)
         order = list(order) if order is not None else list(range(self.nwaves))
         ops = self.prog.ops

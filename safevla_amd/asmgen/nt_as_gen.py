@@ -32,14 +32,16 @@ import os as _os
 
 from .amdasm import EXEC, M0, Prog, a, s, v
 
-KS = 32                    # k-steps of 16 (K = 512)
+KS_DEFAULT = 32            # k-steps of 16 (K = 512); the ViT-S flavours run K = 384 (24 k-steps: 192 of the 256 AGPRs hold A)
 LDS_W = (0, 65536)
 LDS_STG = 131072           # + wave * 4096
 LDS_BIAS = 147456          # fp32 bias[N], N <= 4096 (the bias table doubles as the accumulator initialiser)
 LDS_BYTES = 163840
 
 # ---- kernel arguments (byte offsets in the kernarg segment)
-KARG = dict(A=0, lda=8, B=16, ldb=24, bias=32, res=40, ldr=48, C=56, ldc=64, cmask=72, N=76, alpha=80, npanels=84, bits=88,
+# nr: columns of the n-range one workgroup sweeps (= N for the row-streaming launches; N / nsplit for the mid-M launches whose grid is (panel slots,
+# nsplit): workgroup_id_y picks the range [y * nr, (y + 1) * nr)); flags bit 0: no phases (every wave of a workgroup starts its sweep in step 0)
+KARG = dict(A=0, lda=8, B=16, ldb=24, bias=32, res=40, nr=48, flags=52, C=56, ldc=64, cmask=72, N=76, alpha=80, npanels=84, bits=88,
             key=96, thr=100, scale=104, row_mult=108, seed_dev=112, stream_key=120, grid=124)
 KARG_BYTES = 128
 
@@ -48,6 +50,10 @@ S_A, S_LDA, S_B, S_LDB, S_BIAS, S_RES, S_LDR, S_C = s(4, 2), s(6, 2), s(8, 2), s
 S_LDC, S_CMASK, S_N, S_ALPHA, S_NPANELS, S_BITS = s(20, 2), s(22), s(23), s(24), s(25), s(26, 2)
 S_KEY, S_THR, S_SCALE, S_ROWMULT, S_SEEDDEV, S_STREAMKEY, S_GRID = s(28), s(29), s(30), s(31), s(32, 2), s(34), s(35)
 S_WID = s(36)
+S_NLO = S_RES.sub(0)                  # first column of this workgroup's n-range (prologue only; the residual pointer's slot: no residual flavour exists)
+S_NR, S_FLAGS = S_LDR.sub(0), S_LDR.sub(1)      # kernargs nr / flags (prologue only); afterwards s16:17 = exec mask of the 48 DMA lanes of a 768-byte W row (K = 384)
+S_LO48 = s(16, 2)
+S_NFULL, S_PHSTEP = s(46), s(47)      # N of the whole problem (sign-bit / dropout indexing; S_N = nr from the prologue on); steps between the phases of consecutive waves
 S_LDA2, S_LDC2, S_LDR2 = s(37), s(38), s(39)
 SRD_X, SRD_C, SRD_T = s(40, 4), s(48, 4), s(56, 4)
 S_DUM, S_NEXTN0 = s(44), s(45)        # dummy steps left; n0 of the next step
@@ -94,6 +100,7 @@ V_RB = [[v(220 + 4 * i, 4) for i in range(4)]] * 2      # read-back (row-major) 
 V_L0, V_C8, V_H4 = v(236), v(237), v(211)           # flavour lane constants: dropout pair index of (row, 4 h); 8 * (lane & 31); 4 * (lane >> 5)
 V_F = [v(238 + i) for i in range(18)]               # flavour temporaries (v244.. double as prologue temporaries)
 V_TMP = [v(244 + i) for i in range(12)]
+V_BCH = [v(220 + i) for i in range(16)]             # prologue: the bias chunks in flight (the read-back registers' space)
 
 
 def BW(par, mb):
@@ -101,7 +108,7 @@ def BW(par, mb):
     return v(128 + (par * 2 + mb) * 2, 2)
 
 
-def XFRAG(mb, ks):
+def XFRAG(mb, ks, KS=KS_DEFAULT):
     return a((mb * KS + ks) * 4, 4)
 
 
@@ -132,8 +139,13 @@ class NtAsGen:
     DMA_END = 72       # the last LDS-DMA piece of the next tile is issued by this gap (~1.5 k cycles before the barrier)
     BAR_GAP = 119      # the barrier follows MFMA 119 (k-step 29); the last fragment reads of the tile are issued at gaps 113 / 115
 
-    def __init__(self, name="svla_nt_as_f0", relu=False, drop=False, bits_out=False, bits_in=False, cap=None, dbg="", stagger=0, epi_order=1, dma_end=None, store_nt=True, load_nt=False, xstart=0, wphases=4, xburst=2):
+    def __init__(self, name="svla_nt_as_f0", relu=False, drop=False, bits_out=False, bits_in=False, cap=None, dbg="", stagger=0, epi_order=1, dma_end=None, store_nt=True, load_nt=False, xstart=0, wphases=4, xburst=2, K=512):
         self.name = name
+        assert K in (384, 512)
+        self.K, self.KS = K, K // 16
+        if K != 512:      # the gap positions of the K = 512 schedule scaled to NG = 4 KS gaps
+            self.BAR_GAP = 4 * self.KS - 9
+            self.DMA_END = (72 * self.KS) // 32
         # epilogue flavour: relu (+ bits_out: the output's sign bits, + drop: train-mode dropout after the activation) | bits_in: alpha * product,
         # zeroed where the ReLU sign bit of the forward activation is 0 (no bias) | none of them: + bias
         self.relu, self.drop, self.bits_out, self.bits_in = relu, drop, bits_out, bits_in
@@ -203,6 +215,10 @@ class NtAsGen:
         p.v_lshrrev_b32(T[3], 5, T[0])              # h = lane >> 5
         p.s_waitcnt(lgkmcnt=0)
         p.s_mov_b64(S_STMASK, 0)
+        # ---- this workgroup's n-range: from here on S_N is the width of the range it sweeps, pointers / offsets are moved to its first column
+        p.s_mov_b32(S_NFULL, S_N)
+        p.s_mov_b32(S_N, S_NR)
+        p.s_mul_i32(S_NLO, s(3), S_NR)              # workgroup_id_y * nr
         if "time" in self.dbg:
             for i in range(28, 35):
                 p.s_mov_b32(s(i), 0)
@@ -211,6 +227,12 @@ class NtAsGen:
         p.s_lshl_b32(S_LDR2, S_LDR.sub(0), 1)
         p.s_lshl_b32(S_LDB2, S_LDB.sub(0), 1)
         p.s_mul_i32(S_LDB2X48, S_LDB2, 48)
+        p.s_mul_i32(S_T[0], S_NLO, S_LDB2)          # (< 2^32: N <= 4096 rows)
+        p.s_add_u32(S_B.sub(0), S_B.sub(0), S_T[0])
+        p.s_addc_u32(S_B.sub(1), S_B.sub(1), 0)
+        p.s_lshl_b32(S_T[0], S_NLO, 2)
+        p.s_add_u32(S_BIAS.sub(0), S_BIAS.sub(0), S_T[0])
+        p.s_addc_u32(S_BIAS.sub(1), S_BIAS.sub(1), 0)
         p.s_lshl_b32(S_T[0], S_WID, 4)
         p.s_mul_i32(S_T[1], S_T[0], S_LDB2)         # w * 16 * ldb2 (< 2^32: N <= 4096 rows)
         p.s_add_u32(S_WBASE, S_B.sub(0), S_T[1])
@@ -243,6 +265,8 @@ class NtAsGen:
         p.v_and_b32(T[7], 7, T[0])                  # lane & 7
         p.v_mul_lo_u32(T[8], T[6], S_LDC2)
         p.v_lshl_add_u32(V_COFF, T[7], 4, T[8])
+        p.s_lshl_b32(S_T[3], S_NLO, 1)
+        p.v_add_u32(V_COFF, S_T[3], V_COFF)         # + 2 * n_lo bytes
         # staging (wave-private 4 KiB at LDS_STG + w * 4096): [32 rows][128 B], 16-byte chunk q of row r stored at chunk q ^ ((r >> 1) & 7), and in
         # rows 16-31 the two 8-byte halves of a chunk are swapped: the 32 lanes of an accumulator-layout write (8 bytes each, rows 0-31, one chunk) then
         # cover 32 different 8-byte slots of the 256 bytes the LDS serves per clock (with q ^ (r & 7), rows r, r + 8, r + 16, r + 24 met in one slot:
@@ -278,10 +302,11 @@ class NtAsGen:
         p.s_lshl_b32(S_T[0], S_WID, 1)
         for mb in range(2):
             p.s_add_u32(S_T[1], S_T[0], mb)
-            p.s_mul_i32(S_T[1], S_T[1], S_N)
-            p.s_lshl_b32(S_BROW[mb], S_T[1], 2)     # (w*2 + mb) * (N/64) * 256
+            p.s_mul_i32(S_T[1], S_T[1], S_NFULL)
+            p.s_add_u32(S_T[1], S_T[1], S_NLO)
+            p.s_lshl_b32(S_BROW[mb], S_T[1], 2)     # (w*2 + mb) * (N/64) * 256 + (n_lo/64) * 256
         if self.drop:
-            p.s_mul_i32(S_RN2, S_ROWMULT, S_N)
+            p.s_mul_i32(S_RN2, S_ROWMULT, S_NFULL)
             p.s_lshr_b32(S_RN2, S_RN2, 1)
             p.s_lshl_b32(S_RN32, S_RN2, 5)
             p.s_mov_b32(S_ONE1, 0x00010001)
@@ -293,6 +318,8 @@ class NtAsGen:
             p.v_add_u32(T[8], S_T[1], T[2])
             p.v_mul_lo_u32(T[8], T[8], S_RN2)
             p.v_lshl_add_u32(V_L0, T[3], 1, T[8])
+            p.s_lshr_b32(S_T[1], S_NLO, 1)
+            p.v_add_u32(V_L0, S_T[1], V_L0)         # + n_lo / 2 pairs
             # device-resident pass seed (recorded launch sequences): key = *seed_dev ^ stream_key
             p.s_or_b32(S_T[1], S_SEEDDEV.sub(0), S_SEEDDEV.sub(1))
             p.s_cmp("eq_u32", S_T[1], 0)
@@ -304,12 +331,18 @@ class NtAsGen:
         elif self.bits_out:
             p.s_mov_b32(S_ONE1, 0x00010001)
         if self.bias:
-            self.bias_table()
+            self.bias_loads()
         # ---- phase of this wave: phi = w * NS/4 + (workgroup & cmask) dummy steps before its first panel, (3 - w) * NS/4 after its last
         sh = {4: 0, 2: 1, 1: 2}[self.wphases]
         p.s_lshr_b32(S_T[0], S_N, 8 - sh)           # NS / wphases
+        p.s_and_b32(S_T[1], S_FLAGS, 1)
+        p.s_cmp("eq_u32", S_T[1], 0)
+        p.s_cselect_b32(S_PHSTEP, S_T[0], 0)        # flags bit 0: no phases
         p.s_lshr_b32(S_T[1], S_WID, sh)             # phase index of this wave
-        p.s_mul_i32(S_DUM, S_T[1], S_T[0])
+        p.s_mul_i32(S_DUM, S_T[1], S_PHSTEP)
+        if self.K == 384:
+            p.s_mov_b32(S_LO48.sub(0), 0xffffffff)      # (nr / flags are consumed)
+            p.s_mov_b32(S_LO48.sub(1), 0x0000ffff)
         if sh:
             p.s_lshl_b32(S_CMASK, S_CMASK, sh)      # the workgroups spread over NS / wphases steps
             p.s_or_b32(S_CMASK, S_CMASK, (1 << sh) - 1)
@@ -319,12 +352,12 @@ class NtAsGen:
         p.s_mov_b32(S_P, s(2))
         p.s_mov_b32(S_PN, s(2))
         self.panel_srd(SRD_X, S_A, S_PN, S_LDA2)
-        for ks in range(KS):
+        for ks in range(self.KS):
             for mb in range(2):
                 if "nox" not in self.dbg:
-                    p.buffer_load(XFRAG(mb, ks), V_XOFF[mb], SRD_X, S_XROW, ks * 32)
+                    p.buffer_load(XFRAG(mb, ks, self.KS), V_XOFF[mb], SRD_X, S_XROW, ks * 32)
             if ks == 23:
-                p.s_waitcnt(vmcnt=0)
+                p.s_waitcnt(vmcnt=0)            # (6-bit counter: bias chunks + 48 fragment loads so far; K = 384: the 16 DMA pieces follow)
         # ---- ROTATION: workgroup g starts the shared tile sequence at tile (g mod NS).  Without it every CU of the chip stores the same
         # 128-byte column of C (row stride 2 N bytes: one L2 / HBM channel group) and fetches the same W tile at the same moment.
         p.s_lshr_b32(S_T[0], S_N, 6)                # NS
@@ -347,6 +380,9 @@ class NtAsGen:
         p.s_waitcnt(vmcnt=0, lgkmcnt=0)
         self.vm.wait(0)
         self.lg.wait(0)
+        if self.bias:
+            self.bias_table()
+            p.s_waitcnt(lgkmcnt=0)
         if "time" in self.dbg:
             p.s_memtime(s(0, 2))
             p.s_waitcnt(lgkmcnt=0)
@@ -362,26 +398,45 @@ class NtAsGen:
             for nb in range(2):
                 self.wread(ks, nb)
 
+    def bias_loads(self):
+        """bias[N] -> VGPRs, every 1-KiB chunk requested before anything waits (the host always passes a bias pointer: zeros when the GEMM has none).  With
+        one wait per chunk the prologue of a launch that runs a handful of n-steps per workgroup (mid-M) spent 8 serial memory latencies on a 2048-wide
+        bias.  num_records = 4 N: reads past bias[N) return 0 -- the chunk offset is part of the VGPR offset (soffset is excluded from the hardware's range
+        check: with it there, N % 256 == 128 read 512 bytes past the bias)."""
+        p = self.p
+        T = V_TMP
+        p.v_lshlrev_b32(T[8], 2, v(0))
+        p.s_lshl_b32(S_T[4], S_N, 2)
+        p.s_mov_b32(SRD_T.sub(2), S_T[4])
+        for i in range(16):       # N <= 4096
+            if i:
+                p.s_cmp("gt_u32", S_T[4], 1024 * i)
+                p.s_cbranch_scc0("L_BIASLD")
+            if "nobias" in self.dbg:
+                p.v_mov_b32(V_BCH[i], 0)
+            else:
+                p.buffer_load(V_BCH[i], T[8], SRD_T, 0, 0)
+            if i < 15:
+                p.v_add_u32(T[8], 1024, T[8])
+        p.label("L_BIASLD")
+
     def bias_table(self):
-        """bias[N] -> LDS (the host always passes a bias pointer: zeros when the GEMM has none)"""
+        """the chunks -> LDS (after the wait that also covers the first panel's A fragments and the first W tile)"""
         p = self.p
         T = V_TMP
         p.v_lshlrev_b32(T[8], 2, v(0))
         p.v_add_u32(T[9], LDS_BIAS, T[8])
-        p.s_mov_b32(S_T[3], 0)
         p.s_lshl_b32(S_T[4], S_N, 2)
-        p.s_mov_b32(SRD_T.sub(2), S_T[4])           # num_records = 4 N: reads past bias[N) return 0
-        p.label("L_BIAS")
-        if "nobias" in self.dbg:
-            p.v_mov_b32(T[10], 0)
-        else:
-            p.buffer_load(T[10], T[8], SRD_T, S_T[3])
-        p.s_waitcnt(vmcnt=0)
-        p.ds_write(T[9], T[10])
-        p.v_add_u32(T[9], 1024, T[9])
-        p.s_add_u32(S_T[3], S_T[3], 1024)
-        p.s_cmp("lt_u32", S_T[3], S_T[4])
-        p.s_cbranch_scc1("L_BIAS")
+        for i in range(16):
+            if i:
+                p.s_cmp("gt_u32", S_T[4], 1024 * i)
+                p.s_cbranch_scc0("L_BIASST")
+            p.ds_write(T[9], V_BCH[i], 0)
+            if i == 7:
+                p.s_waitcnt(lgkmcnt=0)          # (4-bit counter)
+            if i < 15:
+                p.v_add_u32(T[9], 1024, T[9])
+        p.label("L_BIASST")
 
     def panel_srd(self, srd, base, panel, ld2):
         """srd.base = base + panel * 256 * ld2 (64-bit); one group: the carry travels through SCC"""
@@ -396,7 +451,7 @@ class NtAsGen:
     def bits_srd(self, panel):
         """SRD_B.base = bits + panel * 8 slab rows * (N/64) slabs * 256 B = bits + panel * N * 32"""
         p = self.p
-        p.s_mul_i32(S_T[5], panel, S_N)
+        p.s_mul_i32(S_T[5], panel, S_NFULL)
         p.s_lshl_b32(S_T[5], S_T[5], 5)
         p.s_add_u32(SRD_B.sub(0), S_BITS.sub(0), S_T[5])
         p.s_addc_u32(S_T[6], S_BITS.sub(1), 0)
@@ -425,7 +480,11 @@ class NtAsGen:
 
         def g2():
             if "nodma" not in self.dbg:
+                if self.K == 384:      # a W row is 768 bytes = 48 lanes (LDS pitch stays 1 KiB): lanes 48..63 fetch nothing
+                    p.s_mov_b64(EXEC, S_LO48)
                 p.global_load_lds_x4(V_DMATMP, S_WPTR)
+                if self.K == 384:
+                    p.s_mov_b64(EXEC, -1)
                 self.vm.issue(f"dma{t}")
 
         def g3():
@@ -663,6 +722,7 @@ class NtAsGen:
     def body(self, kind, st):
         """kind: 'first' | 'mid' | 'last' of this wave's sweep over a panel; st: accumulator set of this step"""
         p = self.p
+        KS = self.KS
         NG = 4 * KS
         BAR = self.BAR_GAP
         fixed = [[] for _ in range(NG)]
@@ -679,7 +739,7 @@ class NtAsGen:
                 fixed[BAR + 1 + 2 * k + nb].append(lambda k=k, nb=nb: self.wread(k, nb))
         # toggle the read addresses to the other buffer after their last use for this tile (chunk class j: last k-step 24 + j, read at gaps 4 (21 + j) + 1 / + 3)
         for j in range(8):
-            fixed[4 * (21 + j) + 3].append(lambda j=j: p.v_xor_b32(V_WRD[j], 0x10000, V_WRD[j]))
+            fixed[4 * (KS - 11 + j) + 3].append(lambda j=j: p.v_xor_b32(V_WRD[j], 0x10000, V_WRD[j]))
         # ---- barrier: every read of this tile issued (last: k-step 31 at gaps 113 / 115) and retired, own DMA pieces of the next tile landed
         fixed[BAR].insert(0, lambda: self.barrier(kind))
 
@@ -713,7 +773,7 @@ class NtAsGen:
                     def xl(ks=ks, mb=mb):
                         if "nox" in self.dbg:
                             return
-                        p.buffer_load(XFRAG(mb, ks), V_XOFF[mb], SRD_X, S_XROW, ks * 32, nt=self.load_nt)
+                        p.buffer_load(XFRAG(mb, ks, self.KS), V_XOFF[mb], SRD_X, S_XROW, ks * 32, nt=self.load_nt)
                         self.vm.issue(f"x{ks}")
                     if self.xburst:
                         continue
@@ -723,7 +783,7 @@ class NtAsGen:
                     def f():
                         if "nox" in self.dbg:
                             return
-                        p.buffer_load(XFRAG(mb, ks), V_XOFF[mb], SRD_X, S_XROW, ks * 32, nt=self.load_nt)
+                        p.buffer_load(XFRAG(mb, ks, self.KS), V_XOFF[mb], SRD_X, S_XROW, ks * 32, nt=self.load_nt)
                         self.vm.issue(f"x{ks}")
                     return f
                 if self.xburst == 3:          # two lines (8 k-steps) per burst
@@ -780,7 +840,7 @@ class NtAsGen:
                 lg_tags += [t for t in self.lg.q if t.startswith("bias")]
             self.wait_for(vm_tags=vm_tags, lg_tags=lg_tags)
             c = (BIASR(nb) if self.bias else 0) if ks == 0 else ACC(st, nb, mb)
-            p.v_mfma_f32_32x32x16_bf16(ACC(st, nb, mb), WFRAG(ks, nb), XFRAG(mb, ks), c)
+            p.v_mfma_f32_32x32x16_bf16(ACC(st, nb, mb), WFRAG(ks, nb), XFRAG(mb, ks, self.KS), c)
             for th in fixed[g]:
                 th()
             if g < BAR:
@@ -869,10 +929,9 @@ class NtAsGen:
                 th()
         # trailing dummy steps: (3 - w) * NS/4, so that every wave of the workgroup passes the same number of barriers
         sh = {4: 0, 2: 1, 1: 2}[self.wphases]
-        p.s_lshr_b32(S_T[0], S_N, 8 - sh)
         p.s_lshr_b32(S_T[1], S_WID, sh)
         p.s_sub_u32(S_T[1], self.wphases - 1, S_T[1])
-        p.s_mul_i32(S_DUM, S_T[0], S_T[1])
+        p.s_mul_i32(S_DUM, S_PHSTEP, S_T[1])
         p.label("L_DUMB")
         p.s_cmp("eq_u32", S_DUM, 0)
         p.s_cbranch_scc1("L_EXIT")
@@ -924,7 +983,7 @@ class NtAsGen:
 \t\t.amdhsa_user_sgpr_count 2
 \t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1
 \t\t.amdhsa_system_sgpr_workgroup_id_x 1
-\t\t.amdhsa_system_sgpr_workgroup_id_y 0
+\t\t.amdhsa_system_sgpr_workgroup_id_y 1
 \t\t.amdhsa_system_sgpr_workgroup_id_z 0
 \t\t.amdhsa_system_vgpr_workitem_id 0
 \t\t.amdhsa_next_free_vgpr 512
@@ -968,6 +1027,7 @@ FLAVOURS = {
     "f1d": dict(relu=True, bits_out=True, drop=True),           # bias, ReLU, dropout, sign bits out: linear1 forward in train mode
     "f1": dict(relu=True, bits_out=True),                       # ... eval mode / visual compressor
     "f3": dict(bits_in=True),                                   # alpha * product under the ReLU sign bits: input gradient through linear2 (+ dropout scale)
+    "k384_f0": dict(K=384),                                     # K = 384 (24 k-steps): the frozen ViT-S/14's qkv projection (dino_preprocessors.py:27-35)
 }
 if _os.environ.get("SVLA_ASM_DEBUG_VARIANTS"):      # timing-only / bisection builds (tools/time_nt_as.py)
     for _d in ("time", "time,nostore", "time,nodma", "time,noepi", "time,nox", "time,nobarwait", "time,noepi,nodma,nox"):

@@ -32,6 +32,10 @@ int svla_asm_has(const char* name) {
 }
 
 int svla_asm_launch(const char* name, const void* kernarg, size_t kernarg_bytes, int grid, int block, hipStream_t stream) {
+    return svla_asm_launch2(name, kernarg, kernarg_bytes, grid, 1, block, stream);
+}
+
+int svla_asm_launch2(const char* name, const void* kernarg, size_t kernarg_bytes, int grid_x, int grid_y, int block, hipStream_t stream) {
     hipFunction_t f = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -43,7 +47,7 @@ int svla_asm_launch(const char* name, const void* kernarg, size_t kernarg_bytes,
     }
     size_t sz = kernarg_bytes;
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, (void*)kernarg, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-    HIP_CHECK_RET(hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, 0, stream, nullptr, extra));
+    HIP_CHECK_RET(hipModuleLaunchKernel(f, grid_x, grid_y, 1, block, 1, 1, 0, stream, nullptr, extra));
     return svla_launch_status();
 }
 

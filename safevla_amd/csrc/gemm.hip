@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cstdio>
+#include <mutex>
 
 #define BM 128
 #define BN 128
@@ -949,7 +950,11 @@ static int launch_nt256(const GemmNtArgs& p, int grid, hipStream_t stream) {
 static int g_force_small_tile = 0, g_dbg = 0;
 // SVLA_GEMM_LOG=<file>: one line "kernel M N K" per big-GEMM launch, in launch order -- tools/prof_summarize.py joins it with the rocprofv3
 // counter rows of the same kernel names (i-th dispatch <-> i-th line), so HBM traffic is reported per (kernel, shape) and not as a launch-weighted mean
-static void gemm_log(const char* kernel, int M, int N, int K) {
+static char g_last_kernel[96] = "";
+static int g_last_shape[3] = {0, 0, 0};
+// extra = bytes per output row beyond the A and C rows (residual 2 N, sign bits N / 8): the profile summary counts them as algorithmic bytes;
+// to_file = false: remember the name only (the 128-tile kernel also runs the M % 256 tails, which are not logged, so its dispatches cannot be joined by index)
+static void gemm_log(const char* kernel, int M, int N, int K, int extra = 0, bool to_file = true) {
     static FILE* f = nullptr;
     static bool init = false;
     if (!init) {
@@ -957,11 +962,49 @@ static void gemm_log(const char* kernel, int M, int N, int K) {
         const char* path = getenv("SVLA_GEMM_LOG");
         if (path) f = fopen(path, "w");
     }
-    if (f) { fprintf(f, "%s %d %d %d\n", kernel, M, N, K); fflush(f); }
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s", kernel);
+    g_last_shape[0] = M; g_last_shape[1] = N; g_last_shape[2] = K;
+    static const bool log_all = getenv("SVLA_GEMM_LOG_ALL") != nullptr;      // shape studies (tools/): the 128-tile launches too -- such a log cannot be joined with counter rows
+    if (f && (to_file || log_all)) { fprintf(f, "%s %d %d %d %d\n", kernel, M, N, K, extra); fflush(f); }
+}
+// name (and M, N, K as dispatched: full tiles only for the assembly kernels) of the kernel the last svla_gemm_nt_bf16 / svla_gemm_tn_f32acc call of this
+// process launched for its main problem -- tests assert that an "assembly" test really ran the assembly kernel and not a silent fall-through
+extern "C" int svla_gemm_last_kernel(char* name, int cap, int* mnk) {
+    if (!name || cap <= 0) return SVLA_EINVAL;
+    snprintf(name, (size_t)cap, "%s", g_last_kernel);
+    if (mnk) { mnk[0] = g_last_shape[0]; mnk[1] = g_last_shape[1]; mnk[2] = g_last_shape[2]; }
+    return SVLA_OK;
+}
+// one-time device facts / scratch of the assembly dispatchers.  Thread-safe (std::call_once); refuses to initialise lazily inside a stream capture
+// (hipMalloc + a synchronous memset would invalidate it): call any GEMM once -- or svla_gemm_force_small_tile(0), which _lib.py does at load -- first.
+struct GemmGlobals { int n_cu = 0; float* zero_bias = nullptr; int rc = 0; };
+static GemmGlobals g_gg;
+static std::once_flag g_gg_once;
+static int gemm_globals_init() {
+    std::call_once(g_gg_once, [] {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&g_gg.n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess) e = hipMalloc(&g_gg.zero_bias, 4096 * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(g_gg.zero_bias, 0, 4096 * sizeof(float));
+        g_gg.rc = (e == hipSuccess) ? 0 : (int)e;
+    });
+    return g_gg.rc;
+}
+static int gemm_globals(hipStream_t stream, const GemmGlobals** out) {
+    if (!g_gg.n_cu) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return SVLA_EINVAL;
+        const int rc = gemm_globals_init();
+        if (rc) return rc;
+    }
+    *out = &g_gg;
+    return 0;
 }
 // on = 0/1/2: normal dispatch / force the 128x128 kernels / force the 256-tile kernels wherever their shape constraints hold (tests); on = 10 + f: flags f of the 256-tile kernels -- timing-only ablations 1 / 2 / 64,
 // 128 / 256 = force the 2-buffer kernel (gemm_nt256k64) / the 8-phase kernel (gemm_nt8p) (A/B comparisons)
 extern "C" int svla_gemm_force_small_tile(int on) {
+    if (gemm_globals_init()) return SVLA_EINVAL;
     if (on >= 10) { g_dbg = on - 10; g_force_small_tile = 0; }
     else { g_dbg = 0; g_force_small_tile = on; }
     return SVLA_OK;
@@ -971,15 +1014,22 @@ extern "C" int svla_gemm_force_small_tile(int on) {
 // sub-problem on the 128-tile kernel (row0 keeps its dropout counters / sign-bit blocks on the global row index).
 #define NT_AS_NOT_TAKEN (-12345)
 struct NtAsKarg {      // = asmgen/nt_as_gen.py KARG
-    const void* A; long lda; const void* B; long ldb; const float* bias; const void* res; long ldr; void* C; long ldc;
+    const void* A; long lda; const void* B; long ldb; const float* bias; const void* res; int nr, flags; void* C; long ldc;
     int cmask, N; float alpha; int npanels; const void* bits; unsigned key, thr; float scale; int row_mult; const unsigned* seed_dev; unsigned stream_key; int grid;
 };
 static_assert(sizeof(NtAsKarg) == 128, "kernarg layout of the nt_as kernels");
+// floor of the mid-M launch in 256-row panels (SVLA_NT_AS_MIN_PANELS: sweeps of tools/ab_midm.py; the cost model below decides above it)
+static int nt_as_min_panels() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SVLA_NT_AS_MIN_PANELS"); v = e ? atoi(e) : 8; }
+    return v;
+}
 static int nt_as_try(const GemmNtArgs& p, hipStream_t stream) {
-    if (p.K != 512 || p.out_f32 || (p.N % 128) || p.N > 4096 || p.N < 128 || (p.dbg & 8192) || g_force_small_tile == 1) return NT_AS_NOT_TAKEN;
+    if ((p.K != 512 && p.K != 384) || p.out_f32 || (p.N % 128) || p.N > 4096 || p.N < 128 || (p.dbg & 8192) || g_force_small_tile == 1) return NT_AS_NOT_TAKEN;
     if (p.relu_mask) return NT_AS_NOT_TAKEN;
     const int npanels = p.M / 256;
-    if (npanels < 512 && g_force_small_tile != 2) return NT_AS_NOT_TAKEN;      // fewer than two panels per CU: the tile kernels balance better
+    // >= 2 panels per CU: the row-streaming launch (one persistent workgroup per CU, phases); fewer: the mid-M launch below
+    if (npanels < nt_as_min_panels() && g_force_small_tile != 2) return NT_AS_NOT_TAKEN;
     if (npanels < 1) return NT_AS_NOT_TAKEN;
     const char* name = nullptr;
     if (p.residual) return NT_AS_NOT_TAKEN;
@@ -990,24 +1040,24 @@ static int nt_as_try(const GemmNtArgs& p, hipStream_t stream) {
         if (!p.drop.thr) name = "svla_nt_as_f1";
         else if ((unsigned long long)p.M * (unsigned long long)p.drop.row_mult * (unsigned long long)p.N / 2 < 0xffffffffull) name = "svla_nt_as_f1d";
     } else if (p.act == ACT_NONE && !p.bits_out && !p.drop.thr && p.alpha == 1.f) name = "svla_nt_as_f0";
+    if (p.K == 384) name = (name && !strcmp(name, "svla_nt_as_f0")) ? "svla_nt_as_k384_f0" : nullptr;      // the ViT-S width: bias flavour only
+#ifdef SVLA_ASM_DEBUG      // instrumented builds of tools/ only (SVLA_EXTRA_FLAGS=-DSVLA_ASM_DEBUG): svla_nt_as_f0_<variant>
     static char dbg_name[96];
-    if (name && getenv("SVLA_NT_AS_VARIANT")) {      // fault-bisection builds of tools/: svla_nt_as_f0_<variant>
+    if (name && getenv("SVLA_NT_AS_VARIANT")) {
         snprintf(dbg_name, sizeof(dbg_name), "%s_%s", name, getenv("SVLA_NT_AS_VARIANT"));
         name = dbg_name;
     }
+#endif
     if (!name || !svla_asm_has(name)) return NT_AS_NOT_TAKEN;
-    static int n_cu = 0;
-    static float* zero_bias = nullptr;
-    if (!n_cu) {
-        int dev = 0;
-        HIP_CHECK_RET(hipGetDevice(&dev));
-        HIP_CHECK_RET(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        HIP_CHECK_RET(hipMalloc(&zero_bias, 4096 * sizeof(float)));
-        HIP_CHECK_RET(hipMemset(zero_bias, 0, 4096 * sizeof(float)));
-    }
+    // the sign-bit offset of a panel (panel * N * 32 bytes) is 32-bit scalar arithmetic in the kernel (asmgen/nt_as_gen.py bits_srd)
+    if ((p.bits_in || p.bits_out) && (unsigned long long)p.M * (unsigned long long)p.N / 8 >= 0xffffffffull) return NT_AS_NOT_TAKEN;
+    const GemmGlobals* gg = nullptr;
+    { const int rc = gemm_globals(stream, &gg); if (rc) return rc; }
+    const int n_cu = gg->n_cu;
+    float* const zero_bias = gg->zero_bias;
     NtAsKarg k;
     memset(&k, 0, sizeof(k));
-    k.A = p.A; k.lda = p.lda; k.B = p.B; k.ldb = p.ldb; k.bias = p.bias ? p.bias : zero_bias; k.res = p.residual; k.ldr = p.ldr; k.C = p.C; k.ldc = p.ldc;
+    k.A = p.A; k.lda = p.lda; k.B = p.B; k.ldb = p.ldb; k.bias = p.bias ? p.bias : zero_bias; k.C = p.C; k.ldc = p.ldc;
     {      // phase spread over workgroups: (workgroup & cmask) < NS/4 extra steps, cmask + 1 = the largest power of two <= NS/4
         int q = p.N / 256, m = 1;
         while (m * 2 <= q) m *= 2;
@@ -1015,10 +1065,44 @@ static int nt_as_try(const GemmNtArgs& p, hipStream_t stream) {
     }
     k.N = p.N; k.alpha = p.alpha; k.npanels = npanels; k.bits = p.bits_in ? (const void*)p.bits_in : (const void*)p.bits_out;
     k.key = p.drop.key; k.thr = p.drop.thr; k.scale = p.drop.scale; k.row_mult = p.drop.row_mult; k.seed_dev = p.drop.seed_dev; k.stream_key = p.drop.stream_key;
+    k.nr = p.N; k.flags = 0;
     k.grid = npanels < n_cu ? npanels : n_cu;
+    int grid_y = 1;
+    if (npanels < 2 * n_cu) {
+        // mid-M (an acting step's 45 panels, the 233 of the batch-256 probe, the ViT's 216): too few panels to give every CU two sweeps.  The grid becomes
+        // (panel slots) x (n-ranges): workgroup (x, y) sweeps columns [y nr, (y + 1) nr) of panels x, x + slots, ...; no phases (a workgroup that holds one
+        // panel has nothing to de-phase).  nsplit minimises rounds * (steps per sweep + ~2.5 steps of prologue / drain) over the divisors of N / 128.
+        // Cost model, calibrated on profiles/r05_midm_sweep.txt (asm side within ~10 % of the measurements): one n-step (64 columns of a 256-row panel) takes
+        // ~2.76 us * K/512; a workgroup pays ~5 steps per panel it loads (the fragment-shaped A gather runs at ~13 B/clk) + its sweep; the tile kernels take
+        // ~(6.2 + 11.6 K/512) us per round of 256 tiles.  The assembly launch is taken when it is at least 5 % ahead (a ragged M adds the tail launch).
+        const int ns = p.N / 64;
+        double best = 1e30;
+        int best_d = 1, best_slots = k.grid;
+        for (int d = 1; d <= p.N / 128; ++d) {
+            if ((p.N / 128) % d) continue;
+            int slots = npanels * d <= n_cu ? npanels : n_cu / d;
+            if (slots < 1) break;
+            const int rounds = (npanels + slots - 1) / slots;
+            const double cost = rounds * ((double)ns / d + 5.0);
+            if (cost < best - 1e-9) { best = cost; best_d = d; best_slots = slots; }
+        }
+        if (g_force_small_tile != 2) {
+            const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+            const double hip = (double)((tiles + n_cu - 1) / n_cu) * (6.2 + 11.6 * p.K / 512.0);
+            const double asm_cost = (best + ((p.M % 256) ? 2.5 : 0.0)) * 2.76 * p.K / 512.0;
+            if (asm_cost > 0.95 * hip) return NT_AS_NOT_TAKEN;
+        }
+        grid_y = best_d;
+        k.grid = best_slots;
+        k.nr = p.N / best_d;
+        k.flags = 1;
+        k.cmask = 0;
+    }
+#ifdef SVLA_ASM_DEBUG
     if (getenv("SVLA_NT_AS_DBGBUF")) k.bits = (const void*)strtoull(getenv("SVLA_NT_AS_DBGBUF"), nullptr, 16);      // timing builds of tools/time_nt_as.py
-    gemm_log(name, npanels * 256, p.N, p.K);
-    const int rc = svla_asm_launch(name, &k, sizeof(k), k.grid, 256, stream);
+#endif
+    gemm_log(name, npanels * 256, p.N, p.K, (p.bits_in || p.bits_out) ? p.N / 8 : 0);
+    const int rc = svla_asm_launch2(name, &k, sizeof(k), k.grid, grid_y, 256, stream);
     if (rc) return rc;
     const int tail = p.M - npanels * 256;
     if (tail > 0) {
@@ -1058,23 +1142,22 @@ static int nt_os_try(const GemmNtArgs& p, hipStream_t stream) {
     if ((long)mtiles * ntn < 1024 && g_force_small_tile != 2) return NT_AS_NOT_TAKEN;      // fewer than four tiles per CU: the two-workgroup-per-CU tile kernel balances better
     if (mtiles < 1) return NT_AS_NOT_TAKEN;
     const char* name = p.bias ? (p.residual ? "svla_nt_os_br" : "svla_nt_os_b") : (p.residual ? "svla_nt_os_r" : "svla_nt_os_p");
+#ifdef SVLA_ASM_DEBUG      // timing-only builds of tools/var_nt_os.py: svla_nt_os_r_<variant>
     static char dbg_name[96];
-    if (getenv("SVLA_NT_OS_VARIANT")) {      // timing-only builds of tools/var_nt_os.py: svla_nt_os_r_<variant>
+    if (getenv("SVLA_NT_OS_VARIANT")) {
         snprintf(dbg_name, sizeof(dbg_name), "%s_%s", name, getenv("SVLA_NT_OS_VARIANT"));
         name = dbg_name;
     }
+#endif
     if (!svla_asm_has(name)) return NT_AS_NOT_TAKEN;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        HIP_CHECK_RET(hipGetDevice(&dev));
-        HIP_CHECK_RET(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    const GemmGlobals* gg = nullptr;
+    { const int rc = gemm_globals(stream, &gg); if (rc) return rc; }
+    const int n_cu = gg->n_cu;
     NtOsKarg k;
     memset(&k, 0, sizeof(k));
     k.A = p.A; k.lda = p.lda; k.B = p.B; k.ldb = p.ldb; k.bias = p.bias; k.res = p.residual; k.ldr = p.ldr; k.C = p.C; k.ldc = p.ldc;
     k.M = mtiles * 256; k.N = p.N; k.K = p.K; k.ntn = ntn; k.ntiles = mtiles * ntn; k.grid = k.ntiles < n_cu ? k.ntiles : n_cu;
-    gemm_log(name, k.M, p.N, p.K);
+    gemm_log(name, k.M, p.N, p.K, p.residual ? 2 * p.N : 0);
     const int rc = svla_asm_launch(name, &k, sizeof(k), k.grid, 256, stream);
     if (rc) return rc;
     const int tail = p.M - mtiles * 256;
@@ -1135,11 +1218,12 @@ extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, lon
             if (n_cu < 8) n_cu = 8;
         }
         const int ntiles = ((M + 255) / 256) * ((N + 255) / 256);
-        gemm_log(nt_use_8p(p) ? "gemm_nt8p_bf16_kernel" : "gemm_nt256k64_bf16_kernel", M, N, K);
+        gemm_log(nt_use_8p(p) ? "gemm_nt8p_bf16_kernel" : "gemm_nt256k64_bf16_kernel", M, N, K, (p.residual ? 2 * N : 0) + ((p.bits_in || p.bits_out) ? N / 8 : 0) + (p.relu_mask ? 2 * N : 0));
         int grid = n_cu;                       // persistent: one 512-thread workgroup (160 KiB LDS) per CU
         while (grid > 8 && (grid / 8) * 8 > ntiles) grid -= 8;
         return launch_nt256(p, grid, (hipStream_t)stream);
     }
+    gemm_log("gemm_nt_bf16_kernel", M, N, K, 0, false);
     const int mt = (M + BM - 1) / BM, nt = N / BN;
     const size_t lds = BM * (BN + 4) * sizeof(float);  // 66 KiB: max(NST operand stages 64 KiB, fp32 epilogue tile)
     static bool attr_set = false;

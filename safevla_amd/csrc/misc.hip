@@ -141,7 +141,10 @@ __global__ void decoder_embed_bwd_kernel(const bf16_t* __restrict__ dout, const 
     const int lane = threadIdx.x & 63;
     const int nw = (gridDim.x * blockDim.x) >> 6;
     auto add = [&](int idx, float v) {
-        if constexpr (DET) atomicAdd(&tab[idx], det_fixed(v)); else atomicAdd(&tab[idx], v);
+        if constexpr (DET) {
+            if (fabsf(v) < DET_PARTIAL_MAX) atomicAdd(&tab[idx], det_fixed(v));      // < 8192 rows per block: the table cannot wrap
+            else atomicAdd(idx < (n_actions + 2) * 512 ? &d_act_tab[idx] : &d_hand_tab[idx - (n_actions + 2) * 512], v);      // NaN / Inf / huge: straight to fp32, visible
+        } else atomicAdd(&tab[idx], v);
     };
     for (int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wave < T * B; wave += nw) {
         const int t = wave / B, b = wave % B;

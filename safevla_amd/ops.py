@@ -308,6 +308,16 @@ def gemm_force_small_tile(on):
     lib().call("svla_gemm_force_small_tile", int(on))
 
 
+def gemm_last_kernel():
+    """(kernel name, (M, N, K) as dispatched) of the last big-GEMM launch of this process (svla_gemm_last_kernel): kernel-choice tests."""
+    import ctypes
+
+    buf = ctypes.create_string_buffer(96)
+    mnk = (ctypes.c_int * 3)()
+    lib().call("svla_gemm_last_kernel", ctypes.cast(buf, ctypes.c_void_p), 96, ctypes.cast(mnk, ctypes.c_void_p))
+    return buf.value.decode(), tuple(mnk)
+
+
 def attn_bwd_two_pass(on) -> None:
     """True: the dQ + dK/dV kernel pair instead of the single-pass attention backward (A/B and tests)."""
     lib().call("svla_attn_bwd_two_pass", int(bool(on)))
@@ -382,7 +392,7 @@ def det_active() -> bool:
 
 
 def det_finalize(f32: torch.Tensor, shadow: torch.Tensor) -> None:
-    """f32 += shadow * 2^-40; shadow = 0 (svla_det_finalize), on the current stream."""
+    """f32 += shadow * 2^-52; shadow = 0 (svla_det_finalize), on the current stream."""
     lib().call("svla_det_finalize", _p(f32), _p(shadow), f32.numel(), _stream())
 
 

@@ -11,9 +11,6 @@ import pytest
 from safevla_amd.asmgen import nt_as_gen as G
 from safevla_amd.asmgen.amdasm import Emu, bf16_to_f32, f32_to_bf16_rne
 
-K = 512
-
-
 def _bf16(x):
     return f32_to_bf16_rne(np.asarray(x, dtype=np.float32)).astype(np.uint16)
 
@@ -41,9 +38,11 @@ def _bits_pack(pos, N):
     return np.ascontiguousarray(b.transpose(0, 2, 1, 3)).reshape(-1)
 
 
-def run_kernel(flavour, M, N, grid, order=None, seed=0, alpha=1.0, key=0x1234567, p_drop=0.1, row_mult=1, gen_kw=None):
+def run_kernel(flavour, M, N, grid, order=None, seed=0, alpha=1.0, key=0x1234567, p_drop=0.1, row_mult=1, gen_kw=None, nsplit=1, flags=0, K=512):
+    """grid workgroups in x (panel slots) times nsplit in y (n-ranges of N / nsplit columns: the mid-M launches)"""
     g = G.NtAsGen(name="t", **dict(G.FLAVOURS[flavour], **(gen_kw or {})))
     g.build()
+    assert g.K == K
     rs = np.random.RandomState(seed)
     X = _bf16(rs.standard_normal((M, K)))
     W = _bf16(rs.standard_normal((N, K)) * 0.05)
@@ -55,8 +54,8 @@ def run_kernel(flavour, M, N, grid, order=None, seed=0, alpha=1.0, key=0x1234567
     bits = _bits_pack(bits_in_bool, N) if g.bits_in else np.zeros(M * N // 8, dtype=np.uint8)
     npanels = M // 256
     q = max(N // 256, 1)
-    cmask = (1 << (q.bit_length() - 1)) - 1
-    for wg in range(min(grid, npanels)):
+    cmask = 0 if flags & 1 else (1 << (q.bit_length() - 1)) - 1
+    for wg, wy in [(x, y) for x in range(min(grid, npanels)) for y in range(nsplit)]:
         emu = Emu(g.p)
         aX, aW, aB, aC, aBits = emu.alloc(X), emu.alloc(W), emu.alloc(bias), emu.alloc(C, writable=True), emu.alloc(bits, writable=True)
         ka = bytearray(G.KARG_BYTES)
@@ -67,7 +66,8 @@ def run_kernel(flavour, M, N, grid, order=None, seed=0, alpha=1.0, key=0x1234567
         put("C", "<Q", aC); put("ldc", "<q", N); put("cmask", "<i", cmask); put("N", "<i", N); put("alpha", "<f", alpha)
         put("npanels", "<i", npanels); put("grid", "<i", grid); put("bits", "<Q", aBits)
         put("key", "<I", key); put("thr", "<I", thr); put("scale", "<f", float(scale)); put("row_mult", "<i", row_mult)
-        emu.run(ka, wg, order=order)
+        put("nr", "<i", N // nsplit); put("flags", "<i", flags)
+        emu.run(ka, wg, order=order, wg_id_y=wy)
     acc = (bf16_to_f32(X).astype(np.float64) @ bf16_to_f32(W).astype(np.float64).T).astype(np.float32)
     out = bf16_to_f32(C)
     if g.bits_in:
@@ -112,6 +112,46 @@ def test_nt_as_relu_dropout_signbits_matches_the_dropout_counter():
     assert (bits == _bits_pack(out > 0, 512)).all()
     kept = _drop_keep(512, 512, 0x1234567, int(0.1 * 65536 + 0.5), 3)
     assert (out[~kept] == 0).all() and 0.85 < kept.mean() < 0.95
+
+
+def test_nt_as_bias_n_range_split_mid_m():
+    """mid-M launches: grid (panel slots, nsplit), workgroup_id_y sweeps its own n-range of N / nsplit columns, no phases"""
+    out, ref, _, _ = run_kernel("f0", 512, 512, 2, nsplit=2, flags=1)
+    check(out, ref)
+    out, ref, _, _ = run_kernel("f0", 256, 1024, 1, nsplit=4, flags=1, order=[2, 0, 3, 1])
+    check(out, ref)
+
+
+def test_nt_as_no_phase_persistent_two_panels():
+    out, ref, _, _ = run_kernel("f0", 512, 256, 1, flags=1)      # one workgroup, two panels, every wave switches in the same step
+    check(out, ref)
+
+
+def test_nt_as_dropout_signbits_n_range_split_keeps_the_global_counter_and_bit_layout():
+    out, ref, bits, _ = run_kernel("f1d", 256, 512, 1, nsplit=2, flags=1, row_mult=3)
+    check(out, ref)
+    assert (bits == _bits_pack(out > 0, 512)).all()
+    kept = _drop_keep(256, 512, 0x1234567, int(0.1 * 65536 + 0.5), 3)
+    assert (out[~kept] == 0).all()
+
+
+def test_nt_as_signbit_mask_n_range_split():
+    out, ref, _, _ = run_kernel("f3", 256, 512, 1, nsplit=2, flags=1, alpha=1.0 / 0.9)
+    check(out, ref)
+
+
+def test_nt_as_bias_n_384_does_not_read_past_the_bias():
+    """N % 256 == 128: the bias table is loaded in 1-KiB chunks; the last chunk must be clamped by the descriptor"""
+    out, ref, _, _ = run_kernel("f0", 256, 384, 1)
+    check(out, ref)
+
+
+def test_nt_as_k384_bias():
+    """K = 384 (ViT-S width): 24 k-steps, 768-byte W rows fetched by 48 DMA lanes into the 1-KiB LDS pitch"""
+    out, ref, _, _ = run_kernel("k384_f0", 512, 384, 1, K=384)
+    check(out, ref)
+    out, ref, _, _ = run_kernel("k384_f0", 256, 1152, 1, K=384, nsplit=3, flags=1, order=[3, 2, 1, 0])
+    check(out, ref)
 
 
 def test_nt_as_signbit_mask_alpha():

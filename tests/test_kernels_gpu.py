@@ -723,6 +723,10 @@ def test_gemm_nt_assembly_kernels(ops, N, flavour):
                 k2["relu_bits_out"] = torch.zeros(ops.relu_bits_bytes(M, N), device=DEV, dtype=torch.uint8)
             y = ops.gemm_nt(A, B, M, N, K, **k2)
             torch.cuda.synchronize()
+            # the dispatch itself is asserted: assembly on -> the A-stationary flavour of this epilogue, off -> a HIP kernel
+            name, mnk = ops.gemm_last_kernel()
+            want_name = {"bias": "svla_nt_as_f0", "relu_bits": "svla_nt_as_f1", "relu_drop_bits": "svla_nt_as_f1d", "bits_in": "svla_nt_as_f3"}[flavour]
+            assert (name == want_name and mnk == (M // 256 * 256, N, K)) if not off else name.startswith("gemm_nt"), (off, name, mnk)
             outs.setdefault(off, []).append((y, k2.get("relu_bits_out")))
     finally:
         _asm_off(ops, False)
@@ -742,6 +746,68 @@ def test_gemm_nt_assembly_kernels(ops, N, flavour):
         finally:
             _asm_off(ops, False)
         assert torch.equal(chk, b1), "sign bits are not (output > 0)"
+
+
+@pytest.mark.parametrize("M,N,K,flavour", [(256 * 45 + 64, 1536, 512, "bias"), (256 * 233, 2048, 512, "relu_drop_bits"), (256 * 60 + 5, 512, 512, "bits_in"),
+                                             (256 * 30, 1024, 512, "relu_bits"), (55424, 1152, 384, "bias"), (55424, 384, 384, "bias")])
+def test_gemm_nt_assembly_mid_m_launches(ops, M, N, K, flavour):
+    """Mid-M launches of the A-stationary kernels (round 5: an acting step's 45 row panels, the 233 of the batch-256 probe, the ViT-S/14's 216 at K = 384):
+    grid = panel slots x n-ranges (workgroup_id_y sweeps its own N / nsplit columns), no phases.  Forced on (hook 2) so that every flavour is exercised
+    at sizes the cost model would leave to the tile kernels; against the HIP kernels (at most one bf16 rounding apart), fp32 torch, run to run."""
+    from safevla_amd._lib import lib
+    p = 0.1
+    A = bf(rnd(M, K, seed=61)).to(DEV).bfloat16(); B = bf(rnd(N, K, seed=62, scale=0.05)).to(DEV).bfloat16(); bias = rnd(N, seed=63, scale=0.5).to(DEV)
+    acc = A.float() @ B.float().t()
+    if flavour == "bias":
+        kw, want = dict(bias=bias), acc + bias
+    elif flavour in ("relu_bits", "relu_drop_bits"):
+        kw, want = dict(bias=bias, act=ops.ACT_RELU), torch.relu(acc + bias)
+        if flavour == "relu_drop_bits":
+            kw["drop"] = ops.Dropout(seed=99, stream=3, p=p)
+            idx = (np.arange(M, dtype=np.uint64)[:, None] * np.uint64(N)) + np.arange(N, dtype=np.uint64)[None, :]
+            want = want * _keep_np(99, 3, p, idx).float().to(DEV) / (1 - p)
+    else:
+        mask = torch.rand(M, N, device=DEV) < 0.6
+        bits = torch.zeros(ops.relu_bits_bytes(M, N), device=DEV, dtype=torch.uint8)
+        _asm_off(ops, True)
+        ops.gemm_nt(torch.where(mask, 1.0, -1.0).bfloat16(), torch.eye(N, device=DEV).bfloat16(), M, N, N, act=ops.ACT_RELU, relu_bits_out=bits)
+        kw, want = dict(relu_bits=bits, alpha=1 / (1 - p)), torch.where(mask, acc / (1 - p), torch.zeros((), device=DEV))
+    want_name = {"bias": "svla_nt_as_f0" if K == 512 else "svla_nt_as_k384_f0", "relu_bits": "svla_nt_as_f1", "relu_drop_bits": "svla_nt_as_f1d", "bits_in": "svla_nt_as_f3"}[flavour]
+    outs = []
+    try:
+        for mode in ("hip", "asm", "asm"):
+            if mode == "hip":
+                _asm_off(ops, True)
+            else:
+                lib().call("svla_gemm_force_small_tile", 2)
+            k2 = dict(kw)
+            if "relu" in flavour:
+                k2["relu_bits_out"] = torch.zeros(ops.relu_bits_bytes(M, N), device=DEV, dtype=torch.uint8)
+            y = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+            ops.gemm_nt(A, B, M, N, K, out=y, **k2)
+            torch.cuda.synchronize()
+            name, mnk = ops.gemm_last_kernel()
+            assert (name == want_name and mnk == (M // 256 * 256, N, K)) if mode == "asm" else name.startswith("gemm_nt"), (mode, name, mnk)
+            outs.append((y, k2.get("relu_bits_out")))
+    finally:
+        _asm_off(ops, False)
+    (hip, hb), (a1, b1), (a2, b2) = outs
+    assert torch.equal(a1.view(torch.int16), a2.view(torch.int16)), "assembly kernel differs from run to run"
+    close(a1.float(), want, 1e-2, 2e-2, f"mid-M asm {flavour} vs fp32 torch")
+    d = (a1.float() - hip.float()).abs()
+    assert (d <= hip.float().abs() * 2.0 ** -7 + 1e-6).all(), f"asm vs HIP kernel: max {d.max().item()}"
+    if b1 is not None:
+        assert torch.equal(b1, b2) and (b1 != hb).float().mean().item() < 1e-4
+
+
+def test_gemm_nt_mid_m_cost_model_dispatch(ops):
+    """Normal dispatch (no hook): the batch-256 probe's 233 panels x N = 1536 and the ViT's qkv projection go to the assembly kernels, an acting step's
+    45 panels x N = 512 stay on the tile kernel (profiles/r05_midm_sweep.txt)."""
+    for (M, N, K, want) in [(59648, 1536, 512, "svla_nt_as_f0"), (55424, 1152, 384, "svla_nt_as_k384_f0"), (11584, 512, 512, "gemm_nt_bf16_kernel")]:
+        A = torch.zeros(M, K, device=DEV, dtype=torch.bfloat16); B = torch.zeros(N, K, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(A, B, M, N, K, bias=torch.zeros(N, device=DEV))
+        torch.cuda.synchronize()
+        assert ops.gemm_last_kernel()[0] == want, (M, N, K, ops.gemm_last_kernel())
 
 
 @pytest.mark.parametrize("N,K", [(512, 2048), (512, 1536), (1024, 384), (512, 512)])
@@ -769,6 +835,9 @@ def test_gemm_nt_output_stationary_assembly_kernels(ops, N, K, flavour):
             y = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
             ops.gemm_nt(A, B, M, N, K, out=y, **kw)
             torch.cuda.synchronize()
+            name, mnk = ops.gemm_last_kernel()
+            want_name = "svla_nt_os_" + {"plain": "p", "bias": "b", "res": "r", "bias_res": "br"}[flavour]
+            assert (name == want_name and mnk == (M // 256 * 256, N, K)) if not off else name.startswith("gemm_nt"), (off, name, mnk)
             outs.setdefault(off, []).append(y)
     finally:
         _asm_off(ops, False)
@@ -800,6 +869,7 @@ def test_gemm_tn_assembly_kernel(ops, N, K):
             dW, db = w0.clone(), b0.clone()
             ops.gemm_tn_acc(dY, X, dW, M, N, K, db=db)
             torch.cuda.synchronize()
+            assert ops.gemm_last_kernel()[0] == ("gemm_tn8p_bf16_kernel" if off else "svla_tn_os"), (off, ops.gemm_last_kernel())
             res[off] = (dW, db)
     finally:
         _asm_off(ops, False)

@@ -37,12 +37,12 @@ def pmc_shapes(fdb, wdb, log, out):
     f, w = rows(fdb, "FETCH_SIZE"), rows(wdb, "WRITE_SIZE")
     logs = collections.defaultdict(list)
     for line in open(log):
-        k, M, N, K = line.split()
-        logs[k].append((int(M), int(N), int(K)))
+        k, M, N, K, *x = line.split()
+        logs[k].append((int(M), int(N), int(K), int(x[0]) if x else 0))      # 5th column: bytes per row beyond A and C (residual, sign bits)
     res = {"_method": "rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2), --kernel-trace only, on `python bench.py --steps 1 --warmup 0 "
                       "--no-cpu-baseline --no-roofline --no-secondary` with SVLA_GEMM_LOG: the i-th dispatch of a kernel name is the i-th logged launch of that "
                       "name; counters are KiB; gfx950: FETCH_SIZE reports half of a wide (16 B/lane) coalesced stream (MI355X_MICROARCH.md, HBM) => fetch bytes = "
-                      "2*FETCH_SIZE*1024, WRITE_SIZE as is.  algorithmic_bytes: NT 2*(M*K + M*N) [+ residual / sign bits], TN 2*M*(N + K).",
+                      "2*FETCH_SIZE*1024, WRITE_SIZE as is.  algorithmic_bytes: NT 2*(M*K + M*N) + M*extra_bytes_per_row (residual / ReLU-mask rows 2 N, sign bits N/8: counted since round 5), TN 2*M*(N + K).",
            "kernel_sources_sha256": _sources_sha(), "shapes": []}
     for k, shp in logs.items():
         fk, wk = f.get(k, []), w.get(k, [])
@@ -50,12 +50,12 @@ def pmc_shapes(fdb, wdb, log, out):
             res["shapes"].append({"kernel": k, "error": f"{len(shp)} logged launches vs {len(fk)} / {len(wk)} counter rows"})
             continue
         agg = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
-        for (M, N, K), (fv, fd), (wv, wd) in zip(shp, fk, wk):
-            a = agg[(M, N, K)]
+        for (M, N, K, X), (fv, fd), (wv, wd) in zip(shp, fk, wk):
+            a = agg[(M, N, K, X)]
             a[0] += 1; a[1] += 2 * fv * 1024; a[2] += wv * 1024; a[3] += fd
-        for (M, N, K), (n, fb, wb, dur) in sorted(agg.items(), key=lambda kv: -kv[1][3]):
-            alg = 2 * M * (N + K) if "tn" in k else 2 * (M * K + M * N)
-            res["shapes"].append({"kernel": k, "M": M, "N": N, "K": K, "launches": n, "fetch_bytes_per_launch": fb / n, "write_bytes_per_launch": wb / n,
+        for (M, N, K, X), (n, fb, wb, dur) in sorted(agg.items(), key=lambda kv: -kv[1][3]):
+            alg = 2 * M * (N + K) if "tn" in k else 2 * (M * K + M * N) + M * X
+            res["shapes"].append({"kernel": k, "M": M, "N": N, "K": K, "extra_bytes_per_row": X, "launches": n, "fetch_bytes_per_launch": fb / n, "write_bytes_per_launch": wb / n,
                                   "hbm_bytes_per_launch": (fb + wb) / n, "algorithmic_bytes_per_launch": alg, "ratio_to_algorithmic": round((fb + wb) / n / alg, 3),
                                   "avg_duration_us_profiled": dur / n / 1e3, "total_ms_profiled": dur / 1e6})
     res["shapes"].sort(key=lambda r: -r.get("total_ms_profiled", 0))
@@ -76,7 +76,7 @@ def pmc(fdb, wdb, out):
                       "gfx950: FETCH_SIZE reports half of a wide (16 B/lane) coalesced stream (MI355X_MICROARCH.md, HBM) => fetch bytes = "
                       "2*FETCH_SIZE*1024; WRITE_SIZE as is", "kernel_sources_sha256": _sources_sha(), "kernels": {}}
     for n in sorted(set(f) | set(w)):
-        if any(k in n for k in ("gemm", "attn", "norm", "colsum", "adam")):
+        if any(k in n for k in ("gemm", "attn", "norm", "colsum", "adam", "svla_", "patchify", "vit_tokens", "adaptive_pool")):
             fv, fc, fd = f.get(n, (0, 0, 0)); wv, wc, wd = w.get(n, (0, 0, 0))
             res["kernels"][n.split("(")[0]] = {"launches": fc, "fetch_bytes_per_launch": 2 * fv * 1024, "write_bytes_per_launch": wv * 1024,
                                                "hbm_bytes_per_launch": 2 * fv * 1024 + wv * 1024, "avg_duration_us_profiled": fd / 1e3}
