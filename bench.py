@@ -156,7 +156,10 @@ def north_star_probe(model, dev, rows_T=32, rows_B=8, L=64):
         model.zero_grad()
         eng._accumulate(batch, R, 0.1, cache_key="probe")     # like the epochs of one update: the first pass records, the others replay
 
-    once()
+    from safevla_amd import ops
+    with GemmTimer(ops) as gt:      # the recording pass: every MFMA launch goes through the Python bindings once -> the FLOPs this engine EXECUTES
+        once()
+    executed = sum(v["flops"] for v in gt.summary().values())
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3):
@@ -165,9 +168,13 @@ def north_star_probe(model, dev, rows_T=32, rows_B=8, L=64):
     ms = (time.perf_counter() - t0) / 3 * 1e3
     U = int(st.observations["goal_token_ids"][:rows_T].reshape(R, -1).unique(dim=0).shape[0])
     fl = flops_per_update(R, 169 + L, L, U, 1)
-    return {"rows": R, "goal_tokens": L, "ms_fwd_bwd_3_towers": round(ms, 2), "algorithmic_tflop": round(fl / 1e12, 2),
-            "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 1), "frac_of_bf16_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-            "note": "north_star secondary target (>= 0.70) -- small batch: 256 rows x 233 tokens"}
+    return {"rows": R, "goal_tokens": L, "ms_fwd_bwd_3_towers": round(ms, 2),
+            "executed_mfma_tflop": round(executed / 1e12, 2), "executed_tflops": round(executed / (ms * 1e-3) / 1e12, 1),
+            "frac_of_bf16_mfma_peak": round(executed / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "reference_schedule_tflop": round(fl / 1e12, 2), "reference_schedule_frac_of_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "note": "north_star secondary target (>= 0.70) -- small batch: 256 rows x 233 tokens.  frac_of_bf16_mfma_peak divides the MFMA FLOPs the engine "
+                    "EXECUTES (GEMMs + attention, counted launch by launch) by the time; reference_schedule_* divides SURVEY 8(d)'s FLOPs of the reference's "
+                    "schedule (which runs the whole last fusion layer and T5 per row) -- VERDICT r4"}
 
 
 def _oracle_epochs(T, B, L, train_mode, device="cpu", epochs=1, autocast=False):
@@ -261,6 +268,59 @@ def kernel_sources_sha():
     return h.hexdigest()
 
 
+def _stamped_profile(suffix):
+    """newest profiles/*<suffix> measured on THIS build's kernel sources (hash-stamped), or (None, None)"""
+    for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(suffix)), reverse=True):
+        try:
+            doc = json.load(open(os.path.join(ROOT, "profiles", cand)))
+            if doc.get("kernel_sources_sha256") == kernel_sources_sha():
+                return doc, cand
+        except Exception:
+            pass
+    return None, None
+
+
+def family_roofs(allk, ms):
+    """Both roofs per kernel family (d = 512 sits at the ridge, 165-410 FLOP/B against 312).  MFMA side: live HIP-event FLOP/s of this
+    run.  HBM side: the family's FLOP-per-HBM-byte from the rocprofv3 counter passes of the same command on the same kernel sources (profiles/, hash-stamped;
+    the profiled run holds one update + the rollout's forward pass, so the intensity -- not the absolute byte count -- is what carries over), applied to the
+    live FLOP/s; attention / LayerNorm / whole-run figures are the profile's own bytes over the profile's own durations."""
+    shp, src_s = _stamped_profile("_pmc_hbm_traffic_by_shape.json")
+    ker, src_k = _stamped_profile("_pmc_hbm_traffic.json")
+    out = {"_sources": {"by_shape": src_s, "by_kernel": src_k}}
+    for fam, key, pick in (("nt_gemms", "gemm_nt256", lambda k: "tn" not in k), ("tn_gemms", "gemm_tn", lambda k: "tn" in k)):
+        v = allk.get(key)
+        if not v or not v["launches"]:
+            continue
+        row = {"achieved_tflops": round(v["tflops"], 1), "mfma_frac": round(v["tflops"] / PEAK_BF16_TFLOPS, 4), "share_of_update": round(v["total_s"] / (ms * 1e-3), 3)}
+        if shp is not None:
+            rows = [r for r in shp["shapes"] if "error" not in r and pick(r["kernel"]) and r["M"] >= 65536]
+            fl = sum(2.0 * r["M"] * r["N"] * r["K"] * r["launches"] for r in rows)
+            by = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows)
+            alg = sum(r["algorithmic_bytes_per_launch"] * r["launches"] for r in rows)
+            if by > 0:
+                row.update(flop_per_hbm_byte=round(fl / by, 1), hbm_TBps=round(v["tflops"] / (fl / by), 3), hbm_frac=round(v["tflops"] / (fl / by) / PEAK_HBM_TBPS, 4),
+                           traffic_over_algorithmic=round(by / alg, 3))
+        out[fam] = row
+    for fam, key in (("attn_fwd", "attn_fwd"), ("attn_bwd", "attn_bwd")):
+        v = allk.get(key)
+        if v and v["launches"]:
+            out[fam] = {"achieved_tflops": round(v["tflops"], 1), "mfma_frac": round(v["tflops"] / PEAK_BF16_TFLOPS, 4), "share_of_update": round(v["total_s"] / (ms * 1e-3), 3),
+                        "avg_launch_ms": round(v["avg_ms"], 4)}
+    if ker is not None:
+        tot_b = tot_t = 0.0
+        for name, r in ker["kernels"].items():
+            tot_b += r["hbm_bytes_per_launch"] * r["launches"]
+            tot_t += r["avg_duration_us_profiled"] * 1e-6 * r["launches"]
+            for fam, pat in (("attn_fwd", "attn_fwd_persist"), ("attn_bwd", "attn_bwd_fused"), ("norm_fwd", "norm_fwd_kernel"), ("norm_bwd", "norm_bwd_kernel")):
+                if pat in name and r["launches"] >= 8 and r["avg_duration_us_profiled"] > 200:
+                    tb = r["hbm_bytes_per_launch"] / (r["avg_duration_us_profiled"] * 1e-6) / 1e12
+                    out.setdefault(fam, {}).update(hbm_TBps_profiled=round(tb, 3), hbm_frac=round(tb / PEAK_HBM_TBPS, 4), hbm_GB_per_launch=round(r["hbm_bytes_per_launch"] / 1e9, 3))
+        if tot_t > 0:
+            out["whole_profiled_run"] = {"hbm_TB": round(tot_b / 1e12, 2), "kernel_s": round(tot_t, 3), "hbm_TBps": round(tot_b / tot_t / 1e12, 3), "hbm_frac": round(tot_b / tot_t / 1e12 / PEAK_HBM_TBPS, 4)}
+    return out
+
+
 def parity_gate(dev, T=8, B=4):
     """the parity gate of the same run.  One seeded (T x B)-row minibatch through the CPU oracle (the checker) and through
     the HIP path with the same weights, eval mode: the fp32 verification mode must agree at fp32 tolerance (1e-4), the bf16 product path
@@ -350,6 +410,7 @@ def timed_updates(eng, st, nxt, ep, steps, warmup, world, dev):
     parallel.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    timed_updates.per_rank_ms = [x / steps * 1e3 for x in parallel.gather_floats(dt, dev)]      # every rank's own clock over the same K steps
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -402,6 +463,7 @@ def main():
                     "the default bench line is measured with the fp32 atomics")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-cpu-c1", action="store_true", help="skip the full CPU timing of BASELINE configs[0] inside cpu_baseline (~1 min of host time)")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (the reference trains with the policy in train() mode: default here too)")
     ap.add_argument("--cpu-c1-full", action="store_true", help="only time BASELINE configs[0] (4 envs x 32 steps) IN FULL on the host CPU and exit")
@@ -428,6 +490,11 @@ def main():
     model.train(not args.eval_mode)
     if world > 1:                    # ... and made certain by a broadcast of every parameter and buffer
         parallel.broadcast_model_(model)
+    # N > 1: the update's collectives on sentinels, checked on every rank BEFORE anything is timed (one async all-reduce per tower range of the
+    # gradient arena, the cost reduction, the rank count) -- a mis-wired RCCL run fails here, not in the numbers
+    pre = parallel.preflight(model, dev)
+    if pre["ranks"] != max(1, args.gpus):
+        raise SystemExit(f"bench.py --gpus {args.gpus}: the collective pre-flight saw {pre['ranks']} rank(s)")
     torch.manual_seed(1234 + rank)   # per-rank streams from here on (sampling, synthetic environments)
     T, B = args.T, args.envs_per_gpu
     if args.scaling == "strong":      # fixed total work: this rank's share of the global env list (uneven shards are legal)
@@ -452,6 +519,7 @@ def main():
         cfg = PPOLagConfig(env_chunk=chunk, cost_limit=args.cost_limit, deterministic=args.deterministic)
         eng = PPOLagEngine(model, cfg)
         ms, info, step = timed_updates(eng, st, nxt, ep, args.steps, args.warmup, world, dev)
+    per_rank_ms = list(timed_updates.per_rank_ms)
     env_steps = T * (args.global_envs if args.scaling == "strong" else B * world)
     S, R = 169 + args.L, T * B
     U = int(st.observations["goal_token_ids"][:T].reshape(R, -1).unique(dim=0).shape[0])
@@ -489,6 +557,11 @@ def main():
                 break
             except Exception:
                 pass
+        families = None
+        try:
+            families = family_roofs(allk, ms)
+        except Exception as e:
+            families = {"error": repr(e)[:200]}
         roof = {"bound": "mfma", "kernel": "svla_gemm_nt_bf16, row-streaming shapes: svla_nt_as_* (generated gfx950 assembly, A panel stationary in 256 AGPRs per wave, K = 512) + "
                                            "gemm_nt8p_bf16_kernel (HIP, persistent 256x256x64 tile, K > 512 / residual epilogues); all launches of one update, HIP events", "achieved": round(g["tflops"], 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(g["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
@@ -499,6 +572,7 @@ def main():
                 "share_of_update": round(g["total_s"] / (ms * 1e-3), 3),
                 "other_mfma_kernels": {k: {"achieved_tflops": round(v["tflops"], 1), "launches": v["launches"], "avg_launch_ms": round(v["avg_ms"], 4),
                                            "share_of_update": round(v["total_s"] / (ms * 1e-3), 3)} for k, v in allk.items() if k != "gemm_nt256"},
+                "families": families,
                 "executed_mfma_tflop_per_update": round(executed / 1e12, 1),
                 "executed_mfma_tflops_sustained": round(executed / (ms * 1e-3) / 1e12, 1),
                 "executed_mfma_frac_of_peak": round(executed / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
@@ -539,6 +613,11 @@ def main():
             cpu["single_thread"] = {"value": one["value"], "unit": one["unit"], "sample": one["sample"]}
         except Exception as e:
             cpu = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(e)[:200]}
+        if not args.no_cpu_c1:
+            try:         # BASELINE configs[0] (the reference's own CPU-runnable case) timed IN FULL on the host cores, in the same run (~1 min)
+                cpu["c1_full"] = cpu_c1_full(not args.eval_mode)
+            except Exception as e:
+                cpu["c1_full"] = {"error": repr(e)[:200]}
         try:
             cpu["stock_pytorch_rocm"] = stock_rocm_baseline(dev, L=args.L, train_mode=not args.eval_mode)
         except Exception as e:          # the intermediate baseline must never take the bench line down
@@ -550,6 +629,7 @@ def main():
     if rank == 0:
         out = {"metric": "env-steps/sec through PPO-Lagrangian update", "value": round(env_steps / (ms * 1e-3), 1), "unit": "env-steps/s",
                "n_gpus": world, "rccl_ranks": (torch.distributed.get_world_size() if world > 1 else 1),
+               "collective_preflight": pre, "ms_per_step_per_rank": {"min": round(min(per_rank_ms), 2), "max": round(max(per_rank_ms), 2)},
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
                "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": (f"C4: {args.task}, {args.global_envs} envs sharded over {world} GPU(s) ({B} on rank 0) x T={T}-step rollout "
@@ -566,6 +646,10 @@ def main():
                        "layer only for the consumed token, T5 once per unique goal) -- see roofline.executed_mfma_*",
                "loss": {k: (round(v, 5) if isinstance(v, float) else v) for k, v in info.items()},
                "roofline": roof, "cpu_baseline": cpu, "acting": acting, "north_star_batch256": ns, "secondary": secondary}
+        for sc in (secondary or []):      # the reference-faithful noise statistics right beside the headline
+            if isinstance(sc, dict) and "reference-faithful" in sc.get("workload", ""):
+                out["value_with_reference_faithful_t5_dropout"] = {"value": sc.get("env_steps_per_s"), "ms_per_update": sc.get("ms_per_update"),
+                                                                   "note": "the headline workload with one T5 dropout realisation per (t, b) row and tower, as the reference draws it; the headline draws one per unique goal and pass (SURVEY section 7 permits the de-duplication)"}
         pg = (cpu or {}).get("parity_gate")
         if pg is not None:      # the gate ran: a regression against the CPU oracle (or an exception inside the gate) fails the run
             out["parity_ok"] = bool("error" not in pg and pg.get("fp32", {}).get("passed") and pg.get("bf16", {}).get("passed"))

@@ -238,10 +238,12 @@ int svla_embed_gather_f32_bf16(const float* table, const int64_t* ids, long n, i
 
 /* ---- frozen ViT preprocessor (rollout time) ------------------------------------------------------------------- */
 /* DataAugmentationPreprocessor.process without augmentation: (x/255 - mean)/std
- * (architecture/allenact_preprocessors/dino_preprocessors.py:224-239; DINO_RGB_MEANS/STDS :42-43). */
+ * (architecture/allenact_preprocessors/dino_preprocessors.py:224-239; DINO_RGB_MEANS/STDS :42-43).  x 4-byte aligned, y 16-byte aligned
+ * (one dword of the HWC stream per lane -> one float4 per lane). */
 int svla_normalize_u8_f32(const unsigned char* x, long n, const float* mean3, const float* std3, float* y, void* stream);
 /* The same normalisation fused with the W crop [3:-3] and the 14x14/14 patch-embedding im2col of DinoViTEmbedder.forward
- * (dino_preprocessors.py:27-35): u8 HWC frames -> bf16 rows [B, gh*gw, KP], k = c*P*P + ky*P + kx, zero padded to KP. */
+ * (dino_preprocessors.py:27-35): u8 HWC frames -> bf16 rows [B, gh*gw, KP], k = c*P*P + ky*P + kx, zero padded to KP (KP % 8 == 0: every lane
+ * writes 16 bytes of an im2col row; the image rows are fetched as aligned dwords). */
 int svla_patchify_u8_bf16(const unsigned char* frames, int B, int H, int W, int crop_x, int P, int gh, int gw, int KP,
                           const float* mean3, const float* std3, svla_bf16* out, void* stream);
 /* cls token + position embedding (DINOv2 prepare_tokens [3P torch.hub facebookresearch/dinov2], dino_preprocessors.py:106);

@@ -541,6 +541,57 @@ class Prog:
     def v_max_f32(self, d, x, y):
         self._vf2("v_max_f32", d, x, y, np.maximum)
 
+    def v_med3_f32(self, d, x, y, z, neg=(0, 0, 0)):
+        """median of three fp32 (a clamp when two operands are the bounds); neg: per-source negation modifiers (the same SGPR may serve as -c and +c:
+        one constant-bus read)"""
+        def tx(o, n):
+            return ("-" if n else "") + (_txt(o) if not isinstance(o, float) else repr(o))
+
+        def fn(w):
+            vals = []
+            for o, n in zip((x, y, z), neg):
+                f = w.rd(o).view(np.float32).astype(np.float32)
+                vals.append(-f if n else f)
+            with np.errstate(all="ignore"):
+                st = np.sort(np.stack(vals), axis=0)[1]
+            w.wr(d, st.astype(np.float32).view(np.uint32))
+        for o in (x, y, z):
+            assert not isinstance(o, float) or o in (0.5, -0.5, 1.0, -1.0, 2.0, -2.0, 4.0, -4.0, 0.0), "VOP3 on gfx9 takes inline constants only"
+        self._valu(f"v_med3_f32 {_txt(d)}, {tx(x, neg[0])}, {tx(y, neg[1])}, {tx(z, neg[2])}", fn)
+
+    def _pk_f32(self, name, d, srcs, sel, f):
+        """packed fp32 (two fp32 operations per lane on 64-bit register pairs).  sel[i] = (dword of source i that feeds the LOW result, dword that feeds
+        the HIGH result): (0, 1) = the pair as it is, (0, 0) / (1, 1) = its low / high dword broadcast (op_sel / op_sel_hi) -- how one SGPR pair carries
+        two constants.  gfx9: at most one SGPR (pair) per instruction, no literals."""
+        assert d.n == 2 and all(isinstance(o, Reg) and o.n == 2 for o in srcs), "packed fp32 operands are 64-bit register pairs"
+        assert sum(1 for o in srcs if o.kind == "s") <= 1 or len({(o.kind, o.idx) for o in srcs if o.kind == "s"}) == 1, "constant bus: one SGPR pair"
+        sel = list(sel) + [(0, 1)] * (len(srcs) - len(sel))
+        op_sel, op_sel_hi = [lo for lo, _ in sel], [hi for _, hi in sel]
+        mods = ""
+        if any(op_sel):
+            mods += " op_sel:[" + ",".join(str(b) for b in op_sel) + "]"
+        if not all(op_sel_hi):
+            mods += " op_sel_hi:[" + ",".join(str(b) for b in op_sel_hi) + "]"
+
+        def fn(w):
+            out = []
+            for half in (0, 1):
+                with np.errstate(all="ignore"):
+                    args = [w.rd(o, sl[half]).view(np.float32).astype(np.float64) for o, sl in zip(srcs, sel)]
+                    out.append(f(*args).astype(np.float32).view(np.uint32))      # one rounding (the fp64 intermediate holds the product exactly)
+            w.wr(d, out[0], 0)
+            w.wr(d, out[1], 1)
+        self._valu(f"{name} {_txt(d)}, " + ", ".join(_txt(o) for o in srcs) + mods, fn)
+
+    def v_pk_mul_f32(self, d, x, y, sel=()):
+        self._pk_f32("v_pk_mul_f32", d, (x, y), sel, lambda p, q: p * q)
+
+    def v_pk_add_f32(self, d, x, y, sel=()):
+        self._pk_f32("v_pk_add_f32", d, (x, y), sel, lambda p, q: p + q)
+
+    def v_pk_fma_f32(self, d, x, y, z, sel=()):
+        self._pk_f32("v_pk_fma_f32", d, (x, y, z), sel, lambda p, q, r: p * q + r)
+
     def v_cvt_pk_bf16_f32(self, d, x, y):
         def fn(w):
             lo = f32_to_bf16_rne(w.rd(x).view(np.float32))

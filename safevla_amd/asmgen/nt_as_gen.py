@@ -30,6 +30,7 @@ whole (carry chains through SCC, M0 write + DMA).
 """
 import os as _os
 
+from . import gelu_poly
 from .amdasm import EXEC, M0, Prog, a, s, v
 
 KS_DEFAULT = 32            # k-steps of 16 (K = 512); the ViT-S flavours run K = 384 (24 k-steps: 192 of the 256 AGPRs hold A)
@@ -103,6 +104,16 @@ V_TMP = [v(244 + i) for i in range(12)]
 V_BCH = [v(220 + i) for i in range(16)]             # prologue: the bias chunks in flight (the read-back registers' space)
 
 
+# ---- GELU flavour (no dropout / sign bits: their SGPRs and temporaries are free).  Constants: SGPR pairs, two fp32 values each, picked by op_sel / op_sel_hi
+SG_PAIRS = [s(28, 2), s(30, 2), s(32, 2), s(52, 2), s(54, 2), s(92, 2), s(94, 2)]
+def SGC(i):
+    """(SGPR pair, broadcast selector) of GELU constant i: 0..9 = c0..c9, 10 = sqrt(zscale), 11 = -1, 12 = 1/2, 13 = clamp"""
+    return SG_PAIRS[i // 2], (i % 2, i % 2)
+S_GCLAMP = s(95)                      # = constant 13 as a single register (v_med3_f32)
+G_T, G_Z, G_P = [v(238, 2), v(244, 2)], [v(240, 2), v(246, 2)], [v(242, 2), v(248, 2)]      # two interleaved chains
+G_C9 = v(250, 2)                      # c9 in both halves (the Horner seed: a second SGPR operand would exceed the constant bus)
+
+
 def BW(par, mb):
     """ReLU sign-bit words of a 32-row x 64-column slab as loaded (flavour bits_in has no bias: the bias registers' space)"""
     return v(128 + (par * 2 + mb) * 2, 2)
@@ -139,8 +150,10 @@ class NtAsGen:
     DMA_END = 72       # the last LDS-DMA piece of the next tile is issued by this gap (~1.5 k cycles before the barrier)
     BAR_GAP = 119      # the barrier follows MFMA 119 (k-step 29); the last fragment reads of the tile are issued at gaps 113 / 115
 
-    def __init__(self, name="svla_nt_as_f0", relu=False, drop=False, bits_out=False, bits_in=False, cap=None, dbg="", stagger=0, epi_order=1, dma_end=None, store_nt=True, load_nt=False, xstart=0, wphases=4, xburst=2, K=512):
+    def __init__(self, name="svla_nt_as_f0", relu=False, drop=False, bits_out=False, bits_in=False, cap=None, dbg="", stagger=0, epi_order=1, dma_end=None, store_nt=True, load_nt=False, xstart=0, wphases=4, xburst=2, K=512, gelu=False):
         self.name = name
+        self.gelu = gelu          # epilogue = erf-GELU(acc + bias) as the polynomial of asmgen/gelu_poly.py (the frozen ViT's fc1)
+        assert not (gelu and (relu or drop or bits_out or bits_in))
         assert K in (384, 512)
         self.K, self.KS = K, K // 16
         if K != 512:      # the gap positions of the K = 512 schedule scaled to NG = 4 KS gaps
@@ -330,6 +343,12 @@ class NtAsGen:
             p.label("L_KEYOK")
         elif self.bits_out:
             p.s_mov_b32(S_ONE1, 0x00010001)
+        if self.gelu:
+            import math as _m
+            import struct as _st
+            cs = gelu_poly.coefs() + [_st.unpack("<f", _st.pack("<f", _m.sqrt(gelu_poly.zscale())))[0], -1.0, 0.5, gelu_poly.CLAMP]
+            for i, c in enumerate(cs):
+                p.s_mov_b32(SG_PAIRS[i // 2].sub(i % 2), float(c))
         if self.bias:
             self.bias_loads()
         # ---- phase of this wave: phi = w * NS/4 + (workgroup & cmask) dummy steps before its first panel, (3 - w) * NS/4 after its last
@@ -383,6 +402,9 @@ class NtAsGen:
         if self.bias:
             self.bias_table()
             p.s_waitcnt(lgkmcnt=0)
+        if self.gelu:           # (v250:251 are prologue temporaries up to here)
+            p.v_mov_b32(G_C9.sub(0), SG_PAIRS[4].sub(1))
+            p.v_mov_b32(G_C9.sub(1), SG_PAIRS[4].sub(1))
         if "time" in self.dbg:
             p.s_memtime(s(0, 2))
             p.s_waitcnt(lgkmcnt=0)
@@ -596,6 +618,32 @@ class NtAsGen:
                     gi = nb * 4 + rg
                     acc = ACC(st, nb, mb)
                     pk = V_PK[gi % 4]
+                    if self.gelu:
+                        # the two element pairs of the piece as two interleaved dependent chains (19 instructions each), emitted six instructions per group
+                        ins = []
+                        for ch in range(2):
+                            gX, gT, gZ, gP = acc.sub(4 * rg + 2 * ch, 2), G_T[ch], G_Z[ch], G_P[ch]
+                            seq = [lambda gX=gX, gT=gT: p.v_med3_f32(gT.sub(0), gX.sub(0), S_GCLAMP, S_GCLAMP, neg=(0, 1, 0)),
+                                   lambda gX=gX, gT=gT: p.v_med3_f32(gT.sub(1), gX.sub(1), S_GCLAMP, S_GCLAMP, neg=(0, 1, 0)),
+                                   lambda gT=gT, gZ=gZ: p.v_pk_mul_f32(gZ, gT, SGC(10)[0], sel=((0, 1), SGC(10)[1])),
+                                   lambda gZ=gZ: p.v_pk_fma_f32(gZ, gZ, gZ, SGC(11)[0], sel=((0, 1), (0, 1), SGC(11)[1])),
+                                   lambda gZ=gZ, gP=gP: p.v_pk_fma_f32(gP, gZ, G_C9, SGC(8)[0], sel=((0, 1), (0, 1), SGC(8)[1]))]
+                            for k in range(7, -1, -1):
+                                seq.append(lambda gZ=gZ, gP=gP, k=k: p.v_pk_fma_f32(gP, gP, gZ, SGC(k)[0], sel=((0, 1), (0, 1), SGC(k)[1])))
+                            seq += [lambda gT=gT, gP=gP: p.v_pk_mul_f32(gP, gP, gT),
+                                    lambda gP=gP: p.v_med3_f32(gP.sub(0), gP.sub(0), -0.5, 0.5),
+                                    lambda gP=gP: p.v_med3_f32(gP.sub(1), gP.sub(1), -0.5, 0.5),
+                                    lambda gP=gP: p.v_pk_add_f32(gP, gP, SGC(12)[0], sel=((0, 1), SGC(12)[1])),
+                                    lambda gX=gX, gP=gP: p.v_pk_mul_f32(gP, gP, gX),
+                                    lambda gP=gP, ch=ch, pk=pk: p.v_cvt_pk_bf16_f32(pk.sub(ch), gP.sub(0), gP.sub(1))]
+                            ins.append(seq)
+                        inter = [th for pair in zip(*ins) for th in pair]
+                        for i0 in range(0, len(inter), 6):
+                            grp = inter[i0:i0 + 6]
+                            add(lambda grp=grp: [th() for th in grp])
+                        add(lambda gi=gi: p.v_xor_b32(V_STWX, gi << 4, V_STW))
+                        add(lambda pk=pk: self.ds_write(V_STWX, pk))
+                        continue
                     for pr in range(2):
                         src = [acc.sub(4 * rg + 2 * pr), acc.sub(4 * rg + 2 * pr + 1)]
                         if self.bits_in:
@@ -1028,6 +1076,7 @@ FLAVOURS = {
     "f1": dict(relu=True, bits_out=True),                       # ... eval mode / visual compressor
     "f3": dict(bits_in=True),                                   # alpha * product under the ReLU sign bits: input gradient through linear2 (+ dropout scale)
     "k384_f0": dict(K=384),                                     # K = 384 (24 k-steps): the frozen ViT-S/14's qkv projection (dino_preprocessors.py:27-35)
+    "k384_f2": dict(K=384, gelu=True),                          # ... its fc1: bias + erf-GELU (asmgen/gelu_poly.py)
 }
 if _os.environ.get("SVLA_ASM_DEBUG_VARIANTS"):      # timing-only / bisection builds (tools/time_nt_as.py)
     for _d in ("time", "time,nostore", "time,nodma", "time,noepi", "time,nox", "time,nobarwait", "time,noepi,nodma,nox"):

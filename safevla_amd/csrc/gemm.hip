@@ -65,18 +65,19 @@ __device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) {
     typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
     return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
-// exact (erf) GELU of nn.GELU / timm's Mlp, branch-free: 1 + erf(x / sqrt 2) through Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 on erf, and no
-// cancellation in the negative tail: for x < 0 the quantity q = 1 - erf(|z|) IS the factor).  17 VALU ops (2 transcendental) where ocml's erff
-// is ~45 with branches -- the GELU epilogue was a third of the ViT's GEMM time.
+// erf-GELU of nn.GELU / timm's Mlp as x * (1/2 + clamp(t P(z))) with t = clamp(x, +-4.5), z = t^2 * (2 / 20.25) - 1 and a degree-9 polynomial P (asmgen/
+// gelu_poly.py: |error| <= 2.2e-5 for all x, exact tails): 15 plain VALU operations, no transcendental -- round 4's Abramowitz-Stegun form was 17 + v_rcp +
+// v_exp, and the exposed GELU epilogue was 40 % of the ViT's fc1 GEMM.  The assembly GELU flavour (svla_nt_as_k384_f2) evaluates the same polynomial.
+#include "_obj/gelu_poly.h"
 __device__ __forceinline__ float gelu_f(float x) {
-    const float az = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.f));
-    float q = fmaf(t, 1.061405429f, -1.453152027f);
-    q = fmaf(q, t, 1.421413741f);
-    q = fmaf(q, t, -0.284496736f);
-    q = fmaf(q, t, 0.254829592f);
-    q = q * t * __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);      // exp(-x^2 / 2)
-    return 0.5f * x * (x >= 0.f ? 2.f - q : q);
+    constexpr float c[SVLA_GELU_DEGREE + 1] = SVLA_GELU_COEFS;
+    const float t = __builtin_amdgcn_fmed3f(x, -SVLA_GELU_CLAMP, SVLA_GELU_CLAMP);
+    const float z = fmaf(t * t, SVLA_GELU_ZSCALE, -1.f);
+    float p = c[SVLA_GELU_DEGREE];
+#pragma unroll
+    for (int k = SVLA_GELU_DEGREE - 1; k >= 0; --k) p = fmaf(p, z, c[k]);
+    const float g = __builtin_amdgcn_fmed3f(t * p, -0.5f, 0.5f);
+    return x * (g + 0.5f);
 }
 
 __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p) {
@@ -1040,7 +1041,11 @@ static int nt_as_try(const GemmNtArgs& p, hipStream_t stream) {
         if (!p.drop.thr) name = "svla_nt_as_f1";
         else if ((unsigned long long)p.M * (unsigned long long)p.drop.row_mult * (unsigned long long)p.N / 2 < 0xffffffffull) name = "svla_nt_as_f1d";
     } else if (p.act == ACT_NONE && !p.bits_out && !p.drop.thr && p.alpha == 1.f) name = "svla_nt_as_f0";
-    if (p.K == 384) name = (name && !strcmp(name, "svla_nt_as_f0")) ? "svla_nt_as_k384_f0" : nullptr;      // the ViT-S width: bias flavour only
+    if (p.K == 384) {      // the ViT-S width: bias (qkv) and bias + erf-GELU (fc1) flavours
+        if (name && !strcmp(name, "svla_nt_as_f0")) name = "svla_nt_as_k384_f0";
+        else if (!p.bits_in && p.act == ACT_GELU && !p.bits_out && !p.drop.thr && p.alpha == 1.f) name = "svla_nt_as_k384_f2";
+        else name = nullptr;
+    }
 #ifdef SVLA_ASM_DEBUG      // instrumented builds of tools/ only (SVLA_EXTRA_FLAGS=-DSVLA_ASM_DEBUG): svla_nt_as_f0_<variant>
     static char dbg_name[96];
     if (name && getenv("SVLA_NT_AS_VARIANT")) {

@@ -416,53 +416,103 @@ extern "C" int svla_rows_add_bf16(bf16_t* dst, long dst_ld, const bf16_t* src, l
 // :27-35 crop 3:-3 + 14x14/14 patch embedding): uint8 HWC frames -> normalised bf16 im2col rows [B, gh*gw, KP]
 // with k = c*P*P + ky*P + kx (the flattened conv-weight order), zero padded to KP.  One block per (frame, patch row):
 // the P image rows are staged in LDS with coalesced byte loads, outputs are written as coalesced dword pairs.
+// Round 5: dword-wide.  The P image rows of the block are fetched as ALIGNED 4-byte words (256 B per wave instruction instead of 64; the crop starts
+// 9 bytes into a row, so each staged row keeps its own 0..3-byte lead), the (c, ky, kx) decode of k is a per-block LDS table instead of three integer
+// divisions per element, and every lane writes 16 bytes (8 bf16) of an output row: full 1-KiB wave stores.
 __global__ void patchify_u8_kernel(const unsigned char* __restrict__ frames, int H, int W, int crop_x, int P, int gh, int gw,
-                                   int KP, float m0, float m1, float m2, float s0, float s1, float s2, bf16_t* __restrict__ out) {
-    extern __shared__ unsigned char rows[];   // [P][gw*P*3]
+                                   int KP, float m0, float m1, float m2, float s0, float s1, float s2, bf16_t* __restrict__ out, int wide) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / gh, gy = blockIdx.x % gh;
     const int rowbytes = gw * P * 3;
+    const int pitch = (rowbytes + 8 + 3) & ~3;                  // staged row: up to 3 lead bytes + the segment, dword aligned
+    unsigned char* rows = smem;                                // [P][pitch]
+    unsigned short* lut = (unsigned short*)(smem + ((P * pitch + 15) & ~15));      // [KP]: byte offset of (ky, kx = 0.., c) inside the staged rows, patch column 0
+    unsigned char* cls = (unsigned char*)(lut + KP);           // [KP]: channel of k (3 = padding)
     const unsigned char* src = frames + ((size_t)b * H + gy * P) * W * 3 + crop_x * 3;
-    for (int i = threadIdx.x; i < P * rowbytes; i += blockDim.x) rows[i] = src[(size_t)(i / rowbytes) * W * 3 + (i % rowbytes)];
-    __syncthreads();
-    const float mean[3] = {m0, m1, m2}, inv[3] = {1.f / s0, 1.f / s1, 1.f / s2};
     const int K = 3 * P * P;
-    bf16_t* dst = out + ((size_t)b * gh * gw + (size_t)gy * gw) * KP;
-    for (int i = threadIdx.x; i < gw * (KP / 2); i += blockDim.x) {
-        const int gx = i / (KP / 2), k0 = (i % (KP / 2)) * 2;
-        float v[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int k = k0 + e;
+    if (wide) {
+        const int ndw = (rowbytes + 3 + 3) / 4;                 // words covering lead + segment
+        for (int i = threadIdx.x; i < P * ndw; i += blockDim.x) {
+            const int r = i / ndw, j = i % ndw;
+            const unsigned char* rp = src + (size_t)r * W * 3;
+            const uint32_t* ap = (const uint32_t*)((uintptr_t)rp & ~(uintptr_t)3);
+            *(uint32_t*)(rows + r * pitch + 4 * j) = __builtin_nontemporal_load(ap + j);
+        }
+        for (int k = threadIdx.x; k < KP; k += blockDim.x) {
             if (k < K) {
                 const int c = k / (P * P), ky = (k % (P * P)) / P, kx = k % P;
-                const float px = (float)rows[ky * rowbytes + (gx * P + kx) * 3 + c];
-                v[e] = (px / 255.0f - mean[c]) * inv[c];
-            } else v[e] = 0.f;
+                const int lead = (int)((uintptr_t)(src + (size_t)ky * W * 3) & 3);
+                lut[k] = (unsigned short)(ky * pitch + lead + kx * 3 + c);
+                cls[k] = (unsigned char)c;
+            } else { lut[k] = 0; cls[k] = 3; }
         }
-        *(uint32_t*)(dst + (size_t)gx * KP + k0) = pack_bf2(v[0], v[1]);
+    } else {
+        for (int i = threadIdx.x; i < P * rowbytes; i += blockDim.x) rows[(i / rowbytes) * pitch + (i % rowbytes)] = src[(size_t)(i / rowbytes) * W * 3 + (i % rowbytes)];
+        for (int k = threadIdx.x; k < KP; k += blockDim.x) {
+            if (k < K) {
+                const int c = k / (P * P), ky = (k % (P * P)) / P, kx = k % P;
+                lut[k] = (unsigned short)(ky * pitch + kx * 3 + c);
+                cls[k] = (unsigned char)c;
+            } else { lut[k] = 0; cls[k] = 3; }
+        }
+    }
+    __syncthreads();
+    const float mean[4] = {m0, m1, m2, 0.f}, inv[4] = {1.f / s0, 1.f / s1, 1.f / s2, 0.f};
+    bf16_t* dst = out + ((size_t)b * gh * gw + (size_t)gy * gw) * KP;
+    const int kv = KP / 8;
+    for (int i = threadIdx.x; i < gw * kv; i += blockDim.x) {
+        const int gx = i / kv, k0 = (i % kv) * 8;
+        const int xo = gx * P * 3;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cls[k0 + e];
+            const float px = (float)rows[lut[k0 + e] + xo];
+            v[e] = c < 3 ? (px / 255.0f - mean[c]) * inv[c] : 0.f;
+        }
+        u32x4 w = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        *(u32x4*)(dst + (size_t)gx * KP + k0) = w;
     }
 }
 extern "C" int svla_patchify_u8_bf16(const unsigned char* frames, int B, int H, int W, int crop_x, int P, int gh, int gw, int KP,
                                      const float* mean3, const float* std3, bf16_t* out, void* stream) {
-    if (B <= 0 || gh * P > H || crop_x + gw * P > W || KP < 3 * P * P || (KP % 2) || !mean3 || !std3) return SVLA_EINVAL;
-    const size_t lds = (size_t)P * gw * P * 3;
+    if (B <= 0 || gh * P > H || crop_x + gw * P > W || KP < 3 * P * P || (KP % 8) || !mean3 || !std3) return SVLA_EINVAL;
+    const int rowbytes = gw * P * 3, pitch = (rowbytes + 8 + 3) & ~3;
+    if ((size_t)P * pitch + 64 > 60000) return SVLA_EINVAL;      // 16-bit offsets of the decode table
+    const size_t lds = (((size_t)P * pitch + 15) & ~(size_t)15) + (size_t)KP * 3;
+    // aligned word loads may touch up to 3 bytes on either side of a row segment: inside the frame buffer unless the crop ends at the very last byte of it
+    const int wide = ((uintptr_t)frames % 4 == 0) && (crop_x > 0 || ((size_t)W * 3) % 4 == 0) && ((size_t)(crop_x + gw * P) * 3 + 3 <= (size_t)W * 3 || gh * P < H) ? 1 : 0;
     hipLaunchKernelGGL(patchify_u8_kernel, dim3(B * gh), dim3(256), lds, (hipStream_t)stream, frames, H, W, crop_x, P, gh, gw, KP,
-                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], out);
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], out, wide);
     return svla_launch_status();
 }
 
 // DataAugmentationPreprocessor.process without augmentation (dino_preprocessors.py:224-239): u8 HWC -> (x/255 - mean)/std fp32 HWC
+// Round 5: one aligned dword (4 bytes of the HWC stream) per lane -> one float4 per lane: 256-B wave loads, 1-KiB wave stores, non-temporal (stream-once).
 __global__ void normalize_u8_kernel(const unsigned char* __restrict__ x, long n, float m0, float m1, float m2, float s0, float s1,
                                     float s2, float* __restrict__ y) {
-    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};      // (x / 255 - mean) / std exactly as the reference writes it
+    const long nw = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (long)gridDim.x * blockDim.x) {
+        const uint32_t w = __builtin_nontemporal_load((const uint32_t*)x + i);
+        int c = (int)((4 * i) % 3);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = ((float)((w >> (8 * e)) & 0xffu) / 255.0f - mean[c]) / sd[c];
+            c = c == 2 ? 0 : c + 1;
+        }
+        __builtin_nontemporal_store(o, (f32x4*)y + i);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {      // tail bytes (n % 4)
+        const long i = (nw << 2) + threadIdx.x;
         const int c = (int)(i % 3);
         y[i] = ((float)x[i] / 255.0f - mean[c]) / sd[c];
     }
 }
 extern "C" int svla_normalize_u8_f32(const unsigned char* x, long n, const float* mean3, const float* std3, float* y, void* stream) {
-    if (n <= 0 || (n % 3)) return SVLA_EINVAL;
-    long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    if (n <= 0 || (n % 3) || ((uintptr_t)x % 4) || ((uintptr_t)y % 16)) return SVLA_EINVAL;
+    long blocks = ((n >> 2) + 255) / 256; if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(normalize_u8_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, n, mean3[0], mean3[1], mean3[2],
                        std3[0], std3[1], std3[2], y);
     return svla_launch_status();

@@ -116,6 +116,46 @@ def mean_episode_cost(sum_cost: float, n_episodes: float, device, group=None) ->
     return (s / n if n > 0 else 0.0), n
 
 
+def preflight(model, device) -> dict:
+    """Before anything is timed on N > 1 ranks: the collectives the update will issue, on sentinels, checked on EVERY rank --
+    one asynchronous SUM all-reduce per tower range of the flat gradient arena (the same tensors, sizes and call as engine.py's per-tower
+    exchange; rank r contributes r + 1, so every element must come back as N (N + 1) / 2), the [sum cost, #episodes] reduction, and the
+    backend's own idea of the world size.  Raises on any mismatch; returns what it saw (bench.py puts it in the line).  The gradient buffer is
+    zero on return."""
+    if not is_dist():
+        return {"ranks": 1, "backend": None, "tower_ranges_checked": 0}
+    n, r = dist.get_world_size(), dist.get_rank()
+    want = n * (n + 1) / 2.0
+    ar = model.arena
+    handles = []
+    for lo, hi in ar.tower_ranges:
+        ar.flat_g[lo:hi].fill_(float(r + 1))
+        handles.append(allreduce_sum_async(ar.flat_g[lo:hi]))
+    for h in handles:
+        h.wait()
+    bad = 0
+    for lo, hi in ar.tower_ranges:
+        g = ar.flat_g[lo:hi]
+        bad += int((g != want).sum().item())
+        g.zero_()
+    jc, ne = mean_episode_cost(float(r + 1), 1.0, device)
+    cnt = global_count(1, device)
+    if bad or cnt != n or abs(ne - n) > 0 or abs(jc - want / n) > 1e-12:
+        raise RuntimeError(f"collective pre-flight failed on rank {r}: {bad} gradient elements != {want}, rank count {cnt} (world {n}), cost reduction ({jc}, {ne})")
+    return {"ranks": cnt, "backend": dist.get_backend(), "tower_ranges_checked": len(ar.tower_ranges),
+            "bytes_per_tower_allreduce": [int((hi - lo) * 4) for lo, hi in ar.tower_ranges]}
+
+
+def gather_floats(v: float, device) -> List[float]:
+    """the value of every rank, on every rank (per-rank step times of bench.py)"""
+    if not is_dist():
+        return [float(v)]
+    t = torch.zeros(dist.get_world_size(), device=device, dtype=torch.float64)
+    t[dist.get_rank()] = float(v)
+    dist.all_reduce(t)
+    return t.tolist()
+
+
 def barrier():
     if is_dist():
         dist.barrier()

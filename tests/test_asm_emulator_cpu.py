@@ -78,6 +78,9 @@ def run_kernel(flavour, M, N, grid, order=None, seed=0, alpha=1.0, key=0x1234567
             ref = np.where(_drop_keep(M, N, key, thr, row_mult), ref * scale, np.float32(0))
         if g.relu:
             ref = np.maximum(ref, 0)
+        if g.gelu:
+            from safevla_amd.asmgen import gelu_poly
+            ref = gelu_poly.gelu_ref_np(ref)
     return out, ref, bits, g
 
 
@@ -152,6 +155,20 @@ def test_nt_as_k384_bias():
     check(out, ref)
     out, ref, _, _ = run_kernel("k384_f0", 256, 1152, 1, K=384, nsplit=3, flags=1, order=[3, 2, 1, 0])
     check(out, ref)
+
+
+def test_nt_as_k384_gelu_flavour_evaluates_the_shared_polynomial():
+    """bias + erf-GELU (the frozen ViT's fc1) as packed-fp32 Horner chains in the MFMA gaps: against the numpy restatement of asmgen/gelu_poly.py to one
+    bf16 rounding, and against scipy's exact erf-GELU of the fp32 pre-activation"""
+    from scipy.special import erf
+    out, ref, _, _ = run_kernel("k384_f2", 256, 256, 1, K=384, flags=1)
+    assert not np.isnan(out).any()
+    err = np.abs(out - ref)
+    assert (err <= 2.0 ** -8 * np.abs(ref) + 1e-5).all(), float(err.max())
+    pre = ref        # recompute the pre-activation for the exact form
+    out2, ref2, _, _ = run_kernel("k384_f0", 256, 256, 1, K=384, flags=1)      # same seed: ref2 = acc + bias
+    exact = (ref2.astype(np.float64) * 0.5 * (1 + erf(ref2.astype(np.float64) / np.sqrt(2)))).astype(np.float32)
+    assert np.abs(out - exact).max() <= 2.0 ** -8 * np.abs(exact).max() + 3e-5
 
 
 def test_nt_as_signbit_mask_alpha():

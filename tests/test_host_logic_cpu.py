@@ -179,3 +179,25 @@ def test_reference_entry_point_shim_parses_fire_style_command_lines():
                                    "--callbacks", "wandb_logging_callback", "--checkpoint", "c.pt"])
     assert (a.il_ckpt_path, a.num_train_processes, a.cost_limit, a.checkpoint) == ("il.ckpt", 32, 2.31964, "c.pt")
     assert infer_task(a.tag, a.dataset_dir) == "Fetch" and infer_task("ObjectNavType", "") == "ObjectNav" and infer_task("PickupType", "") == "PickUp"
+
+
+def test_polynomial_erf_gelu_of_the_kernels_against_scipy():
+    """safevla_amd/asmgen/gelu_poly.py: the degree-9 form every GELU epilogue evaluates (HIP: csrc/gemm.hip gelu_f through the generated header; assembly:
+    svla_nt_as_k384_f2) against the exact erf-GELU of nn.GELU() (the frozen ViT's Mlp), over all magnitudes; exact tails; the generated C header carries
+    the same fp32 constants."""
+    import re
+    import struct
+
+    import numpy as np
+    from scipy.special import erf
+
+    from safevla_amd.asmgen import gelu_poly as G
+
+    x = np.concatenate([np.linspace(-12, 12, 600001), np.array([-1e4, -50.0, 50.0, 1e4, 0.0, -0.0])]).astype(np.float32)
+    y = G.gelu_ref_np(x)
+    exact = x.astype(np.float64) * 0.5 * (1 + erf(x.astype(np.float64) / np.sqrt(2)))
+    assert np.abs(y - exact).max() < 3e-5
+    assert (y[x >= G.CLAMP] == x[x >= G.CLAMP]).all() and (y[x <= -G.CLAMP] == 0).all()
+    hdr = G.c_header()
+    cs = [float(v) for v in re.search(r"SVLA_GELU_COEFS \{(.*)\}", hdr).group(1).replace("f", "").split(",")]
+    assert [struct.unpack("<I", struct.pack("<f", v))[0] for v in cs] == G.COEF_BITS

@@ -59,6 +59,15 @@ def _worker(rank, world, port, q):
     for h in handles:
         h.wait()
     jc, n_ep = parallel.mean_episode_cost(3.0 * (rank + 1), 2.0, "cpu")
+    # bench.py's collective pre-flight on a stand-in arena (three "tower ranges" of one flat buffer) + the per-rank clock gather
+    class _Arena:
+        flat_g = torch.zeros(3000)
+        tower_ranges = [(0, 1024), (1024, 2048), (2048, 3000)]
+    class _M:
+        arena = _Arena()
+    pre = parallel.preflight(_M(), "cpu")
+    assert pre["ranks"] == world and pre["tower_ranges_checked"] == 3 and float(_Arena.flat_g.abs().sum()) == 0.0, pre
+    assert parallel.gather_floats(10.0 + rank, "cpu") == [10.0 + i for i in range(world)]
     parallel.barrier()
     if rank == 0:
         q.put((flat.numpy(), jc, n_ep))

@@ -34,6 +34,30 @@ def test_normalize_matches_reference_formula(pre):
     assert torch.allclose(got.cpu(), ref_vit.normalize(fr), rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,H,W,crop_x,P,gh,gw", [(3, 224, 384, 3, 14, 16, 27),      # DINOv2 ViT-S/14 on the 224 x 384 frames (crop 3:-3)
+                                                  (2, 256, 256, 0, 16, 16, 16),      # SigLIP 256 x 256, 16 x 16 patches, no crop
+                                                  (2, 30, 45, 3, 14, 2, 2),          # odd row pitch (135 B): every staged row has its own 0..3-byte lead
+                                                  (1, 28, 29, 1, 14, 2, 2)])         # crop ends at the last byte of the buffer: byte-wise staging path
+def test_patchify_u8_matches_numpy_im2col(B, H, W, crop_x, P, gh, gw):
+    """svla_patchify_u8_bf16 (normalise + crop + im2col, dino_preprocessors.py:27-35,224-239) against a numpy restatement, incl. the geometries that
+    exercise the aligned-dword row staging (round 5): k = c*P*P + ky*P + kx, zero padded to KP."""
+    from safevla_amd import ops
+    from safevla_amd.preproc import DINO_RGB_MEANS, DINO_RGB_STDS
+
+    rs = np.random.RandomState(B * 1000 + W)
+    fr = rs.randint(0, 256, (B, H, W, 3), dtype=np.uint8)
+    K = 3 * P * P
+    KP = (K + 31) // 32 * 32
+    out = torch.full((B, gh * gw, KP), float("nan"), device=DEV, dtype=torch.bfloat16)
+    ops.patchify_u8(torch.from_numpy(fr).to(DEV), DINO_RGB_MEANS, DINO_RGB_STDS, out, crop_x=crop_x, P=P, gh=gh, gw=gw)
+    x = (fr.astype(np.float32) / 255.0 - np.array(DINO_RGB_MEANS, np.float32)) / np.array(DINO_RGB_STDS, np.float32)
+    x = x[:, :gh * P, crop_x:crop_x + gw * P]                                       # [B, gh*P, gw*P, 3]
+    x = x.reshape(B, gh, P, gw, P, 3).transpose(0, 1, 3, 5, 2, 4).reshape(B, gh * gw, K)      # (c, ky, kx)
+    got = out.float().cpu().numpy()
+    assert (got[:, :, K:] == 0).all()
+    np.testing.assert_allclose(got[:, :, :K], x, rtol=2.0 ** -7, atol=1e-6)
+
+
 def test_vit_features_vs_oracle(pre):
     from oracle import ref_vit
 

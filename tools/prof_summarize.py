@@ -79,7 +79,8 @@ def pmc(fdb, wdb, out):
         if any(k in n for k in ("gemm", "attn", "norm", "colsum", "adam", "svla_", "patchify", "vit_tokens", "adaptive_pool")):
             fv, fc, fd = f.get(n, (0, 0, 0)); wv, wc, wd = w.get(n, (0, 0, 0))
             res["kernels"][n.split("(")[0]] = {"launches": fc, "fetch_bytes_per_launch": 2 * fv * 1024, "write_bytes_per_launch": wv * 1024,
-                                               "hbm_bytes_per_launch": 2 * fv * 1024 + wv * 1024, "avg_duration_us_profiled": fd / 1e3}
+                                               "hbm_bytes_per_launch": 2 * fv * 1024 + wv * 1024, "avg_duration_us_profiled": fd / 1e3,
+                                               "hbm_TBps_profiled": round((2 * fv * 1024 + wv * 1024) / max(fd, 1) / 1e3, 4)}
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res["kernels"].items():
         print(f'{k[:42]:42s} n={v["launches"]:5d} hbm={v["hbm_bytes_per_launch"]/1e9:8.3f} GB/launch  {v["avg_duration_us_profiled"]:9.1f} us')

@@ -23,4 +23,15 @@ if [ "${SKIP_PMC:-0}" != "1" ]; then
   cmp -s /tmp/gemm_f.log /tmp/gemm_w.log || echo "WARNING: the two passes launched different GEMM sequences"
   python $REPO/tools/prof_summarize.py pmc_shapes "$FDB" "$WDB" /tmp/gemm_f.log $OUT/${TAG}_pmc_hbm_traffic_by_shape.json
 fi
+if [ "${SKIP_PREPROC:-0}" != "1" ]; then
+  # observation-tensor loads (north_star: "coalesced HBM loads of the (T.B, C, H, W) observation tensor evidenced by rocprof HBM-GB/s"): the u8 frame kernels
+  # (normalize_u8, patchify_u8) and the rest of the frozen ViT, same separate-pass recipe
+  VCMD="python $REPO/tools/vit_probe.py"
+  rm -rf /tmp/v_kt /tmp/v_f /tmp/v_w
+  rocprofv3 --kernel-trace --stats -d /tmp/v_kt -o kt -- $VCMD > /dev/null 2> /tmp/vkt.err
+  python $REPO/tools/prof_summarize.py stats "$(find /tmp/v_kt -name '*.db' | head -1)" $OUT/${TAG}_vit_kernel_stats.txt "frozen DINOv2 ViT-S/14 probe + normalize_u8 (tools/vit_probe.py; $TAG)" > /dev/null
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/v_f -o f -- $VCMD > /dev/null 2> /tmp/vf.err
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/v_w -o w -- $VCMD > /dev/null 2> /tmp/vw.err
+  python $REPO/tools/prof_summarize.py pmc "$(find /tmp/v_f -name '*.db' | head -1)" "$(find /tmp/v_w -name '*.db' | head -1)" $OUT/${TAG}_pmc_preproc_traffic.json > /dev/null
+fi
 ls -la $OUT | grep "$TAG"
