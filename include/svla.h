@@ -173,8 +173,10 @@ int svla_replay_abi_stamp(unsigned long long* stamp);
  * an int64 shadow (zero-initialised, n elements) of the fp32 range [f32_base, f32_base + n): from then on every such accumulation
  * whose target lies in a registered range is added to the shadow as 64-bit fixed point (2^-52 resolution; only partials with |partial| < 0.25 enter the shadow, so up to 8192 of them cannot wrap its +-2048 range -- larger or non-finite ones take the plain fp32 atomic and stay visible; integer adds commute,
  * so the sum is bitwise repeatable; each partial is rounded once to the grid, non-finite partials bypass the shadow) instead.
- * svla_det_finalize adds shadow * 2^-52 into the fp32 buffer and clears the shadow.  Repeatable are the GRADIENTS: the clip coefficient (fp64
- * atomics of the squared norm) and the three loss sums are still accumulated in arrival order.
+ * svla_det_finalize adds shadow * 2^-52 into the fp32 buffer and clears the shadow.  With it the GRADIENTS are repeatable, and so is the optimiser step: the
+ * squared gradient norm behind the clip coefficient is reduced in a fixed order in every mode (svla_sumsq_f32: per-block partials, summed by the last block
+ * in slot order).  What still accumulates in arrival order are the loss sums of the info dictionary (fp64 atomics: reported scalars only, no parameter
+ * depends on them).
  * slot 0 / 1: two independent ranges (the flat gradient buffer; a scratch range for accumulated intermediates).  NULL, NULL, 0
  * unregisters.  bf16 product path only (the fp32 verification kernels keep their atomics). */
 int svla_det_config(int slot, float* f32_base, long long* i64_shadow, long n);
@@ -260,6 +262,8 @@ int svla_dropout_bf16(svla_bf16* x, long rows, int N, const svla_dropout* drop, 
 
 /* ---- optimiser (Adam lr 2e-5, max_grad_norm 0.5: training/online/dinov2_vits_tsfm_base.py:331-334; weight_decay > 0 = the
  * decoupled AdamW of the imitation-learning trainer, training/offline/train_pl.py:283-287) ---------------------------------- */
+/* *out += sum g[i]^2, reduced in a fixed order (block partials in a library-owned scratch, summed by the block that arrives last): calls that share `out`
+ * must be issued on one stream (the engine's per-tower calls are); the first call allocates the scratch (not inside a stream capture). */
 int svla_sumsq_f32(const float* g, long n, double* out, void* stream);
 int svla_adam_step_f32(float* p, const float* g, float* m, float* v, svla_bf16* p_bf16, long n, float lr, float beta1,
                        float beta2, float eps, int step, const double* gnorm_sq, float max_norm, float grad_scale,

@@ -813,8 +813,13 @@ class NtAsGen:
         # ---- panel switch (last step of a panel): the next panel's A fragments replace the ones whose last MFMA has been issued
         if kind == "last":
             p.s_add_u32(S_PN, S_P, S_GRID)
+            p.s_cmp("lt_u32", S_PN, S_NPANELS)
+            # past the end (a mid-M workgroup's ONLY panel; every workgroup's last one): the fragment loads stay in the stream -- the counted waits of the
+            # following code assume them -- but with num_records = 0 every lane is out of range, so they return zeros without a memory request.  (With the
+            # real re-fetch of the last panel the last step of a one-panel workgroup took 11.9 k cycles instead of 3.6 k: profiles/r05_midm_step_timing.txt.)
+            p.s_cselect_b32(SRD_X.sub(2), 0xffffffff, 0)
             p.s_sub_u32(S_T[7], S_NPANELS, 1)
-            p.s_min_u32(S_PN, S_PN, S_T[7])          # past the end: re-fetch the last panel (never used)
+            p.s_min_u32(S_PN, S_PN, S_T[7])
             self.panel_srd(SRD_X, S_A, S_PN, S_LDA2)
             for ks in range(KS):
                 for mb in range(2):
@@ -1085,6 +1090,8 @@ if _os.environ.get("SVLA_ASM_DEBUG_VARIANTS"):      # timing-only / bisection bu
         FLAVOURS["f0_" + _k] = _o
     for _k in ("f1d", "f1", "f3"):
         FLAVOURS[_k + "_time"] = dict(FLAVOURS[_k], dbg="time") if _k != "f1d" else FLAVOURS[_k]
+    for _d in ("time", "time,nostore", "time,nodma", "time,noepi", "time,noepi,nodma"):      # round 5: the K = 384 flavours (tools/time_midm.py)
+        FLAVOURS["k384_f0_" + _d.replace(",", "_")] = dict(K=384, dbg=_d)
 
 
 def generate(flavour="f0"):

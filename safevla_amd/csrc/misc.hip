@@ -5,6 +5,7 @@
 //   swiglu / _bwd       : llama FeedForward gate
 //   adam / sumsq / cast / transpose : flat-buffer optimiser step (clip by global norm, no host sync)
 #include "common.h"
+#include <mutex>
 #include <type_traits>
 
 // ------------------------------------------------------------------------------------------------
@@ -274,19 +275,49 @@ extern "C" int svla_swiglu_bwd(const bf16_t* ab, const bf16_t* dg, long M, int H
 }
 
 // ------------------------------------------------------------------------------------------------ optimiser
-__global__ void sumsq_kernel(const float* __restrict__ g, long n, double* __restrict__ out) {
+// Order-independent (round 5): every block writes its partial into a scratch slot, the block that finishes LAST adds the partials in slot order and
+// accumulates the total into *out -- the clip coefficient (hence every parameter after the Adam step) no longer depends on the arrival order of 1024 fp64
+// atomics ("deterministic mode repeats gradients only").  Launches on one stream are ordered, so the per-tower calls accumulate in a fixed order too.
+__global__ void sumsq_kernel(const float* __restrict__ g, long n, double* __restrict__ out, double* __restrict__ partial, unsigned* __restrict__ done) {
     float s = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += g[i] * g[i];
     s = wave_sum(s);
     __shared__ float part[4];
+    __shared__ bool last;
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, (double)(part[0] + part[1] + part[2] + part[3]));
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&partial[blockIdx.x], (double)part[0] + (double)part[1] + (double)part[2] + (double)part[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = atomicAdd(done, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    double t = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) t += __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ double red[256];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { *out += red[0]; *done = 0u; }
 }
 extern "C" int svla_sumsq_f32(const float* g, long n, double* out, void* stream) {
     if (n <= 0) return SVLA_EINVAL;
     long blocks = (n + 1023) / 1024; if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(sumsq_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+    static std::once_flag once;
+    static double* scratch = nullptr;      // [1024] partials + the arrival counter; one stream at a time uses it (the optimiser step of one engine)
+    static int rc_alloc = 0;
+    std::call_once(once, [] {
+        hipError_t e = hipMalloc(&scratch, 1025 * sizeof(double));
+        if (e == hipSuccess) e = hipMemset(scratch, 0, 1025 * sizeof(double));
+        rc_alloc = (e == hipSuccess) ? 0 : (int)e;
+    });
+    if (rc_alloc) return rc_alloc;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, g, n, out, scratch, (unsigned*)(scratch + 1024));
     return svla_launch_status();
 }
 

@@ -112,6 +112,34 @@ def test_deterministic_mode_gives_bitwise_repeatable_gradients(model, T, B, chun
     model.zero_grad()
 
 
+def test_deterministic_mode_repeats_the_whole_update_bitwise(model):
+    """Round 5: the squared gradient norm behind the clip coefficient is reduced in a fixed order (svla_sumsq_f32), so with deterministic=True the PARAMETERS
+    after a full update (GAE, lambda, 2 epochs of forward / losses / backward / clip / Adam) are bitwise identical from run to run, not only the gradients."""
+    from safevla_amd.engine import PPOLagConfig, PPOLagEngine
+    from safevla_amd.synth_env import SynthSpec, fill_synthetic_rollout
+
+    model.eval()
+    T, B = 64, 16
+    st, nxt, ep = fill_synthetic_rollout(model, SynthSpec(T=T, B=B, L=12, task="PickUp", seed=33), device=DEV)
+    p0, m0, v0 = model.arena.flat_p.clone(), model.arena.flat_m.clone(), model.arena.flat_v.clone()
+    outs = []
+    try:
+        for _ in range(2):
+            model.arena.flat_p.copy_(p0); model.arena.flat_m.copy_(m0); model.arena.flat_v.copy_(v0)
+            model.sync_weights(frozen=False)
+            eng = PPOLagEngine(model, PPOLagConfig(update_repeats=2, cost_limit=2.31964, deterministic=True, record_small_updates=False))
+            eng.update(st, nxt["next_value"], nxt["next_c_value"], ep["episode_cost_sum"], ep["n_episodes"])
+            torch.cuda.synchronize()
+            outs.append(model.arena.flat_p.clone())
+            del eng
+    finally:
+        model.arena.flat_p.copy_(p0); model.arena.flat_m.copy_(m0); model.arena.flat_v.copy_(v0)
+        model.sync_weights(frozen=False)
+        model.zero_grad()
+    assert torch.isfinite(outs[0]).all() and not torch.equal(outs[0], p0)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_c5_shard_fp8_attention_gradient_close_to_bf16(model):
     """BASELINE configs[4]: one GPU's 32 envs x 256 steps of the mixed-task sampler with 64-token instructions (S = 233), fusion-encoder
     attention on the fp8 MFMA kernels (e4m3 Q/K/V/P, e5m2 dO/dS) against the same minibatch through the bf16 kernels, eval mode.
