@@ -168,7 +168,32 @@ def north_star_probe(model, dev, rows_T=32, rows_B=8, L=64):
     ms = (time.perf_counter() - t0) / 3 * 1e3
     U = int(st.observations["goal_token_ids"][:rows_T].reshape(R, -1).unique(dim=0).shape[0])
     fl = flops_per_update(R, 169 + L, L, U, 1)
-    return {"rows": R, "goal_tokens": L, "ms_fwd_bwd_3_towers": round(ms, 2),
+    # the shape as north_star writes it -- "batch 256 x (2 x 3 x 224 x 224 + 64 tok)" -- includes the image encoder on two 224 x 224 frames per row: the
+    # frozen DINOv2 ViT-S/14 on 512 uint8 frames (16 x 16 patches + class token) in front of the same 3-tower forward + backward
+    as_written = None
+    try:
+        from safevla_amd.preproc import DINO_RGB_MEANS, DINO_RGB_STDS, DinoViTPreprocessor
+        vit = DinoViTPreprocessor("rgb_raw", "rgb_dinov2", device=dev).vit
+        fr = torch.randint(0, 256, (2 * R, 224, 224, 3), device=dev, dtype=torch.uint8)
+        with GemmTimer(ops) as gv:
+            vit.patch_tokens(fr, DINO_RGB_MEANS, DINO_RGB_STDS, crop_x=0)
+        vit_fl = sum(v["flops"] for v in gv.summary().values())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            vit.patch_tokens(fr, DINO_RGB_MEANS, DINO_RGB_STDS, crop_x=0)
+        torch.cuda.synchronize()
+        vit_ms = (time.perf_counter() - t0) / 3 * 1e3
+        as_written = {"vit_frames": 2 * R, "vit_ms": round(vit_ms, 2), "vit_executed_tflop": round(vit_fl / 1e12, 2), "vit_tflops": round(vit_fl / (vit_ms * 1e-3) / 1e12, 1),
+                      "combined_ms": round(vit_ms + ms, 2), "combined_executed_tflop": round((vit_fl + executed) / 1e12, 2),
+                      "combined_frac_of_bf16_mfma_peak": round((vit_fl + executed) / ((vit_ms + ms) * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                      "note": "frozen DINOv2 ViT-S/14 forward on 2 x 256 frames of 224 x 224 (uint8 -> normalise -> 14 x 14 patches -> 12 blocks, S = 257) + the 3-tower "
+                              "forward + backward above; executed MFMA FLOPs / (ViT time + policy time) / 2.5 PFLOP/s"}
+        del fr, vit
+        torch.cuda.empty_cache()
+    except Exception as e:
+        as_written = {"error": repr(e)[:200]}
+    return {"rows": R, "goal_tokens": L, "ms_fwd_bwd_3_towers": round(ms, 2), "as_written_with_image_encoder": as_written,
             "executed_mfma_tflop": round(executed / 1e12, 2), "executed_tflops": round(executed / (ms * 1e-3) / 1e12, 1),
             "frac_of_bf16_mfma_peak": round(executed / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "reference_schedule_tflop": round(fl / 1e12, 2), "reference_schedule_frac_of_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),

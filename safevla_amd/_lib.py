@@ -59,6 +59,12 @@ def abi_stamp(path: str = HEADER) -> int:
     return h
 
 
+def torch_cuda_available() -> bool:
+    import torch
+
+    return torch.cuda.is_available()
+
+
 class SvlaError(RuntimeError):
     pass
 
@@ -88,6 +94,7 @@ class _Lib:
         # signature list it was built from.
         stamp = ctypes.c_ulonglong(0)
         self.cdll.svla_replay_abi_stamp(ctypes.byref(stamp))
+        self._gpu_init_done = False
         if stamp.value != abi_stamp():
             raise SvlaError(f"{LIB_PATH} was built from a different include/svla.h (entry-point table stamp {stamp.value:#x}, header {abi_stamp():#x}): "
                             "rebuild with `python safevla_amd/build.py`")
@@ -95,6 +102,12 @@ class _Lib:
     recorder = None      # optional list: every call is appended as (bound C function, args) -- launch-replay experiments (tools/replay_probe.py)
 
     def call(self, name: str, *args):
+        if not self._gpu_init_done:
+            # one-time device-side initialisation of the GEMM dispatchers (CU count, zero bias, the assembly code object) before the first real launch -- not
+            # lazily inside a HIP-graph capture or a replay thread.  Deferred to the first call so that CPU-only processes can still load the library.
+            self._gpu_init_done = True
+            if torch_cuda_available():
+                self.cdll.svla_gemm_force_small_tile(0)
         fn = getattr(self.cdll, name)
         if self.recorder is not None:
             self.recorder.append((fn, args))

@@ -25,6 +25,11 @@ int load_locked() {
 }
 }  // namespace
 
+int svla_asm_preload() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return load_locked();
+}
+
 int svla_asm_has(const char* name) {
     for (int i = 0; svla_asm_kernel_names[i]; ++i)
         if (std::string(svla_asm_kernel_names[i]) == name) return 1;

@@ -988,7 +988,7 @@ static int gemm_globals_init() {
         if (e == hipSuccess) e = hipDeviceGetAttribute(&g_gg.n_cu, hipDeviceAttributeMultiprocessorCount, dev);
         if (e == hipSuccess) e = hipMalloc(&g_gg.zero_bias, 4096 * sizeof(float));
         if (e == hipSuccess) e = hipMemset(g_gg.zero_bias, 0, 4096 * sizeof(float));
-        g_gg.rc = (e == hipSuccess) ? 0 : (int)e;
+        g_gg.rc = (e == hipSuccess) ? svla_asm_preload() : (int)e;      // the assembly code object too: nothing is left to load inside a stream capture
     });
     return g_gg.rc;
 }
@@ -1094,7 +1094,7 @@ static int nt_as_try(const GemmNtArgs& p, hipStream_t stream) {
         if (g_force_small_tile != 2) {
             const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
             const double hip = (double)((tiles + n_cu - 1) / n_cu) * (6.2 + 11.6 * p.K / 512.0);
-            const double asm_cost = (best + ((p.M % 256) ? 2.5 : 0.0)) * 2.76 * p.K / 512.0;
+            const double asm_cost = best * 2.76 * p.K / 512.0 + ((p.M % 256) ? 15.0 : 0.0);      // a ragged M: + the tail launch behind it (~15 us in a stream, r05_vit_kernel_stats.txt)
             if (asm_cost > 0.95 * hip) return NT_AS_NOT_TAKEN;
         }
         grid_y = best_d;
