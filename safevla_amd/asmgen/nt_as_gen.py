@@ -1082,6 +1082,7 @@ FLAVOURS = {
     "f3": dict(bits_in=True),                                   # alpha * product under the ReLU sign bits: input gradient through linear2 (+ dropout scale)
     "k384_f0": dict(K=384),                                     # K = 384 (24 k-steps): the frozen ViT-S/14's qkv projection (dino_preprocessors.py:27-35)
     "k384_f2": dict(K=384, gelu=True),                          # ... its fc1: bias + erf-GELU (asmgen/gelu_poly.py)
+    "k384_f1": dict(K=384, relu=True, bits_out=True),           # the visual compressor's first layer on the 384-wide DINOv2 features (bias, ReLU, sign bits)
 }
 if _os.environ.get("SVLA_ASM_DEBUG_VARIANTS"):      # timing-only / bisection builds (tools/time_nt_as.py)
     for _d in ("time", "time,nostore", "time,nodma", "time,noepi", "time,nox", "time,nobarwait", "time,noepi,nodma,nox"):

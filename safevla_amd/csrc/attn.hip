@@ -138,7 +138,9 @@ __device__ __forceinline__ bool masked(const AttnArgs& p, int q, int key, const 
 // of the last key tile is masked and the softmax runs in the exp2 domain with the scale folded in.
 // NW = waves per workgroup.  The long-sequence shapes (S > 256: the ViT's 433 tokens) need > 80 KiB of LDS for K and V, i.e. ONE workgroup
 // per CU: eight waves instead of four share that K/V image (2 waves per SIMD hide each other's latency; measured 1.5x on S = 433).
-template <int NKT, bool GENERIC, int NW = 4>
+// EXACT (round 5; the ViT's S = 433 with NKT = 28): S > (NKT - 1) * 16, so every key tile holds real keys and only the LAST one is ragged -- the per-tile
+// runtime predicates of the general form (28 unrolled wave-uniform conditions) cost 316 spilled SGPRs through v_readlane / v_writelane.
+template <int NKT, bool GENERIC, int NW = 4, bool EXACT = false>
 __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs p) {
     p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -189,7 +191,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            if (kt * 16 < S) {
+            if (EXACT || kt * 16 < S) {
                 a = mfma16(lds_row8i(Krow.lo, kt * 16), qf[0], a);
                 a = mfma16(lds_row8i(Krow.hi, kt * 16), qf[1], a);
             }
@@ -205,7 +207,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs p) {
                     mx = fmaxf(mx, s);
                 }
             } else {
-                const bool tail = (kt + 1) * 16 > S;      // wave-uniform: only the last (ragged) key tile needs masking
+                const bool tail = EXACT ? kt == NKT - 1 : (kt + 1) * 16 > S;      // wave-uniform: only the last (ragged) key tile needs masking
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float s = a[e] * sl2;
@@ -239,7 +241,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs p) {
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < NKT / 2; ++u) {
-            if (u * 32 < S) {
+            if (EXACT || u * 32 < S) {
                 const float pv[8] = {sc[2 * u][0], sc[2 * u][1], sc[2 * u][2], sc[2 * u][3],
                                      sc[2 * u + 1][0], sc[2 * u + 1][1], sc[2 * u + 1][2], sc[2 * u + 1][3]};
                 const bf16x8 pa = pack8(pv);
@@ -1219,8 +1221,13 @@ static int launch_fwd(const AttnArgs& p, int rows, hipStream_t st) {
     if constexpr (NKT >= 28) {           // one workgroup per CU (K + V > 80 KiB): eight waves share the LDS image
         if (!generic) {
             static bool attr8 = false;
-            if (!attr8) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr8 = true; }
-            hipLaunchKernelGGL((attn_fwd_kernel<NKT, false, 8>), dim3(rows * p.H), dim3(512), lds, st, p);
+            if (!attr8) {
+                HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT, false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr8 = true;
+            }
+            if (p.S > (NKT - 1) * 16 && p.Sq == p.S) hipLaunchKernelGGL((attn_fwd_kernel<NKT, false, 8, true>), dim3(rows * p.H), dim3(512), lds, st, p);      // the ViT's 433 tokens
+            else hipLaunchKernelGGL((attn_fwd_kernel<NKT, false, 8>), dim3(rows * p.H), dim3(512), lds, st, p);
             return svla_launch_status();
         }
     }

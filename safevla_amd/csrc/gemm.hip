@@ -1041,8 +1041,9 @@ static int nt_as_try(const GemmNtArgs& p, hipStream_t stream) {
         if (!p.drop.thr) name = "svla_nt_as_f1";
         else if ((unsigned long long)p.M * (unsigned long long)p.drop.row_mult * (unsigned long long)p.N / 2 < 0xffffffffull) name = "svla_nt_as_f1d";
     } else if (p.act == ACT_NONE && !p.bits_out && !p.drop.thr && p.alpha == 1.f) name = "svla_nt_as_f0";
-    if (p.K == 384) {      // the ViT-S width: bias (qkv) and bias + erf-GELU (fc1) flavours
+    if (p.K == 384) {      // the ViT-S / DINOv2-feature width: bias (qkv), bias + erf-GELU (fc1), bias + ReLU + sign bits (the policy's visual compressor)
         if (name && !strcmp(name, "svla_nt_as_f0")) name = "svla_nt_as_k384_f0";
+        else if (name && !strcmp(name, "svla_nt_as_f1")) name = "svla_nt_as_k384_f1";
         else if (!p.bits_in && p.act == ACT_GELU && !p.bits_out && !p.drop.thr && p.alpha == 1.f) name = "svla_nt_as_k384_f2";
         else name = nullptr;
     }

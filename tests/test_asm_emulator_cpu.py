@@ -171,6 +171,12 @@ def test_nt_as_k384_gelu_flavour_evaluates_the_shared_polynomial():
     assert np.abs(out - exact).max() <= 2.0 ** -8 * np.abs(exact).max() + 3e-5
 
 
+def test_nt_as_k384_relu_signbits():
+    out, ref, bits, _ = run_kernel("k384_f1", 512, 512, 1, K=384)
+    check(out, ref)
+    assert (bits == _bits_pack(out > 0, 512)).all() and (out >= 0).all()
+
+
 def test_nt_as_signbit_mask_alpha():
     out, ref, _, _ = run_kernel("f3", 512, 512, 1, alpha=1.0 / 0.9)
     check(out, ref)

@@ -749,7 +749,7 @@ def test_gemm_nt_assembly_kernels(ops, N, flavour):
 
 
 @pytest.mark.parametrize("M,N,K,flavour", [(256 * 45 + 64, 1536, 512, "bias"), (256 * 233, 2048, 512, "relu_drop_bits"), (256 * 60 + 5, 512, 512, "bits_in"),
-                                             (256 * 30, 1024, 512, "relu_bits"), (55424, 1152, 384, "bias"), (55424, 384, 384, "bias"), (55424, 1536, 384, "gelu")])
+                                             (256 * 30, 1024, 512, "relu_bits"), (55424, 1152, 384, "bias"), (55424, 384, 384, "bias"), (55424, 1536, 384, "gelu"), (256 * 600 + 9, 512, 384, "relu_bits")])
 def test_gemm_nt_assembly_mid_m_launches(ops, M, N, K, flavour):
     """Mid-M launches of the A-stationary kernels (round 5: an acting step's 45 row panels, the 233 of the batch-256 probe, the ViT-S/14's 216 at K = 384):
     grid = panel slots x n-ranges (workgroup_id_y sweeps its own N / nsplit columns), no phases.  Forced on (hook 2) so that every flavour is exercised
@@ -774,8 +774,8 @@ def test_gemm_nt_assembly_mid_m_launches(ops, M, N, K, flavour):
         _asm_off(ops, True)
         ops.gemm_nt(torch.where(mask, 1.0, -1.0).bfloat16(), torch.eye(N, device=DEV).bfloat16(), M, N, N, act=ops.ACT_RELU, relu_bits_out=bits)
         kw, want = dict(relu_bits=bits, alpha=1 / (1 - p)), torch.where(mask, acc / (1 - p), torch.zeros((), device=DEV))
-    want_name = {"bias": "svla_nt_as_f0" if K == 512 else "svla_nt_as_k384_f0", "relu_bits": "svla_nt_as_f1", "relu_drop_bits": "svla_nt_as_f1d", "bits_in": "svla_nt_as_f3",
-                 "gelu": "svla_nt_as_k384_f2"}[flavour]
+    want_name = {"bias": "svla_nt_as_f0" if K == 512 else "svla_nt_as_k384_f0", "relu_bits": "svla_nt_as_f1" if K == 512 else "svla_nt_as_k384_f1",
+                 "relu_drop_bits": "svla_nt_as_f1d", "bits_in": "svla_nt_as_f3", "gelu": "svla_nt_as_k384_f2"}[flavour]
     outs = []
     try:
         for mode in ("hip", "asm", "asm"):
