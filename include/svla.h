@@ -97,11 +97,17 @@ int svla_gemm_nt_bf16(const svla_bf16* A, long lda, const svla_bf16* B, long ldb
                       int out_f32, float alpha, unsigned char* relu_bits_out, const unsigned char* relu_bits,
                       const svla_dropout* drop, void* stream);
 /* Kernel choice behind svla_gemm_nt_bf16 (all the same arithmetic; bf16 output, fp32 accumulation, one rounding): generated gfx950 assembly for the row-streaming
- * shapes of the update -- K = 512 without a residual: A-stationary kernels (asmgen/nt_as_gen.py: bias / ReLU + sign bits [+ dropout] / sign-bit mask);
- * K >= 384 (K % 128 == 0, N % 256 == 0) without dropout: output-stationary kernels (asmgen/nt_os_gen.py: bias and / or residual); both from ~4 tiles per CU up,
- * M % 256 tail rows on the 128-tile kernel -- else the 8-phase 256-tile HIP kernel (>= 160 tiles), else the 128-tile HIP kernel.
- * Test / A-B hook: on = 1 forces the 128x128-tile kernel, 2 the 256-tile / assembly kernels wherever their shape constraints hold, 0 = normal dispatch;
- * on = 10 + flags: 8192 = every assembly kernel off, 16384 = the output-stationary ones off (tools/ab_*.py), smaller flags = timing-only ablations of the HIP kernels. */
+ * shapes of the update -- K = 512 without a residual: A-stationary kernels (asmgen/nt_as_gen.py: bias / ReLU + sign bits [+ dropout] / sign-bit mask), and their
+ * K = 384 flavours (bias / ReLU + sign bits / erf-GELU: the frozen ViT-S/14's qkv and fc1, the policy's visual compressor); K >= 384 (K % 128 == 0, N % 256 == 0)
+ * without dropout: output-stationary kernels (asmgen/nt_os_gen.py: bias and / or residual), from ~4 tiles per CU up.  The A-stationary kernels have two launch
+ * shapes: from two 256-row panels per CU up one persistent workgroup per CU sweeps all of N per panel; below that ("mid-M": the 233 panels of the batch-256 probe,
+ * the ViT's 216) the grid is (panel slots) x (n-ranges) and a cost model calibrated on profiles/r05_midm_sweep.txt decides between it and the tile kernels (an
+ * acting step's 45 panels stay on the tile kernels).  M % 256 tail rows run on the 128-tile kernel -- else the 8-phase 256-tile HIP kernel (>= 160 tiles), else
+ * the 128-tile HIP kernel.  ACT_GELU is the erf-GELU of nn.GELU() evaluated as x (1/2 + clamp(t P(z))) with a degree-9 polynomial (asmgen/gelu_poly.py:
+ * |error| <= 2.2e-5 for all x, exact tails) in every kernel.
+ * Test / A-B hook: on = 1 forces the 128x128-tile kernel, 2 the 256-tile / assembly kernels wherever their shape constraints hold (incl. the mid-M launch whatever the
+ * cost model says), 0 = normal dispatch; on = 10 + flags: 8192 = every assembly kernel off, 16384 = the output-stationary ones off (tools/ab_*.py), smaller flags =
+ * timing-only ablations of the HIP kernels.  Any value also performs the one-time device-side initialisation of the dispatchers (the binding calls it with 0 at load). */
 int svla_gemm_force_small_tile(int on);
 /* Test hook: name (NUL-terminated, at most cap - 1 characters) and dispatched M, N, K (mnk[3], may be NULL) of the kernel that the last
  * svla_gemm_nt_bf16 / svla_gemm_tn_f32acc call of this process launched for its main problem ("svla_nt_as_f0", "svla_nt_os_br", "svla_tn_os",

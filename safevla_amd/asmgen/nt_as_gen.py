@@ -1,4 +1,4 @@
-"""Generator of the A-stationary NT GEMM kernels for gfx950 (C[M,N] = epi(A[M,512] . W[N,512]^T), M % 256 == 0, N % 128 == 0).
+"""Generator of the A-stationary NT GEMM kernels for gfx950 (C[M,N] = epi(A[M,K] . W[N,K]^T), K = 512 or 384, M % 256 == 0, N % 128 == 0).
 
 Replaces, for the K = 512 linears of the fusion encoder (reference: nn.TransformerEncoder layers of
 architecture/models/allenact_transformer_models/allenact_dino_transformer.py:545-552,702-708 -- in_proj, out_proj, linear1, and the
@@ -23,6 +23,11 @@ input-gradient GEMM through linear2), the 256x256-tile kernel of csrc/gemm.hip. 
     CU switching in the same step that was a chip-wide burst of 256 KiB per CU (measured: the last step took 22.8 k cycles instead of 5 k);
     with phases the chip fetches A at a constant rate;
   * every s_waitcnt is counted by this generator from a model of the in-order VM / LGKM queues; amdasm.Emu checks the result.
+
+Round 5: (a) MID-M launches -- grid = (panel slots) x (n-ranges): workgroup_id_y = y sweeps columns [y nr, (y + 1) nr) of its panels (kernargs nr / flags; the
+prologue moves B / bias / C / sign-bit / dropout offsets to the range's first column, S_N becomes the range's width, S_NFULL keeps N for the global indexing), flags
+bit 0 switches the phases off (one panel per workgroup has nothing to de-phase); (b) K = 384 (24 k-steps: the gap positions of the schedule scale, a W row is 768
+bytes = 48 DMA lanes under an exec mask, LDS pitch unchanged); (c) the GELU flavour (asmgen/gelu_poly.py as packed-fp32 Horner chains in the MFMA gaps).
 
 The instruction stream is emitted by a list scheduler: each MFMA is followed by up to CAP "filler" groups taken from fixed slots
 (W fragment reads) and from ordered streams (LDS-DMA of the next W tile, epilogue of the previous step).  A group is emitted
