@@ -293,6 +293,45 @@ def kernel_sources_sha():
     return h.hexdigest()
 
 
+def live_traffic(M, N, K, flavour, kernel_substr, timeout=180):
+    """HBM bytes per launch of ONE GEMM shape measured in THIS run (the stored-profile figure is a claim about another run): tools/one_gemm.py under two
+    rocprofv3 passes -- --kernel-trace --pmc FETCH_SIZE, then WRITE_SIZE, separately, as MI355X_MICROARCH.md prescribes -- in child processes; counters are KiB and
+    FETCH_SIZE reports half of a wide coalesced stream on gfx950 (the same corrections as tools/prof_summarize.py).  Returns a dict or {"error": ...}; never raises."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None:
+        return {"error": "rocprofv3 not on PATH"}
+    out, tmp = {}, tempfile.mkdtemp(prefix="svla_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "x", "--", sys.executable, os.path.join(ROOT, "tools", "one_gemm.py"),
+                   str(M), str(N), str(K), "asm", "4", flavour]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return {"error": f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr[-200:]}"}
+            cur = sqlite3.connect(dbs[0]).cursor()
+            rows = cur.execute("select kernel_name, value, duration from counters_collection where counter_name=?", (counter,)).fetchall()
+            rows = [(v, du) for n_, v, du in rows if kernel_substr in n_]
+            if not rows:
+                return {"error": f"no {kernel_substr} dispatch in the {counter} pass"}
+            out[counter] = sum(v for v, _ in rows) / len(rows) * 1024.0
+            out["dur_us"] = sum(du for _, du in rows) / len(rows) / 1e3
+        fetch, write = 2.0 * out["FETCH_SIZE"], out["WRITE_SIZE"]
+        return {"kernel": kernel_substr, "M": M, "N": N, "K": K, "flavour": flavour, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+                "hbm_bytes_per_launch": fetch + write, "avg_duration_us_under_pmc": round(out["dur_us"], 1),
+                "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child-process passes of tools/one_gemm.py in this bench run); bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024"}
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def _stamped_profile(suffix):
     """newest profiles/*<suffix> measured on THIS build's kernel sources (hash-stamped), or (None, None)"""
     for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(suffix)), reverse=True):
@@ -488,6 +527,7 @@ def main():
                     "the default bench line is measured with the fp32 atomics")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="skip the two rocprofv3 --pmc child processes that measure roofline.traffic_live in this run (~1 min)")
     ap.add_argument("--no-cpu-c1", action="store_true", help="skip the full CPU timing of BASELINE configs[0] inside cpu_baseline (~1 min of host time)")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (the reference trains with the policy in train() mode: default here too)")
@@ -582,17 +622,31 @@ def main():
                 break
             except Exception:
                 pass
+        # the same quantity measured in THIS run, for the NT family's largest-share launch of the headline workload (linear1's forward: ReLU + dropout + sign bits,
+        # N = 2048, K = 512 over all local rows): two rocprofv3 --pmc child processes, ~1 min; --no-live-traffic skips it
+        traffic_live = None
+        if world == 1 and not args.no_live_traffic:
+            Ml = R * S
+            traffic_live = live_traffic(Ml, 2048, 512, "relu_drop_bits", "svla_nt_as_f1d")
+            if "error" not in traffic_live:
+                alg = 2.0 * Ml * (512 + 2048) + Ml * 2048 / 8
+                traffic_live.update(algorithmic_bytes_per_launch=alg, ratio_to_algorithmic=round(traffic_live["hbm_bytes_per_launch"] / alg, 3))
         families = None
         try:
             families = family_roofs(allk, ms)
         except Exception as e:
             families = {"error": repr(e)[:200]}
+        traffic_stored = traffic
+        if traffic_live and "error" not in traffic_live:
+            traffic = round(traffic_live["hbm_bytes_per_launch"])      # the figure measured in THIS run takes precedence over the stored profile's
         roof = {"bound": "mfma", "kernel": "svla_gemm_nt_bf16, row-streaming shapes: svla_nt_as_* (generated gfx950 assembly, A panel stationary in 256 AGPRs per wave, K = 512) + "
                                            "gemm_nt8p_bf16_kernel (HIP, persistent 256x256x64 tile, K > 512 / residual epilogues); all launches of one update, HIP events", "achieved": round(g["tflops"], 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(g["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_unit": (f"HBM bytes per launch of the family's largest-share (kernel, shape) -- traffic_shape -- (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/{traffic_src}, same kernel sources as this build)"
+                "traffic_unit": ("HBM bytes per launch of the family's largest-share (kernel, shape) of the headline workload, measured in THIS run: traffic_live (two rocprofv3 --pmc child passes); "
+                                 f"traffic_stored_profile / traffic_shape = the same quantity from profiles/{traffic_src} (same kernel sources as this build)" if (traffic_live and "error" not in traffic_live) else
+                                 f"HBM bytes per launch of the family's largest-share (kernel, shape) -- traffic_shape -- (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/{traffic_src}, same kernel sources as this build)"
                                  if traffic is not None else "null: no profiles/*_pmc_hbm_traffic_by_shape.json was measured on this build's kernel sources (tools/profile_round.sh)"),
-                "traffic_shape": traffic_shape,
+                "traffic_shape": traffic_shape, "traffic_live": traffic_live, "traffic_stored_profile": traffic_stored,
                 "launches_per_update": g["launches"], "avg_launch_ms": round(g["avg_ms"], 4), "flops_per_launch": g["flops"] / max(1, g["launches"]),
                 "share_of_update": round(g["total_s"] / (ms * 1e-3), 3),
                 "other_mfma_kernels": {k: {"achieved_tflops": round(v["tflops"], 1), "launches": v["launches"], "avg_launch_ms": round(v["avg_ms"], 4),
@@ -604,9 +658,13 @@ def main():
                 # the other roof: this GEMM family is d = 512 wide (<= 256 FLOP/B at N = K = 512, below the 312 FLOP/B ridge of 2.5 PF / 8 TB/s),
                 # so the HBM roof binds before the MFMA one; counter traffic per launch / live launch duration
                 # (tiny configurations launch none of the 256-tile kernels: no launch duration to divide by, and the profiled traffic is not theirs)
-                "hbm_view": None if traffic is None else {"achieved_TBps": round(traffic / (traffic_shape["avg_duration_us_profiled"] * 1e-6) / 1e12, 3), "peak_TBps": PEAK_HBM_TBPS,
-                                                          "frac": round(traffic / (traffic_shape["avg_duration_us_profiled"] * 1e-6) / 1e12 / PEAK_HBM_TBPS, 4),
-                                                          "note": "traffic_shape's bytes over ITS profiled launch duration"}}
+                "hbm_view": None if traffic_stored is None else {"achieved_TBps": round(traffic_stored / (traffic_shape["avg_duration_us_profiled"] * 1e-6) / 1e12, 3), "peak_TBps": PEAK_HBM_TBPS,
+                                                                 "frac": round(traffic_stored / (traffic_shape["avg_duration_us_profiled"] * 1e-6) / 1e12 / PEAK_HBM_TBPS, 4),
+                                                                 "note": "traffic_shape's bytes over ITS profiled launch duration"},
+                "hbm_view_live": None if not (traffic_live and "error" not in traffic_live) else {
+                    "achieved_TBps": round(traffic_live["hbm_bytes_per_launch"] / (traffic_live["avg_duration_us_under_pmc"] * 1e-6) / 1e12, 3), "peak_TBps": PEAK_HBM_TBPS,
+                    "frac": round(traffic_live["hbm_bytes_per_launch"] / (traffic_live["avg_duration_us_under_pmc"] * 1e-6) / 1e12 / PEAK_HBM_TBPS, 4),
+                    "note": "traffic_live's bytes over its launch duration under the counter pass (the same launch at ~1.0 PFLOP/s: d = 512 GEMMs sit at the ridge)"}}
     cpu = None
     acting = None
     ns = None
