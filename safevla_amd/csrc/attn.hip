@@ -138,8 +138,9 @@ __device__ __forceinline__ bool masked(const AttnArgs& p, int q, int key, const 
 // of the last key tile is masked and the softmax runs in the exp2 domain with the scale folded in.
 // NW = waves per workgroup.  The long-sequence shapes (S > 256: the ViT's 433 tokens) need > 80 KiB of LDS for K and V, i.e. ONE workgroup
 // per CU: eight waves instead of four share that K/V image (2 waves per SIMD hide each other's latency; measured 1.5x on S = 433).
-// EXACT (round 5; the ViT's S = 433 with NKT = 28): S > (NKT - 1) * 16, so every key tile holds real keys and only the LAST one is ragged -- the per-tile
-// runtime predicates of the general form (28 unrolled wave-uniform conditions) cost 316 spilled SGPRs through v_readlane / v_writelane.
+// EXACT (round 5; the ViT's S = 433 with NKT = 28, S = 257 with NKT = 18): S > (NKT - 2) * 16, so only the LAST TWO key tiles can hold padded keys (zero rows
+// in LDS, masked to -inf) -- the per-tile runtime predicates of the general form (28 unrolled wave-uniform conditions) cost 316 spilled SGPRs through
+// v_readlane / v_writelane.
 template <int NKT, bool GENERIC, int NW = 4, bool EXACT = false>
 __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs p) {
     p.drop = drop_resolve(p.drop);
@@ -207,7 +208,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs p) {
                     mx = fmaxf(mx, s);
                 }
             } else {
-                const bool tail = EXACT ? kt == NKT - 1 : (kt + 1) * 16 > S;      // wave-uniform: only the last (ragged) key tile needs masking
+                const bool tail = EXACT ? kt >= NKT - 2 : (kt + 1) * 16 > S;      // wave-uniform: only the last (ragged) key tiles need masking
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float s = a[e] * sl2;
@@ -1218,6 +1219,14 @@ static int launch_fwd(const AttnArgs& p, int rows, hipStream_t st) {
             return svla_launch_status();
         }
     }
+    if constexpr (NKT == 18) {           // S in (256, 288]: the ViT on 224 x 224 frames (16 x 16 patches + class token = 257): two workgroups per CU, exact tiles
+        if (!generic && p.S > (NKT - 2) * 16 && p.Sq == p.S) {
+            static bool attr18 = false;
+            if (!attr18) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT, false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr18 = true; }
+            hipLaunchKernelGGL((attn_fwd_kernel<NKT, false, 4, true>), dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
+            return svla_launch_status();
+        }
+    }
     if constexpr (NKT >= 28) {           // one workgroup per CU (K + V > 80 KiB): eight waves share the LDS image
         if (!generic) {
             static bool attr8 = false;
@@ -1226,7 +1235,7 @@ static int launch_fwd(const AttnArgs& p, int rows, hipStream_t st) {
                 HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT, false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 attr8 = true;
             }
-            if (p.S > (NKT - 1) * 16 && p.Sq == p.S) hipLaunchKernelGGL((attn_fwd_kernel<NKT, false, 8, true>), dim3(rows * p.H), dim3(512), lds, st, p);      // the ViT's 433 tokens
+            if (p.S > (NKT - 2) * 16 && p.Sq == p.S) hipLaunchKernelGGL((attn_fwd_kernel<NKT, false, 8, true>), dim3(rows * p.H), dim3(512), lds, st, p);      // the ViT's 433 tokens
             else hipLaunchKernelGGL((attn_fwd_kernel<NKT, false, 8>), dim3(rows * p.H), dim3(512), lds, st, p);
             return svla_launch_status();
         }
@@ -1307,6 +1316,7 @@ extern "C" int svla_attn_fwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t
     if (S <= 128) return launch_fwd<8>(p, rows, st);
     if (S <= 192) return launch_fwd<12>(p, rows, st);
     if (S <= 256) return launch_fwd<16>(p, rows, st);
+    if (S <= 288) return launch_fwd<18>(p, rows, st);
     if (S <= 448) return launch_fwd<28>(p, rows, st);
     return launch_fwd<32>(p, rows, st);
 }

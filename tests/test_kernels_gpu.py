@@ -356,7 +356,7 @@ def test_attn_t5_bias_and_padding(ops):
     _attn_case(ops, rows, S, H, bias=bias, kvalid=kvalid, scale=1.0, bwd=False)
 
 
-@pytest.mark.parametrize("S,H", [(433, 6), (257, 12), (300, 8), (448, 6), (449, 6), (512, 2)])
+@pytest.mark.parametrize("S,H", [(433, 6), (257, 12), (300, 8), (448, 6), (449, 6), (512, 2), (417, 6), (272, 6), (273, 6), (288, 4), (289, 4)])      # 417 / 273: exact-tile kernels with an all-padding last tile
 def test_attn_vit_length_fwd(ops, S, H):
     """S > 256 (ViT-S/14: 433 tokens, SigLIP-B/16: 257): the eight-wave long-sequence forward, both tile counts (28 / 32), ragged and full last tiles."""
     _attn_case(ops, 2, S, H, bwd=False)
