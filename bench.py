@@ -161,11 +161,16 @@ def north_star_probe(model, dev, rows_T=32, rows_B=8, L=64):
         once()
     executed = sum(v["flops"] for v in gt.summary().values())
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        once()
+    once()                      # (one untimed replay: the first pass after the recording still allocates)
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 3 * 1e3
+    reps = []
+    for _ in range(3):          # best of three groups of four: a single allocator / clock hiccup used to move a three-iteration mean by 30 %
+        t0 = time.perf_counter()
+        for _ in range(4):
+            once()
+        torch.cuda.synchronize()
+        reps.append((time.perf_counter() - t0) / 4 * 1e3)
+    ms = min(reps)
     U = int(st.observations["goal_token_ids"][:rows_T].reshape(R, -1).unique(dim=0).shape[0])
     fl = flops_per_update(R, 169 + L, L, U, 1)
     # the shape as north_star writes it -- "batch 256 x (2 x 3 x 224 x 224 + 64 tok)" -- includes the image encoder on two 224 x 224 frames per row: the
@@ -193,7 +198,7 @@ def north_star_probe(model, dev, rows_T=32, rows_B=8, L=64):
         torch.cuda.empty_cache()
     except Exception as e:
         as_written = {"error": repr(e)[:200]}
-    return {"rows": R, "goal_tokens": L, "ms_fwd_bwd_3_towers": round(ms, 2), "as_written_with_image_encoder": as_written,
+    return {"rows": R, "goal_tokens": L, "ms_fwd_bwd_3_towers": round(ms, 2), "ms_groups_of_four": [round(x, 2) for x in reps], "as_written_with_image_encoder": as_written,
             "executed_mfma_tflop": round(executed / 1e12, 2), "executed_tflops": round(executed / (ms * 1e-3) / 1e12, 1),
             "frac_of_bf16_mfma_peak": round(executed / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "reference_schedule_tflop": round(fl / 1e12, 2), "reference_schedule_frac_of_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
