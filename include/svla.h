@@ -155,7 +155,8 @@ int svla_attn_bwd_bf16(const svla_bf16* Q, const svla_bf16* K, const svla_bf16* 
                        void* stream);
 /* Test / A-B hook: 1 = the two-kernel backward (dQ kernel + dK/dV kernel, 12 head slices of HBM traffic per (row, head))
  * instead of the single-pass kernel (8 slices) on the unmasked exact-tile shapes; 2 = the single-pass kernel with its (row, head) items in row-major
- * order instead of whole rows per XCD (tools/attn_bwd_once.py: the mapping is worth 1.4 %). */
+ * order instead of whole rows per XCD (tools/attn_bwd_once.py: the mapping is worth 1.4 %); 4 = single-query forwards (Sq == 1 without bias / trajectory mask /
+ * dropout: the KV-cached acting step) on the tile kernels instead of the decode kernel that reads only the valid keys.  Bits combine. */
 int svla_attn_bwd_two_pass(int on);
 
 /* ---- recorded launch sequences --------------------------------------------------------------------------------------------------

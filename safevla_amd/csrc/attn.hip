@@ -1244,9 +1244,10 @@ static int launch_fwd(const AttnArgs& p, int rows, hipStream_t st) {
     else hipLaunchKernelGGL((attn_fwd_kernel<NKT, false>), dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
     return svla_launch_status();
 }
+static int g_attn_no_decode = 0;      // svla_attn_bwd_two_pass(4): single-query forwards on the tile kernels (A/B, tests)
 static int g_attn_bwd_two_pass = 0;   // svla_attn_bwd_two_pass(1): the dQ + dK/dV kernel pair instead of the single-pass kernel (A/B, tests)
 static int g_attn_xcd_rows = 1;       // svla_attn_bwd_two_pass(2): single-pass kernel with row-major items (A/B of the XCD mapping)
-extern "C" int svla_attn_bwd_two_pass(int on) { g_attn_bwd_two_pass = on & 1; g_attn_xcd_rows = !(on & 2); return 0; }
+extern "C" int svla_attn_bwd_two_pass(int on) { g_attn_bwd_two_pass = on & 1; g_attn_xcd_rows = !(on & 2); g_attn_no_decode = (on & 4) ? 1 : 0; return 0; }
 
 template <int NKT>
 static int launch_bwd(const AttnArgs& p, int rows, hipStream_t st) {
@@ -1297,6 +1298,99 @@ static int launch_bwd(const AttnArgs& p, int rows, hipStream_t st) {
     return svla_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------ single-query ("decode") forward
+// Sq == 1, no bias / trajectory mask / dropout: the KV-cached acting step of the llama decoder (one new token per env against a cache window of up to 500
+// slots of which kvalid marks the env's current episode; allenact_dino_transformer.py:388-397) and the pruned last fusion layer in eval mode.  The tile kernels
+// stage all S keys of K and V into LDS for that one query (128 KiB and 73 us per launch at S = 500, whatever the window); here a workgroup reads ONLY the valid keys,
+// straight from global memory: thread (g = tid / 8, c = tid % 8) owns the 16-byte chunk c of keys g, g + 32, ...; scores are reduced over the eight lanes of a key,
+// the softmax over the workgroup, P.V over the 32 key groups.  Same arithmetic as the MFMA path: bf16 products, fp32 accumulation, probabilities rounded to bf16
+// before the product with V.
+#define DEC_THREADS 256
+#define DEC_MAXB 16          // S <= 512: 16 blocks of 32 keys
+__global__ void __launch_bounds__(DEC_THREADS) attn_decode_kernel(AttnArgs p) {
+    __shared__ float red[4][2];
+    __shared__ float accs[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = tid >> 3, c = tid & 7;
+    const int r = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int S = p.S;
+    const size_t tok0 = (size_t)r * p.kv_rows;
+    const unsigned char* kvr = p.kvalid ? p.kvalid + (size_t)r * S : nullptr;
+    const float sl2 = p.scale * LOG2E;
+    float qv[8];
+    {
+        const bf16x8 q8 = *(const bf16x8*)(p.Q + (size_t)r * p.ldq + h * HD + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = bf2f((bf16_t)q8[e]);
+    }
+    const int nb = (S + 31) >> 5;
+    float sc[DEC_MAXB];
+    unsigned vmask = 0;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int b = 0; b < DEC_MAXB; ++b) {
+        sc[b] = -INFINITY;
+        if (b < nb) {
+            const int key = b * 32 + g;
+            const bool ok = key < S && (!kvr || kvr[key]);
+            if (ok) {
+                const bf16x8 k8 = *(const bf16x8*)(p.K + (tok0 + key) * p.ld + h * HD + c * 8);
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d = fmaf(qv[e], bf2f((bf16_t)k8[e]), d);
+                sc[b] = d;
+                vmask |= 1u << b;
+            }
+            // the eight lanes of a key hold its eight partial dot products (ok is uniform over them)
+            float d = ok ? sc[b] : 0.f;
+            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+            sc[b] = ok ? d * sl2 : -INFINITY;
+            mx = fmaxf(mx, sc[b]);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 8, 64)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (lane == 0) red[wid][0] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+    if (mx == -INFINITY) mx = 0.f;
+    float acc[8], lsum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int b = 0; b < DEC_MAXB; ++b) {
+        if (b < nb && ((vmask >> b) & 1u)) {
+            const float pr = __builtin_amdgcn_exp2f(sc[b] - mx);
+            lsum += pr;
+            const float pb = bf2f(f2bf(pr));                         // the MFMA path's operand rounding
+            const bf16x8 v8 = *(const bf16x8*)(p.V + (tok0 + b * 32 + g) * p.ld + h * HD + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(pb, bf2f((bf16_t)v8[e]), acc[e]);
+        }
+    }
+    // every key was counted by its eight lanes: sum over lanes / 8; the accumulators: over the lanes that share chunk c
+    lsum += __shfl_xor(lsum, 1, 64); lsum += __shfl_xor(lsum, 2, 64); lsum += __shfl_xor(lsum, 4, 64);
+    lsum += __shfl_xor(lsum, 8, 64); lsum += __shfl_xor(lsum, 16, 64); lsum += __shfl_xor(lsum, 32, 64);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float a = acc[e];
+        a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+        acc[e] = a;
+    }
+    if (lane == 0) red[wid][1] = lsum * 0.125f;
+    if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) accs[wid][lane * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const float ls = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        const float o = (accs[0][tid] + accs[1][tid]) + (accs[2][tid] + accs[3][tid]);
+        const float inv = ls > 0.f ? 1.f / ls : 0.f;
+        p.O[(size_t)r * p.ldo + h * HD + tid] = f2bf(o * inv);
+        if (p.LSE && tid == 0) p.LSE[(size_t)r * p.H + h] = (mx + __log2f(ls)) * LN2;
+    }
+}
+
 extern "C" int svla_attn_fwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t* V, long ld, bf16_t* O, long ldo, float* LSE,
                                   int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj,
                                   const float* bias, const unsigned char* kvalid, int Sq, long ldq, int kv_rows, const svla_dropout* drop,
@@ -1312,6 +1406,10 @@ extern "C" int svla_attn_fwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t
     p.drop = drop_cfg(drop);
     p.xcd_rows = 0;      // (measured on the persistent forward: +1.5 % time with whole rows per XCD -- its next-item prefetch already hides the fetch; -1.4 % on the backward)
     hipStream_t st = (hipStream_t)stream;
+    if (p.Sq == 1 && !bias && mask_mode == MASK_NONE && !p.drop.thr && !g_attn_no_decode) {      // one query per row: read the valid keys only (KV-cached acting step)
+        hipLaunchKernelGGL(attn_decode_kernel, dim3(rows * H), dim3(DEC_THREADS), 0, st, p);
+        return svla_launch_status();
+    }
     if (S <= 64) return launch_fwd<4>(p, rows, st);
     if (S <= 128) return launch_fwd<8>(p, rows, st);
     if (S <= 192) return launch_fwd<12>(p, rows, st);

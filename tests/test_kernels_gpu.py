@@ -356,6 +356,47 @@ def test_attn_t5_bias_and_padding(ops):
     _attn_case(ops, rows, S, H, bias=bias, kvalid=kvalid, scale=1.0, bwd=False)
 
 
+@pytest.mark.parametrize("S,kv_rows,window", [(500, 500, (37, 121)), (500, 500, (0, 499)), (45, 500, (3, 44)), (181, 181, None), (64, 64, (10, 10)), (500, 500, "none")])
+def test_attn_single_query_decode_kernel(ops, S, kv_rows, window):
+    """The single-query forward (Sq == 1: the KV-cached acting step of the llama decoder, allenact_dino_transformer.py:388-397; the pruned last fusion layer in
+    eval mode) on the decode kernel that reads only the valid keys, against the tile kernels (hook 4) and fp32 torch: cache windows per row (kvalid), a cache
+    larger than the attended length (kv_rows), all keys valid, a single valid key, NO valid key (output 0), and the log-sum-exp."""
+    from safevla_amd._lib import lib
+    rows, H, D = 5, 8, 512
+    kv = bf(rnd(rows * kv_rows, 2 * D, seed=71)).to(DEV).bfloat16()
+    q = bf(rnd(rows, 3 * D, seed=72)).to(DEV).bfloat16()
+    kvalid = None
+    if window is not None:
+        kvalid = torch.zeros(rows, S, dtype=torch.uint8, device=DEV)
+        if window != "none":
+            for r in range(rows):
+                lo, hi = min(window[0] + r, window[1]), window[1]
+                kvalid[r, lo:hi + 1] = 1
+    outs = {}
+    try:
+        for hook in (4, 0):
+            lib().call("svla_attn_bwd_two_pass", hook)
+            o, lse = ops.attn_fwd(q, kv, kv[:, D:], 2 * D, rows, S, H, 0.125, kvalid=kvalid, save_lse=True, Sq=1, ldq=3 * D, kv_rows=kv_rows)
+            torch.cuda.synchronize()
+            outs[hook] = (o.float(), lse.clone())
+    finally:
+        lib().call("svla_attn_bwd_two_pass", 0)
+    K = kv[:, :D].float().view(rows, kv_rows, H, 64)[:, :S]; V = kv[:, D:].float().view(rows, kv_rows, H, 64)[:, :S]
+    sc = torch.einsum("rhd,rshd->rhs", q[:, :D].float().view(rows, H, 64), K) * 0.125
+    if kvalid is not None:
+        sc = sc.masked_fill(~kvalid.bool()[:, None, :], float("-inf"))
+    pr = torch.softmax(sc, -1).nan_to_num(0.0)
+    want = torch.einsum("rhs,rshd->rhd", pr, V).reshape(rows, D)
+    close(outs[0][0], want, 1e-2, 1e-2, "decode kernel vs fp32 torch")
+    close(outs[0][0], outs[4][0], 1e-2, 2e-3, "decode kernel vs tile kernel")
+    if window != "none":
+        ok = torch.isfinite(outs[4][1])
+        assert torch.allclose(outs[0][1][ok], outs[4][1][ok], rtol=1e-4, atol=1e-4)
+        assert torch.allclose(outs[0][1].view(rows, H), torch.logsumexp(sc, -1), rtol=1e-3, atol=1e-3)
+    else:
+        assert (outs[0][0] == 0).all()
+
+
 @pytest.mark.parametrize("S,H", [(433, 6), (257, 12), (300, 8), (448, 6), (449, 6), (512, 2), (417, 6), (272, 6), (273, 6), (288, 4), (289, 4)])      # 417 / 273: exact-tile kernels with an all-padding last tile
 def test_attn_vit_length_fwd(ops, S, H):
     """S > 256 (ViT-S/14: 433 tokens, SigLIP-B/16: 257): the eight-wave long-sequence forward, both tile counts (28 / 32), ragged and full last tiles."""
