@@ -512,6 +512,73 @@ def secondary_config(model, dev, name, task, T, B, L, env_chunk, cost_limit, fp8
             "lagrangian_multiplier": round(info["lagrangian_multiplier"], 6), "Jc": round(info["Jc"], 4)}
 
 
+class _EnvWithImageEncoder:
+    """SynthVectorEnv whose observations carry what the frozen image encoder makes of two uint8 camera frames per env (a fixed synthetic frame batch: the content
+    is irrelevant to the timing), the way the reference's sensor preprocessors run inside the rollout (dino_preprocessors.py:38-125)."""
+
+    def __init__(self, env, vit, frames):
+        self.env, self.vit, self.frames, self.B = env, vit, frames, env.B
+
+    def _encode(self, obs):
+        self.vit.process_tokens_all_cameras(self.frames, obs["dino_tokens"])      # both cameras of all envs in one pass of the frozen trunk
+        return obs
+
+    def reset(self):
+        return self._encode(self.env.reset())
+
+    def step(self, actions, want_results=False):
+        obs, reward, cost, done, res = self.env.step(actions, want_results)
+        return self._encode(obs), reward, cost, done, res
+
+    def pop_episode_costs(self):
+        return self.env.pop_episode_costs()
+
+
+def collect_then_update(model, dev, T=256, B=64, L=12, task="PickUp", cost_limit=2.31964, iters=2):
+    """The whole training iteration as training/online/dinov2_vits_tsfm_base.py runs it (safevla_amd/train.py): collect T steps from B synthetic environments through
+    the ACTING path (KV-cached single-step 3-tower forward, action sampling, env.step, storage.add), then one full PPO-Lagrangian update on that rollout.  Two variants:
+    pre-encoded DINOv2 features from the environment, and two uint8 frames per env and step through the frozen ViT-S/14 inside the rollout (what the reference's sensor
+    preprocessors do).  One untimed iteration, then `iters` timed ones; env-steps/s of the loop and its split."""
+    from safevla_amd.engine import PPOLagConfig, PPOLagEngine
+    from safevla_amd.preproc import DinoViTPreprocessor
+    from safevla_amd.storage import RolloutStorage
+    from safevla_amd.synth_env import SynthVectorEnv, collect_rollout
+
+    out = {"workload": f"{task}, {B} envs x {T} steps collected through the acting path (synthetic vector env) + one full 3-tower update, {iters} timed iterations"}
+    for variant in ("pre_encoded_features", "with_image_encoder"):
+        env = SynthVectorEnv(B, L=L, task=task, seed=99, max_steps=500, device=dev)
+        if variant == "with_image_encoder":
+            vit = DinoViTPreprocessor("rgb_raw", "rgb_dinov2", device=dev)
+            env = _EnvWithImageEncoder(env, vit, torch.randint(0, 256, (2 * B, 224, 384, 3), device=dev, dtype=torch.uint8))
+        st = RolloutStorage(T, device=dev, store_tokens=True)
+        st.initialize(env.reset(), num_samplers=B)
+        eng = PPOLagEngine(model, PPOLagConfig(cost_limit=cost_limit))
+        for t in model.towers:
+            t.time_step_counter, t._kv = 0, None
+        tc = tu = 0.0
+        for it in range(iters + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nxt = collect_rollout(model, env, st, T)
+            s_, n_ = env.pop_episode_costs()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            eng.update(st, nxt["next_value"], nxt["next_c_value"], s_, n_)
+            st.after_updates()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if it > 0:
+                tc += t1 - t0
+                tu += t2 - t1
+        out[variant] = {"env_steps_per_s": round(iters * T * B / (tc + tu), 1), "collect_s_per_iteration": round(tc / iters, 3), "update_s_per_iteration": round(tu / iters, 3),
+                        "collect_ms_per_step_of_all_envs": round(tc / iters / T * 1e3, 3)}
+        del eng, st, env
+        torch.cuda.empty_cache()
+    for t in model.towers:
+        t.time_step_counter, t._kv = 0, None
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -673,6 +740,7 @@ def main():
     cpu = None
     acting = None
     ns = None
+    loop = None
     secondary = None
     if rank == 0 and world == 1 and not args.no_secondary:
         # secondary measurements must never take the headline line down: each one is guarded on its own
@@ -688,6 +756,7 @@ def main():
         del st, nxt
         torch.cuda.empty_cache()
         ns = guarded(north_star_probe, model, dev)
+        loop = guarded(collect_then_update, model, dev)
         secondary = [guarded(secondary_config, model, dev, "C4-shard: one GPU's 32 envs of BASELINE configs[3] (Fetch, 256 envs over 8 GPUs)", "Fetch", 256, 32, 12, None, 2.31964),
                      guarded(secondary_config, model, dev, "C2: BASELINE configs[1] (ObjectNav, 32 envs x 128 steps)", "ObjectNav", 128, 32, 12, None, 2.31964),
                      guarded(secondary_config, model, dev, "C5-shard: mixed ObjectNav+PickUp+Fetch sampler (env e -> task e mod 3), 64-token instructions, 32 envs/GPU", "Mixed", 256, 32, 64, None, 2.31964),
@@ -733,7 +802,7 @@ def main():
                "note": "reference_equivalent counts SURVEY 8(d) FLOPs of the reference's schedule; the engine executes fewer (last fusion "
                        "layer only for the consumed token, T5 once per unique goal) -- see roofline.executed_mfma_*",
                "loss": {k: (round(v, 5) if isinstance(v, float) else v) for k, v in info.items()},
-               "roofline": roof, "cpu_baseline": cpu, "acting": acting, "north_star_batch256": ns, "secondary": secondary}
+               "roofline": roof, "cpu_baseline": cpu, "acting": acting, "collect_then_update": loop, "north_star_batch256": ns, "secondary": secondary}
         for sc in (secondary or []):      # the reference-faithful noise statistics right beside the headline
             if isinstance(sc, dict) and "reference-faithful" in sc.get("workload", ""):
                 out["value_with_reference_faithful_t5_dropout"] = {"value": sc.get("env_steps_per_s"), "ms_per_update": sc.get("ms_per_update"),

@@ -213,6 +213,18 @@ class _ViTPreprocessorBase:
         ops.adaptive_pool_tokens(x, frames_u8.shape[0], 1 if self.vit.has_cls else 0, gh, gw, self.vit.dim, 7, 12, cam=cam, ncam=ncam, tok_out=out_tokens)
 
 
+    @torch.no_grad()
+    def process_tokens_all_cameras(self, frames_u8: torch.Tensor, out_tokens: torch.Tensor):
+        """frames_u8 [ncam * B, H, W, 3] (camera-major: all envs' frames of camera 0, then camera 1, ...) -> out_tokens [B, ncam, 84, C] in ONE pass of the trunk
+        (the rollout's two cameras share the frozen encoder: one 2B-frame batch fills the GPU better than two B-frame batches)."""
+        B, ncam = out_tokens.shape[0], out_tokens.shape[1]
+        assert frames_u8.shape[0] == ncam * B
+        x = self._tokens(frames_u8.to(self.device))
+        gh, gw = self._rt_grid()
+        for cam in range(ncam):
+            ops.adaptive_pool_tokens(x[cam * B:(cam + 1) * B], B, 1 if self.vit.has_cls else 0, gh, gw, self.vit.dim, 7, 12, cam=cam, ncam=ncam, tok_out=out_tokens)
+
+
 class DinoViTPreprocessor(_ViTPreprocessorBase):
     """dino_preprocessors.py:38-125: 224 x 384 frames, W crop [3:-3], DINOv2 ``x_norm_patchtokens`` -> (B, C, 16, 27) -> pool (7, 12)."""
 
