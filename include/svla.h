@@ -109,6 +109,13 @@ int svla_gemm_nt_bf16(const svla_bf16* A, long lda, const svla_bf16* B, long ldb
  * cost model says), 0 = normal dispatch; on = 10 + flags: 8192 = every assembly kernel off, 16384 = the output-stationary ones off (tools/ab_*.py), smaller flags =
  * timing-only ablations of the HIP kernels.  Any value also performs the one-time device-side initialisation of the dispatchers (the binding calls it with 0 at load). */
 int svla_gemm_force_small_tile(int on);
+/* RMSNorm(A) . W'^T for small M: C[m, n] = epi(rstd[m] * sum_k A[m, k] W'[n, k]), rstd[m] = rsqrt(mean_k A[m, k]^2 + eps), W' = W diag(gamma) folded by the
+ * caller -- the pre-norm linears of the frozen T5 encoder block (T5LayerNorm -> q | k | v, -> wi: allenact_dino_transformer.py:506-508 runs HF's T5EncoderModel) and of
+ * the llama decoder block (RMSNorm -> wq | wk | wv, -> w1 | w3: training/online/third_party_models/llama/model.py:28-71,170-467) in a KV-cached acting step, where the
+ * norm was a launch of its own in front of every such GEMM.  128-tile kernel (the row sums of squares fall out of the A fragments its MFMAs read); epi = +bias[n] ->
+ * act -> dropout -> +residual as in svla_gemm_nt_bf16; bf16 output. */
+int svla_gemm_nt_rmsa_bf16(const svla_bf16* A, long lda, const svla_bf16* B, long ldb, const float* bias, const svla_bf16* residual, long ldr,
+                           void* C, long ldc, int M, int N, int K, int act, float eps, const svla_dropout* drop, void* stream);
 /* Test hook: name (NUL-terminated, at most cap - 1 characters) and dispatched M, N, K (mnk[3], may be NULL) of the kernel that the last
  * svla_gemm_nt_bf16 / svla_gemm_tn_f32acc call of this process launched for its main problem ("svla_nt_as_f0", "svla_nt_os_br", "svla_tn_os",
  * "gemm_nt8p_bf16_kernel", "gemm_nt_bf16_kernel", ...): the kernel-choice tests assert the generated assembly really ran (same cited layers). */

@@ -55,6 +55,8 @@ struct GemmNtArgs {
     int row0;         // global row index of A's row 0 (dropout counter / sign-bit block of the M-tail sub-problem behind the assembly kernels); 128-tile kernel only
     int dbg;          // timing-only ablations of the 256-tile kernel (tools/ab_gemm.py, tools/shape_gemm.py): 1 = no C stores,
                       // 2 = no epilogue, 64 = no fragment reads / MFMAs (operand DMA stream + barriers alone)
+    float rms_eps;    // > 0 (svla_gemm_nt_rmsa_bf16, 128-tile kernel only): row m of the product is scaled by rsqrt(mean_k A[m,k]^2 + rms_eps) -- RMSNorm(A) . W^T
+                      // with the norm's gamma folded into W; the row sums of squares fall out of the A fragments the MFMAs read anyway
 };
 
 // ReLU sign bits live in a kernel-private blocked layout: [ceil(M/32)][N/64][32 rows][8 bytes]: the 64 bits of (row m, 64-column
@@ -172,6 +174,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p)
     for (int s = 0; s < NST - 1; ++s)
         if (s < nk) stage(s, s * BK);
     const int fr = lane & 31, fh = lane >> 5;
+    float ssq[2] = {0.f, 0.f};          // rms_eps > 0: sum of squares of A rows wm*64 + t*32 + fr over this lane's half of every 16-wide k-step
     for (int kt = 0; kt < nk; ++kt) {
         const int rem = nk - 1 - kt;       // tiles issued after tile kt that may stay in flight
         if (rem >= NST - 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -201,6 +204,22 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = mfma32(fb[kk][j], fa[kk][i], acc[i][j]);
+        if (p.rms_eps > 0.f) {             // wave-uniform
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float a = bf2f((bf16_t)fa[kk][t][e]); ssq[t] = fmaf(a, a, ssq[t]); }
+        }
+    }
+    float rrow[2] = {1.f, 1.f};         // the accumulators of block row i belong to A row wm*64 + i*32 + fr: the row this lane summed
+    if (p.rms_eps > 0.f) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float s = ssq[t] + __shfl_xor(ssq[t], 32, 64);      // the two k-halves of a step sit in lanes fr and fr + 32
+            rrow[t] = rsqrtf(s / (float)p.K + p.rms_eps);
+        }
     }
     __syncthreads();   // all MFMA reads of the operand stages are done before the epilogue reuses the LDS
 
@@ -221,7 +240,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p)
                     float* op = (float*)&o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float v = acc[i][j][rg * 4 + e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f);
+                        float v = acc[i][j][rg * 4 + e] * (p.alpha * rrow[i]) + (p.bias ? p.bias[n + e] : 0.f);
                         if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
                         else if (p.act == ACT_GELU) v = gelu_f(v);
                         if (p.relu_mask && !(bf2f(p.relu_mask[(size_t)m * p.ldm + n + e]) > 0.f)) v = 0.f;
@@ -247,7 +266,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p)
                 const int nl = wn * 64 + j * 32 + 8 * rg + 4 * fh;
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e] * p.alpha;
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e] * (p.alpha * rrow[i]);
                 *(f32x4*)(Cs + (wm * 64 + i * 32 + fr) * CS + nl) = v;
             }
     __syncthreads();
@@ -1203,7 +1222,7 @@ extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, lon
     if ((relu_bits && (relu_mask || residual || out_f32)) || (relu_bits_out && (act != ACT_RELU || out_f32 || residual || relu_mask || relu_bits))) return SVLA_EINVAL;
     if (act < ACT_NONE || act > ACT_GELU) return SVLA_EINVAL;
     if ((lda % 8) || (ldb % 8) || (ldc % (out_f32 ? 4 : 8)) || (residual && (ldr % 8)) || (relu_mask && (ldm % 8))) return SVLA_EINVAL;
-    GemmNtArgs p{A, lda, B, ldb, bias, residual, ldr, relu_mask, ldm, C, ldc, M, N, K, act, out_f32, alpha, relu_bits_out, relu_bits, drop_cfg(drop), 0, g_dbg};
+    GemmNtArgs p{A, lda, B, ldb, bias, residual, ldr, relu_mask, ldm, C, ldc, M, N, K, act, out_f32, alpha, relu_bits_out, relu_bits, drop_cfg(drop), 0, g_dbg, 0.f};
     {
         const int rc = nt_as_try(p, (hipStream_t)stream);      // K = 512 row-streaming GEMMs: the A-stationary assembly kernels
         if (rc != NT_AS_NOT_TAKEN) return rc;
@@ -1232,6 +1251,26 @@ extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, lon
     gemm_log("gemm_nt_bf16_kernel", M, N, K, 0, false);
     const int mt = (M + BM - 1) / BM, nt = N / BN;
     const size_t lds = BM * (BN + 4) * sizeof(float);  // 66 KiB: max(NST operand stages 64 KiB, fp32 epilogue tile)
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(mt * nt), dim3(NTHREADS), lds, (hipStream_t)stream, p);
+    return svla_launch_status();
+}
+
+// RMSNorm(A) . W^T for small M (the frozen T5 encoder's and the llama decoder's pre-norm linears in an acting step: M = 64 ... 768 rows, where the norm was a
+// launch of its own in front of every such GEMM): 128-tile kernel, the row statistics fall out of the A fragments, gamma is folded into W by the caller.
+extern "C" int svla_gemm_nt_rmsa_bf16(const bf16_t* A, long lda, const bf16_t* B, long ldb, const float* bias, const bf16_t* residual, long ldr,
+                                      void* C, long ldc, int M, int N, int K, int act, float eps, const svla_dropout* drop, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || (N % BN) || (K % BK) || !(eps > 0.f)) return SVLA_EINVAL;
+    if (act < ACT_NONE || act > ACT_GELU) return SVLA_EINVAL;
+    if ((lda % 8) || (ldb % 8) || (ldc % 8) || (residual && (ldr % 8))) return SVLA_EINVAL;
+    GemmNtArgs p{A, lda, B, ldb, bias, residual, ldr, nullptr, 0, C, ldc, M, N, K, act, 0, 1.f, nullptr, nullptr, drop_cfg(drop), 0, 0, eps};
+    gemm_log("gemm_nt_bf16_kernel", M, N, K, 0, false);
+    const int mt = (M + BM - 1) / BM, nt = N / BN;
+    const size_t lds = BM * (BN + 4) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

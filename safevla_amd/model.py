@@ -257,6 +257,26 @@ class Tower(nn.Module):
         for key, ps, (n, k) in self._gemm_weights():
             off, _ = ar.offsets[id(ps[0])]
             ops.transpose_cast_bf16(ar.flat_p[off:off + n * k].view(n, k), self._wt[key])
+        self._wg_dirty = True
+
+    def refresh_folded(self):
+        """W * gamma[None, :] (bf16) of the llama decoder's pre-norm linears -- RMSNorm(x) @ W^T = rstd(x) * (x @ (W gamma)^T) -- for the acting step's norm-fused
+        GEMMs (ops.gemm_nt_rmsa).  Persistent buffers refreshed IN PLACE (recorded acting steps hold their addresses), lazily: only an acting step after an
+        optimiser step / load_state_dict pays for it."""
+        if self.adt != BF16 or not getattr(self, "_wg_dirty", True):
+            return
+        ar = self.arena
+        if not hasattr(self, "_wg"):
+            self._wg = {}
+        for i, l in enumerate(self.decoder.layers):
+            a, f = l.attention, l.feed_forward
+            for key, first, n, gamma in ((f"d{i}.qkv", a.wq.weight, 3 * D, l.attention_norm.weight), (f"d{i}.w13", f.w1.weight, 3072, l.ffn_norm.weight)):
+                off, _ = ar.offsets[id(first)]
+                w32 = ar.flat_p[off:off + n * D].view(n, D)
+                if key not in self._wg:
+                    self._wg[key] = torch.empty(n, D, device=self.device_, dtype=BF16)
+                self._wg[key].copy_(w32 * gamma.detach().float()[None, :])
+        self._wg_dirty = False
 
     def _drop_sites(self):
         """Dropout descriptors of one forward pass: site(layer, k), k = 0 attention probabilities, 1 attention sub-layer output,
@@ -387,9 +407,15 @@ class Tower(nn.Module):
                     ar = self._ar_steps
                     kvalid = ((ar[None, :] <= t_dev) & (ar[None, :] >= torch.clamp(t_dev - prep.time_step, min=0)[:, None])).to(torch.uint8).contiguous()
                 S_att = self.max_steps
+            fused = self.adt == BF16      # bf16 product path: RMSNorm folded into the following GEMM (one launch instead of two)
+            if fused:
+                self.refresh_folded()
             for i, l in enumerate(self.decoder.layers):
-                n1, _, _ = ops.norm_fwd(xd, l.attention_norm.weight, None, 1e-5, B, rms=True, save_stats=False)
-                qkv = ops.gemm_nt(n1, w[f"d{i}.qkv"], B, 3 * D, D)
+                if fused:
+                    qkv = ops.gemm_nt_rmsa(xd, self._wg[f"d{i}.qkv"], B, 3 * D, D, 1e-5)
+                else:
+                    n1, _, _ = ops.norm_fwd(xd, l.attention_norm.weight, None, 1e-5, B, rms=True, save_stats=False)
+                    qkv = ops.gemm_nt(n1, w[f"d{i}.qkv"], B, 3 * D, D)
                 cache = self._kv[i]
                 if t_dev is None:
                     cache[:B, t].copy_(qkv[:, D:])
@@ -401,8 +427,11 @@ class Tower(nn.Module):
                 ao, _ = ops.attn_fwd(qkv, cv, cv[:, D:], 2 * D, B, S_att, 8, 0.125, kvalid=kvalid, save_lse=False, Sq=1, ldq=3 * D,
                                      kv_rows=self.max_steps)
                 h = ops.gemm_nt(ao, w[f"d{i}.wo"], B, D, D, residual=xd)
-                n2, _, _ = ops.norm_fwd(h, l.ffn_norm.weight, None, 1e-5, B, rms=True, save_stats=False)
-                ab = ops.gemm_nt(n2, w[f"d{i}.w13"], B, 3072, D)
+                if fused:
+                    ab = ops.gemm_nt_rmsa(h, self._wg[f"d{i}.w13"], B, 3072, D, 1e-5)
+                else:
+                    n2, _, _ = ops.norm_fwd(h, l.ffn_norm.weight, None, 1e-5, B, rms=True, save_stats=False)
+                    ab = ops.gemm_nt(n2, w[f"d{i}.w13"], B, 3072, D)
                 gg = ops.swiglu_fwd(ab, B, 1536)
                 xd = ops.gemm_nt(gg, w[f"d{i}.w2"], B, D, 1536, residual=h)
             self.time_step_counter += 1
@@ -665,9 +694,13 @@ class T5Frozen(nn.Module):
         rt = []
         for b in self.encoder.block:
             sa, ff = b.layer[0].SelfAttention, b.layer[1].DenseReluDense
-            rt.append(dict(qkv=torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], 0).to(dtype).contiguous(),
+            qkv32 = torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], 0).float()
+            g0, g1 = b.layer[0].layer_norm.weight.float(), b.layer[1].layer_norm.weight.float()
+            rt.append(dict(qkv=qkv32.to(dtype).contiguous(),
                            o=sa.o.weight.to(dtype).contiguous(), wi=ff.wi.weight.to(dtype).contiguous(),
-                           wo=ff.wo.weight.to(dtype).contiguous()))
+                           wo=ff.wo.weight.to(dtype).contiguous(),
+                           # T5LayerNorm folded into the following linear for the norm-fused small-M GEMMs (ops.gemm_nt_rmsa): W * gamma[None, :]
+                           qkv_g=(qkv32 * g0[None, :]).to(dtype).contiguous(), wi_g=(ff.wi.weight.float() * g1[None, :]).to(dtype).contiguous()))
         self._rt, self._rt_dtype = rt, dtype
         self._bias_cache.clear()
 
@@ -707,15 +740,22 @@ class T5Frozen(nn.Module):
         ops.dropout_(x, site(62))
         bias = self.position_bias(L)
         kvalid = attn_mask if attn_mask.dtype == torch.uint8 else attn_mask.to(torch.uint8).contiguous()   # uint8 given: no torch op (recorded steps)
+        fused = dtype == BF16 and n <= 8192      # small passes (an acting step's 64 goals x 12 tokens; an update's unique goals): norm + GEMM in one launch
         for i, (b, rt) in enumerate(zip(self.encoder.block, self._rt)):
             s0 = self.T5_STREAM + 4 * i
-            nrm, _, _ = ops.norm_fwd(x, b.layer[0].layer_norm.weight, None, 1e-6, n, rms=True, save_stats=False)
-            qkv = ops.gemm_nt(nrm, rt["qkv"], n, 3 * D, D)
+            if fused:
+                qkv = ops.gemm_nt_rmsa(x, rt["qkv_g"], n, 3 * D, D, 1e-6)
+            else:
+                nrm, _, _ = ops.norm_fwd(x, b.layer[0].layer_norm.weight, None, 1e-6, n, rms=True, save_stats=False)
+                qkv = ops.gemm_nt(nrm, rt["qkv"], n, 3 * D, D)
             ao, _ = ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, U, L, self.h, 1.0, bias=bias, kvalid=kvalid, save_lse=False,
                                  drop=site(s0))
             x = ops.gemm_nt(ao, rt["o"], n, D, D, residual=x, drop=site(s0 + 1))
-            nrm, _, _ = ops.norm_fwd(x, b.layer[1].layer_norm.weight, None, 1e-6, n, rms=True, save_stats=False)
-            hdn = ops.gemm_nt(nrm, rt["wi"], n, 2048, D, act=ops.ACT_RELU, drop=site(s0 + 2))
+            if fused:
+                hdn = ops.gemm_nt_rmsa(x, rt["wi_g"], n, 2048, D, 1e-6, act=ops.ACT_RELU, drop=site(s0 + 2))
+            else:
+                nrm, _, _ = ops.norm_fwd(x, b.layer[1].layer_norm.weight, None, 1e-6, n, rms=True, save_stats=False)
+                hdn = ops.gemm_nt(nrm, rt["wi"], n, 2048, D, act=ops.ACT_RELU, drop=site(s0 + 2))
             x = ops.gemm_nt(hdn, rt["wo"], n, D, 2048, residual=x, drop=site(s0 + 3))
         out, _, _ = ops.norm_fwd(x, self.encoder.final_layer_norm.weight, None, 1e-6, n, rms=True, save_stats=False)
         ops.dropout_(out, site(63))
@@ -984,6 +1024,8 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
             for k_old in [k_ for k_ in self._acting_graphs if k_[4] != key[4]]:      # plans of replaced KV caches keep B x max_steps x 1024 x layers x 3 alive
                 del self._acting_graphs[k_old]
             self._acting_graphs[key] = st
+        for t in self.towers:
+            t.refresh_folded()          # (recorded / captured steps do not run the Python that would notice an optimiser step: refresh the gamma-folded weights here, in place)
         # per-step inputs -> static buffers
         st.tokens.copy_(prep.tokens); st.prev_actions.copy_(prep.prev_actions); st.masks.copy_(prep.masks); st.hand.copy_(prep.hand)
         st.time_step.copy_(prep.time_step)

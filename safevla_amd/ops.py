@@ -297,6 +297,18 @@ def gemm_nt(A, B, M, N, K, bias=None, residual=None, relu_mask=None, act=ACT_NON
     return out
 
 
+def gemm_nt_rmsa(A, Bg, M, N, K, eps, bias=None, residual=None, act=ACT_NONE, out=None, drop=None):
+    """out[M, N] = epi(RMSNorm(A) @ W^T) with the norm's gamma already folded into ``Bg`` = W * gamma[None, :] (bf16): small-M path (128-tile kernel), the row
+    statistics come out of the GEMM's own A fragments -- no separate norm launch."""
+    _chk(A, BF16, "A")
+    _chk(Bg, BF16, "B")
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=BF16)
+    lib().call("svla_gemm_nt_rmsa_bf16", _p(A), A.stride(-2), _p(Bg), Bg.stride(-2), _p(bias), _p(residual), residual.stride(-2) if residual is not None else 0,
+               _p(out), out.stride(-2), M, N, K, int(act), float(eps), _d(drop), _stream())
+    return out
+
+
 def relu_bits_bytes(M: int, N: int) -> int:
     """Size of the opaque ReLU sign-bit buffer of gemm_nt(..., relu_bits_out=) (SVLA_RELU_BITS_BYTES in svla.h)."""
     return ((M + 31) // 32) * 32 * (N // 8)

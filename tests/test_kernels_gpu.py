@@ -356,6 +356,23 @@ def test_attn_t5_bias_and_padding(ops):
     _attn_case(ops, rows, S, H, bias=bias, kvalid=kvalid, scale=1.0, bwd=False)
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 1536, 512), (768, 2048, 512), (130, 512, 512), (64, 3072, 512)])
+def test_gemm_nt_rmsnorm_fused(ops, M, N, K):
+    """svla_gemm_nt_rmsa_bf16: RMSNorm(A) @ W^T with gamma folded into W and the row statistics taken from the GEMM's own A fragments (the pre-norm linears of
+    the frozen T5 block and of the llama decoder block in an acting step), against fp32 torch and against the two-launch path (norm kernel, then GEMM)."""
+    A = bf(rnd(M, K, seed=81, scale=1.7)).to(DEV).bfloat16(); W = bf(rnd(N, K, seed=82, scale=0.05)).to(DEV).bfloat16()
+    gamma = (1.0 + 0.2 * rnd(K, seed=83)).to(DEV)
+    res = bf(rnd(M, N, seed=84)).to(DEV).bfloat16()
+    Wg = (W.float() * gamma[None, :]).bfloat16()
+    got = ops.gemm_nt_rmsa(A, Wg, M, N, K, 1e-5, residual=res, act=ops.ACT_RELU)
+    a32 = A.float()
+    want = torch.relu((a32 * torch.rsqrt((a32 * a32).mean(-1, keepdim=True) + 1e-5)) @ Wg.float().t()) + res.float()
+    close(got.float(), want, 1e-2, 2e-2, "norm-fused GEMM vs fp32 torch")
+    n1, _, _ = ops.norm_fwd(A, gamma, None, 1e-5, M, rms=True, save_stats=False)
+    two = ops.gemm_nt(n1, W, M, N, K, residual=res, act=ops.ACT_RELU)
+    close(got.float(), two.float(), 2e-2, 3e-2, "norm-fused GEMM vs norm kernel + GEMM")
+
+
 @pytest.mark.parametrize("S,kv_rows,window", [(500, 500, (37, 121)), (500, 500, (0, 499)), (45, 500, (3, 44)), (181, 181, None), (64, 64, (10, 10)), (500, 500, "none")])
 def test_attn_single_query_decode_kernel(ops, S, kv_rows, window):
     """The single-query forward (Sq == 1: the KV-cached acting step of the llama decoder, allenact_dino_transformer.py:388-397; the pruned last fusion layer in
