@@ -216,14 +216,16 @@ class _Layers(nn.Module):
 
 class RefGoalEncoder(nn.Module):
     def __init__(self, tokenizer: Callable, d=512, dino_dim=384, n_layers=3, n_heads=8, dropout=0.0,
-                 goal_uuid="natural_language_spec", nav_uuid="rgb_dinov2", manip_uuid="manipulation_rgb_dinov2"):
+                 goal_uuid="natural_language_spec", nav_uuid="rgb_dinov2", manip_uuid="manipulation_rgb_dinov2", text_encoder=None, text_dim=512):
+        """``text_encoder``: None = frozen t5-small (the RL towers, the IL t5 presets); else a module (oracle.ref_siglip_text.RefSigLIPText for the IL
+        ``siglip_*`` presets, text_cond_visual_encoder.py:35-45) whose feature width is ``text_dim`` (``TEXT_ENCODER_DIMS``, :24-32)."""
         super().__init__()
         self.goal_uuid, self.nav_uuid, self.manip_uuid = goal_uuid, nav_uuid, manip_uuid
         self.tokenizer = tokenizer
-        self.text_encoder = RefT5Encoder()
+        self.text_encoder = RefT5Encoder() if text_encoder is None else text_encoder
         for p in self.text_encoder.parameters():
             p.requires_grad_(True)  # the reference leaves requires_grad on; it is frozen only by no_grad
-        self.text_adapter = nn.Sequential(nn.Linear(512, d), nn.LayerNorm(d), nn.ReLU())
+        self.text_adapter = nn.Sequential(nn.Linear(text_dim, d), nn.LayerNorm(d), nn.ReLU())
         self.fusion_token = nn.Parameter(0.1 * torch.rand(d))
         self.visual_sensor_token_raw_navigation_camera = nn.Parameter(0.1 * torch.rand(d))
         self.visual_sensor_token_raw_manipulation_camera = nn.Parameter(0.1 * torch.rand(d))

@@ -1,15 +1,17 @@
 """Offline imitation-learning workload on the same kernels.
 
-Mirrors ``EarlyFusionCnnTransformer`` in its ``small_3`` configuration with the llama decoder
-(/root/reference/architecture/models/transformer_models/early_fusion_tsfm_models.py:49-207,221-226): text-conditioned multi-camera
+Mirrors ``EarlyFusionCnnTransformer`` with the llama decoder, in every ``model_version`` whose transformers are 512 wide
+(/root/reference/architecture/models/transformer_models/early_fusion_tsfm_models.py:49-207,221-312; ``VERSIONS`` below): text-conditioned multi-camera
 encoder (text_cond_visual_encoder.py:56-268) -> + last-action / in-hand / time embeddings (:120-157) -> causal llama decoder ->
 ``actor`` -> ``nn.CrossEntropyLoss(ignore_index=-1)`` (:93,115-117); and the optimiser of ``training/offline/train_pl.py:283-287``
 (AdamW, lr 1e-4).  It IS one tower of the RL model -- the RL towers are initialised from exactly these weights
 (``checkpoint.init_towers_from_il``) -- so the forward/backward run the update path's kernel schedules (``model.Tower``); new here:
 the batch-first IL batch format, the fused cross-entropy kernel and decoupled weight decay in the Adam kernel.
 
-The frozen image encoder stays outside, as on the RL path: visual sensors are either pre-encoded DINOv2 features ``[B,T,384,7,12]``
-or uint8 frames ``[B,T,H,W,3]`` (then ``preproc.DinoViT`` runs first).  ``state_dict`` uses the reference's names
+The frozen image encoder stays outside, as on the RL path: visual sensors are either pre-encoded features ``[B,T,C,7,12]`` (C = 384 DINOv2-S,
+768 DINOv2-B / SigLIP-B, 1024 SigLIP-L, 2048 CLIP RN50) or uint8 frames ``[B,T,H,W,3]`` (then the frozen ViT of ``preproc`` runs first: DINOv2 on
+224 x 384, SigLIP on 256 x 256 frames).  The frozen text encoder is t5-small or, for the ``siglip_*`` presets, the SigLIP text tower
+(``siglip_text.SigLIPTextFrozen``: ``goals`` is then the tokenizer's id tensor [B, 64], preprocessors.py:334-343).  ``state_dict`` uses the reference's names
 (``actor.weight``, no critic head), so Lightning checkpoints (``model.`` prefix) interchange.
 """
 from typing import Dict, Optional
@@ -43,19 +45,25 @@ class _CEFn(torch.autograd.Function):
 
 
 class EarlyFusionCnnTransformer(Tower):
-    # model_version -> (fusion layers, decoder layers, image-feature width); early_fusion_tsfm_models.py:221-240.  All at d = 512 with the
-    # llama decoder and the t5-small text encoder.  The 768-wide transformers (base_6, siglip_base_*_6 ...), the SigLIP text encoder variants,
-    # the nonTx encoders and clip_resnet_50_3 are not built.
-    VERSIONS = {"small": (3, 3, 384), "small_3": (3, 3, 384), "small_6": (6, 6, 384), "base_3": (3, 3, 768)}
+    # model_version -> (fusion layers, decoder layers, image-feature width, text encoder); early_fusion_tsfm_models.py:221-312.  Every preset whose
+    # fusion transformer and decoder are TransformerConfig(n, 512, 8), with the llama decoder (``use_llama_decoder`` defaults to True, :46):
+    # DINOv2-S / -B, SigLIP-B / -L (image trunk + text tower) and CLIP RN50 (pre-encoded features only: its conv trunk is not built).
+    # Not built: the 768-wide transformers (base_6 = 8 heads of 96; siglip_base_3_6 / _6_3 / _6_6 / _12_12) and the nonTx encoders
+    # (small_3_nonTxEnc, siglip_base_3_nonTxEnc).  ``siglip_base_384_3`` / ``siglip_base_384_resize_3`` name image encoders that the reference's own
+    # IMAGE_ENCODERS table (image_encoders.py:103-112) does not contain -- they cannot be built there either.
+    VERSIONS = {"small": (3, 3, 384, "t5-small"), "small_3": (3, 3, 384, "t5-small"), "small_6": (6, 6, 384, "t5-small"), "base_3": (3, 3, 768, "t5-small"),
+                "siglip_base_3": (3, 3, 768, "SigLIPBase"), "siglip_3": (3, 3, 768, "SigLIPBase"), "siglip_base_3_llama": (3, 3, 768, "SigLIPBase"),
+                "siglip_base_6": (6, 6, 768, "SigLIPBase"), "siglip_large_3": (3, 3, 1024, "SigLIPLarge"), "clip_resnet_50_3": (3, 3, 2048, "t5-small")}
 
     def __init__(self, device="cuda", max_length: int = 1000, input_sensors=(NAV, MANIP, "last_actions", "an_object_is_in_hand"),
-                 image_preprocessor=None, n_fusion_layers: int = 3, n_decoder_layers: int = 3, dino_dim: int = DINO):
+                 image_preprocessor=None, n_fusion_layers: int = 3, n_decoder_layers: int = 3, dino_dim: int = DINO, text_encoder: str = "t5-small"):
         if not torch.cuda.is_available():
             raise RuntimeError("safevla_amd needs an MI355X: there is no CPU or eager fallback for the policy kernels")
         ops.lib()
         arena = _Arena()
         device = torch.device(device)
-        super().__init__(arena, device, n_fusion_layers=n_fusion_layers, n_decoder_layers=n_decoder_layers, max_steps=max_length, dino_dim=dino_dim)
+        super().__init__(arena, device, n_fusion_layers=n_fusion_layers, n_decoder_layers=n_decoder_layers, max_steps=max_length, dino_dim=dino_dim,
+                         text_encoder=text_encoder)
         arena.build(device)
         self.bind()
         self.towers = [self]
@@ -116,8 +124,7 @@ class EarlyFusionCnnTransformer(Tower):
             x = batch[key].to(dev)
             if x.dtype == torch.uint8:                           # raw frames [B,T,H,W,3] -> frozen ViT
                 if self.image_preprocessor is None:
-                    from .preproc import DinoViTPreprocessor
-                    self.image_preprocessor = DinoViTPreprocessor(key, key, dino_model_type={384: "dinov2_vits14", 768: "dinov2_vitb14", 1024: "dinov2_vitl14"}[self.dino_dim], device=dev)
+                    self.image_preprocessor = self._frozen_image_encoder(key, dev)
                 fr = x.transpose(0, 1).reshape(R, *x.shape[2:]).contiguous()
                 self.image_preprocessor.process_tokens(fr, p.tokens, cam)
             else:                                                # pre-encoded features [B,T,384,7,12]
@@ -129,12 +136,27 @@ class EarlyFusionCnnTransformer(Tower):
         p.hand = tb(batch["an_object_is_in_hand"]).to(torch.int64) if "an_object_is_in_hand" in batch else torch.zeros(R, device=dev, dtype=torch.int64)
         p.time_step = tb(batch["time_ids"]).to(torch.int64)
         p.traj_bt = torch.arange(B, device=dev, dtype=torch.int32)[:, None].expand(B, T).contiguous()   # one trajectory per row: causal
-        p.ids = batch["goals"]["input_ids"].to(dev).to(torch.int64).contiguous()
-        p.attn_mask = batch["goals"]["attention_mask"].to(dev).to(torch.int64).contiguous()
+        goals = batch["goals"]
+        if self.text_encoder_name == "t5-small":                 # HF tokenizer output (preprocessors.py:157-163)
+            p.ids = goals["input_ids"].to(dev).to(torch.int64).contiguous()
+            p.attn_mask = goals["attention_mask"].to(dev).to(torch.int64).contiguous()
+            p.U, p.L = p.ids.shape
+        else:                                                    # open_clip tokenizer output: ids [B, context] (preprocessors.py:334-343); + the pooled token
+            p.ids = (goals["input_ids"] if isinstance(goals, dict) else goals).to(dev).to(torch.int64).contiguous()
+            p.attn_mask = torch.ones_like(p.ids)
+            p.U, p.L = p.ids.shape[0], self.visual_encoder.text_encoder.out_tokens(p.ids.shape[1])
         p.gid = (torch.arange(R, device=dev) % B).to(torch.int32).contiguous()
-        p.U, p.L = p.ids.shape
         p.S = TEXT_OFF + p.L
         return p
+
+    def _frozen_image_encoder(self, key, dev):
+        """IMAGE_ENCODERS of image_encoders.py:103-112 for raw uint8 frames, by preset: DINOv2 (224 x 384) or the SigLIP trunk (256 x 256)."""
+        from .preproc import DinoViTPreprocessor, SigLIPPreprocessor
+        if self.text_encoder_name.startswith("SigLIP"):
+            return SigLIPPreprocessor(key, key, siglip_model_type={768: "ViT-B-16-SigLIP-256", 1024: "ViT-L-16-SigLIP-256"}[self.dino_dim], device=dev)
+        if self.dino_dim == 2048:
+            raise NotImplementedError("clip_resnet_50_3: the CLIP RN50 conv trunk is not built; pass its pre-encoded (2048, 7, 12) features")
+        return DinoViTPreprocessor(key, key, dino_model_type={384: "dinov2_vits14", 768: "dinov2_vitb14", 1024: "dinov2_vitl14"}[self.dino_dim], device=dev)
 
     # ---- reference forward API --------------------------------------------------------------------------------------------------
     def forward(self, batch: Dict) -> Dict[str, torch.Tensor]:
@@ -152,10 +174,10 @@ class EarlyFusionCnnTransformer(Tower):
     def build_model(cls, model_version="small_3", input_sensors=(NAV, MANIP, "last_actions", "an_object_is_in_hand"), loss="action",
                     device="cuda", ckpt_pth: Optional[str] = None, ckpt_prefix: str = "model."):
         if model_version not in cls.VERSIONS:
-            raise NotImplementedError(f"model_version {model_version!r}: built are {sorted(cls.VERSIONS)} (DINOv2-S/B features, t5-small text, d = 512 "
-                                      "fusion + llama decoder; early_fusion_tsfm_models.py:221-240)")
-        nf, nd, dd = cls.VERSIONS[model_version]
-        m = cls(device=device, input_sensors=input_sensors, n_fusion_layers=nf, n_decoder_layers=nd, dino_dim=dd)
+            raise NotImplementedError(f"model_version {model_version!r}: built are {sorted(cls.VERSIONS)} (512-wide fusion transformer + llama decoder; "
+                                      "early_fusion_tsfm_models.py:221-312)")
+        nf, nd, dd, te = cls.VERSIONS[model_version]
+        m = cls(device=device, input_sensors=input_sensors, n_fusion_layers=nf, n_decoder_layers=nd, dino_dim=dd, text_encoder=te)
         if ckpt_pth is not None:    # Lightning checkpoint (training/offline/train_utils.py:6-68)
             sd = torch.load(ckpt_pth, map_location="cpu")["state_dict"]
             m.load_state_dict({k[len(ckpt_prefix):]: v for k, v in sd.items() if k.startswith(ckpt_prefix)}, strict=False)

@@ -36,6 +36,7 @@ D = 512
 DINO = 384
 NPATCH = 84          # 7 x 12 grid per camera
 TEXT_OFF = 1 + 2 * NPATCH
+TEXT_ENCODER_DIMS = {"t5-small": 512, "SigLIPBase": 768, "SigLIPLarge": 1024}
 BF16, F32 = torch.bfloat16, torch.float32
 import os as _os0
 _NO_COMPRESSOR_BITS = _os0.environ.get("SVLA_NO_COMPRESSOR_BITS", "0") == "1"     # A/B switch of the 1-bit compressor ReLU masks
@@ -128,9 +129,14 @@ class Tower(nn.Module):
     """``DinoLLAMATxNavActorCritic`` (full-sensor configuration of dinov2_vits_tsfm_base.py:234-270)."""
 
     def __init__(self, arena: _Arena, device, n_fusion_layers=3, n_decoder_layers=3, max_steps=500, critic_type="linear",
-                 precision="bf16", dino_dim=DINO):
+                 precision="bf16", dino_dim=DINO, text_encoder="t5-small"):
         super().__init__()
-        self.dino_dim = dino_dim          # channel width of the frozen image features: 384 (ViT-S/14), 768 (ViT-B/14, SigLIP-B), 1024 (ViT-L)
+        self.dino_dim = dino_dim          # channel width of the frozen image features: 384 (ViT-S/14), 768 (ViT-B/14, SigLIP-B), 1024 (ViT-L), 2048 (CLIP RN50)
+        # frozen text encoder and the width of its features (text_cond_visual_encoder.py:24-45 ``TEXT_ENCODER_DIMS`` / ``create_text_encoder``): the RL towers
+        # and the t5 presets of the IL model use t5-small; the IL model's ``siglip_*`` presets the SigLIP text tower (tokens + pooled token, siglip_text.py)
+        if text_encoder not in TEXT_ENCODER_DIMS:
+            raise NotImplementedError("Only SigLIP and T5 text encoders are supported.")
+        self.text_encoder_name, self.text_dim = text_encoder, TEXT_ENCODER_DIMS[text_encoder]
         if precision not in ("bf16", "fp32"):
             raise ValueError(f"precision must be 'bf16' (MFMA product path) or 'fp32' (verification mode), got {precision!r}")
         # activation / GEMM-operand dtype.  "fp32" = the verification mode: the same schedule on the fp32 twins of every kernel
@@ -160,7 +166,7 @@ class Tower(nn.Module):
         dec(ve, "visual_sensor_token_raw_navigation_camera", (D,), "tok")   # adjacent: [2, 512] camera-token table
         dec(ve, "visual_sensor_token_raw_manipulation_camera", (D,), "tok")
         ve.text_adapter = _seq(3)
-        dec(ve.text_adapter[0], "weight", (D, 512), "lin"); dec(ve.text_adapter[0], "bias", (D,), "zeros")
+        dec(ve.text_adapter[0], "weight", (D, self.text_dim), "lin"); dec(ve.text_adapter[0], "bias", (D,), "zeros")
         dec(ve.text_adapter[1], "weight", (D,), "ones"); dec(ve.text_adapter[1], "bias", (D,), "zeros")
         ve.visual_compressor = _seq(4)
         dec(ve.visual_compressor[0], "weight", (D, dino_dim, 1, 1), "lin"); dec(ve.visual_compressor[0], "bias", (D,), "zeros")
@@ -181,7 +187,11 @@ class Tower(nn.Module):
             l.norm1 = _NS(); dec(l.norm1, "weight", (D,), "ones"); dec(l.norm1, "bias", (D,), "zeros")
             l.norm2 = _NS(); dec(l.norm2, "weight", (D,), "ones"); dec(l.norm2, "bias", (D,), "zeros")
             ve.fusion_xformer.layers.append(l)
-        ve.text_encoder = T5Frozen(device)
+        if text_encoder == "t5-small":
+            ve.text_encoder = T5Frozen(device)
+        else:
+            from .siglip_text import SIGLIP_TEXT_PRESETS, SigLIPTextFrozen
+            ve.text_encoder = SigLIPTextFrozen(device, **SIGLIP_TEXT_PRESETS[text_encoder])
         self.object_in_hand_embed = _NS(); dec(self.object_in_hand_embed, "weight", (3, D), "emb")
         self.last_actions_embed = _NS(); dec(self.last_actions_embed, "weight", (N_ACTIONS + 2, D), "emb")
         self.time_encoder = _NS()
@@ -227,7 +237,7 @@ class Tower(nn.Module):
         """(key, parameter(s), [N, K]) for every MFMA GEMM weight of the tower."""
         ve = self.visual_encoder
         out = [("c1", [ve.visual_compressor[0].weight], (D, self.dino_dim)), ("c2", [ve.visual_compressor[2].weight], (D, D)),
-               ("va", [ve.visual_adapter[0].weight], (D, D)), ("ta", [ve.text_adapter[0].weight], (D, 512))]
+               ("va", [ve.visual_adapter[0].weight], (D, D)), ("ta", [ve.text_adapter[0].weight], (D, self.text_dim))]
         for i, l in enumerate(ve.fusion_xformer.layers):
             out += [(f"f{i}.in", [l.self_attn.in_proj_weight], (3 * D, D)), (f"f{i}.out", [l.self_attn.out_proj.weight], (D, D)),
                     (f"f{i}.l1", [l.linear1.weight], (2048, D)), (f"f{i}.l2", [l.linear2.weight], (D, 2048))]
@@ -336,9 +346,9 @@ class Tower(nn.Module):
         else:
             t5 = ve.text_encoder.encode(prep.ids, getattr(prep, "attn_mask_u8", None) if getattr(prep, "attn_mask_u8", None) is not None else prep.attn_mask,
                                         drop_seed=t5_seed, drop_p=self.dropout_p, dtype=self.adt,
-                                        seed_dev=getattr(self, "_seed_dev", None))   # [U*L, 512], frozen
+                                        seed_dev=getattr(self, "_seed_dev", None))   # [U*L, text_dim], frozen (SigLIP: ids are [U, L - 1], the pooled token is row L - 1)
             self._t5_cache = (key, t5) if (t5_seed is None and key is not None) else (None, None)
-        ta = ops.gemm_nt(t5, w["ta"], U * L, D, 512, bias=ve.text_adapter[0].bias)
+        ta = ops.gemm_nt(t5, w["ta"], U * L, D, self.text_dim, bias=ve.text_adapter[0].bias)
         tf, ta_mean, ta_rstd = ops.norm_fwd(ta, ve.text_adapter[1].weight, ve.text_adapter[1].bias, 1e-5, U * L, relu=True)
         ops.fusion_fill(ve.fusion_token, tf, prep.gid, x, R, S, L, TEXT_OFF)
         c.update(c1=c1, c2=c2, c1b=c1b, c2b=c2b, a1=a1, va=(va_mean, va_rstd), t5=t5, ta=ta, ta_stats=(ta_mean, ta_rstd))
@@ -641,7 +651,7 @@ class Tower(nn.Module):
         ops.cast_bf16(dtf, dtf_b)
         dta = ops.norm_bwd(dtf_b, c["ta"], ve.text_adapter[1].weight, ve.text_adapter[1].bias, c["ta_stats"][0], c["ta_stats"][1], U * L,
                            g(ve.text_adapter[1].weight), g(ve.text_adapter[1].bias), relu=True)
-        ops.gemm_tn_acc(dta, c["t5"], dw["ta"], U * L, D, 512, db=g(ve.text_adapter[0].bias))
+        ops.gemm_tn_acc(dta, c["t5"], dw["ta"], U * L, D, self.text_dim, db=g(ve.text_adapter[0].bias))
         # visual adapter + compressor (both cameras in one batch)
         da1 = ops.norm_bwd(dx0, c["a1"], ve.visual_adapter[1].weight, ve.visual_adapter[1].bias, c["va"][0], c["va"][1], M2,
                            g(ve.visual_adapter[1].weight), g(ve.visual_adapter[1].bias), relu=True, dtok=self._dcamtok,

@@ -15,13 +15,15 @@ from . import ops, parallel
 from .il import MANIP, NAV, PAD_TOKEN, START_TOKEN, EarlyFusionCnnTransformer, ILTrainer
 
 
-def synthetic_batch(B: int, T: int, L: int, device, generator: torch.Generator, raw_frames: bool = False):
+def synthetic_batch(B: int, T: int, L: int, device, generator: torch.Generator, raw_frames: bool = False, feat_dim: int = 384, siglip: bool = False):
+    """``siglip``: 256 x 256 frames and the open_clip tokenizer's goal format (an id tensor [B, 64] padded with 1, preprocessors.py:300-343)."""
     g = generator
     r = lambda *s, hi: torch.randint(0, hi, s, device=device, generator=g)
     if raw_frames:
-        nav, man = r(B, T, 224, 384, 3, hi=256).to(torch.uint8), r(B, T, 224, 384, 3, hi=256).to(torch.uint8)
+        H, W = (256, 256) if siglip else (224, 384)
+        nav, man = r(B, T, H, W, 3, hi=256).to(torch.uint8), r(B, T, H, W, 3, hi=256).to(torch.uint8)
     else:
-        nav, man = (torch.randn(B, T, 384, 7, 12, device=device, generator=g) for _ in range(2))
+        nav, man = (torch.randn(B, T, feat_dim, 7, 12, device=device, generator=g) for _ in range(2))
     valid = torch.randint(max(2, T // 2), T + 1, (B,), device=device, generator=g)
     tt = torch.arange(T, device=device)[None, :].expand(B, T)
     pad = tt >= valid[:, None]
@@ -35,8 +37,11 @@ def synthetic_batch(B: int, T: int, L: int, device, generator: torch.Generator, 
     ids = torch.where(lt == (n_tok[:, None] - 1), torch.ones_like(ids), ids)
     am = (lt < n_tok[:, None]).to(torch.int64)
     ids = ids * am
+    if siglip:
+        ids64 = torch.ones(B, 64, device=device, dtype=ids.dtype)
+        ids64[:, :L] = torch.where(am > 0, ids, torch.ones_like(ids))
     return {NAV: nav, MANIP: man, "time_ids": tt.contiguous(), "padding_mask": pad, "last_actions": last, "actions": actions,
-            "an_object_is_in_hand": r(B, T, hi=3), "goals": dict(input_ids=ids, attention_mask=am)}
+            "an_object_is_in_hand": r(B, T, hi=3), "goals": ids64 if siglip else dict(input_ids=ids, attention_mask=am)}
 
 
 def main():
@@ -69,7 +74,7 @@ def main():
     steps = max(1, args.max_samples // (B * world))
     t0 = time.perf_counter()
     for it in range(steps):
-        batch = synthetic_batch(B, T, args.goal_tokens, dev, gen, args.raw_frames)
+        batch = synthetic_batch(B, T, args.goal_tokens, dev, gen, args.raw_frames, feat_dim=model.dino_dim, siglip=model.text_encoder_name.startswith("SigLIP"))
         model.zero_grad()
         out = model(batch)
         (out["loss"] / world).backward()

@@ -167,3 +167,31 @@ def test_g8_imitation_learning_model_vs_reference():
             assert np.allclose(got, g["gp:" + name], rtol=2e-3, atol=1e-6), (name, got, g["gp:" + name])
             n += 1
     assert n == sum(k.startswith("gp:") for k in g)
+
+
+def test_g9_imitation_learning_siglip_preset_vs_reference():
+    """oracle.ref_il.RefEarlyFusion in the ``siglip_base_3`` configuration vs the reference's own model around the (third-party, restated)
+    SigLIP text tower: [tokens, pooled] concatenation, 768 -> 512 text adapter, 768-channel compressor, fusion over 1 + 168 + 65 tokens."""
+    from oracle.detfill import fill_state_dict, grad_probe
+    from oracle.ref_il import RefEarlyFusion
+
+    g = dict(np.load(os.path.join(G, "g9_il_siglip.npz"), allow_pickle=False))
+    m = RefEarlyFusion(dino_dim=768, text_encoder="SigLIPBase").eval()
+    want = {l.split("\t")[0]: l.rstrip("\n").split("\t")[1] for l in open(os.path.join(G, "state_dict_manifest_il_siglip.txt"))}
+    have = {k: str(tuple(v.shape)) for k, v in m.state_dict().items()}
+    assert have == want
+    fill_state_dict(m, seed=11, share_t5=False)
+    batch = {k: torch.from_numpy(g[k].astype(np.float32) if g[k].dtype == np.float16 else g[k])
+             for k in ("raw_navigation_camera", "raw_manipulation_camera", "time_ids", "an_object_is_in_hand", "actions", "last_actions", "padding_mask")}
+    batch["goals"] = torch.from_numpy(g["goal_ids"])
+    out = m(batch)
+    out["loss"].backward()
+    assert np.allclose(out["actions_logits"].detach().numpy(), g["logits"], rtol=2e-4, atol=2e-4)
+    assert abs(out["loss"].item() - float(g["loss"])) < 1e-5
+    n = 0
+    for name, p in m.named_parameters():
+        if "gp:" + name in g:
+            got = np.array(grad_probe(name, p.grad))
+            assert np.allclose(got, g["gp:" + name], rtol=2e-3, atol=1e-6), (name, got, g["gp:" + name])
+            n += 1
+    assert n == sum(k.startswith("gp:") for k in g) == 84
