@@ -63,7 +63,7 @@ int svla_ce_loss_fwd_bwd_f32(const float* logits, const long* target, int rows, 
 
 /* ---- heads ------------------------------------------------------------------------------------------------ */
 /* LinearActorHead / LinearCriticHead [3P AllenAct] applied at
- * architecture/models/allenact_transformer_models/allenact_dino_transformer.py:441-474.  D must be 512, N <= 20.
+ * architecture/models/allenact_transformer_models/allenact_dino_transformer.py:441-474.  D <= 1024 (a multiple of 8; 512 for the policy), N <= 20.
  * T > 0: x rows are (b*T + t) (decoder layout), out rows are (t*B + b). */
 int svla_small_linear_fwd_f32(const float* x, const float* W, const float* bias, int rows, int N, int D, int T, int B,
                               float* out, void* stream);
@@ -71,7 +71,7 @@ int svla_small_linear_bwd_f32(const float* x, const float* W, const float* dout,
                               int accumulate_dx, float* dx, float* dW, float* db, void* stream);
 
 /* ---- normalisation ---------------------------------------------------------------------------------------- */
-/* LayerNorm (rms=0) / RMSNorm (rms=1) rows of width D.  Forward widths 384 / 512 / 768 / 1024 (frozen ViT-S / policy / ViT-B + SigLIP-B / ViT-L), backward 512.  Row maps (G,GS,OFF): logical row m is
+/* LayerNorm (rms=0) / RMSNorm (rms=1) rows of width D.  Forward widths 384 / 512 / 768 / 1024 (frozen ViT-S / policy / ViT-B + SigLIP-B + the 768-wide IL presets / ViT-L), backward 512 / 768.  Row maps (G,GS,OFF): logical row m is
  * memory row (m/G)*GS + OFF + m%G (G = 0: identity).  Optional fused ReLU and per-group token add: the
  * "Linear -> LayerNorm -> ReLU (+ camera token)" adapters (allenact_dino_transformer.py:509-513,539-543,672-688);
  * nn.TransformerEncoderLayer norm1/norm2 (:545-552); llama RMSNorm (training/online/third_party_models/llama/model.py:28-71). */
@@ -219,21 +219,22 @@ int svla_attn_fp8_bwd(const unsigned char* ws, const float* scales, const svla_b
 /* (R,C,7,12) fp32 channels-first DINO features -> bf16 tokens [R, ncam, P, C] (input layout of the 1x1-conv compressor,
  * allenact_dino_transformer.py:663-667; tensor layout per architecture/allenact_preprocessors/dino_preprocessors.py:31-35). */
 int svla_feat_to_tokens(const float* feat, int R, int C, int P, int cam, int ncam, svla_bf16* out, void* stream);
-/* fusion token + text tokens of the fusion input (allenact_dino_transformer.py:672-692) and the text gradient. */
-int svla_fusion_fill(const float* fusion_token, const svla_bf16* text, const int* gid, int R, int S, int L, int text_off,
+/* fusion token + text tokens of the fusion input (allenact_dino_transformer.py:672-692) and the text gradient.  D = the transformer width
+ * (512 for the policy and most imitation-learning presets, 768 for the wide ones: early_fusion_tsfm_models.py:275-294), a multiple of 8. */
+int svla_fusion_fill(const float* fusion_token, const svla_bf16* text, const int* gid, int R, int S, int L, int text_off, int D,
                      svla_bf16* x0, void* stream);
-int svla_fusion_text_bwd(const svla_bf16* dx0, const int* gid, int T, int B, int S, int L, int text_off, float* dtext,
+int svla_fusion_text_bwd(const svla_bf16* dx0, const int* gid, int T, int B, int S, int L, int text_off, int D, float* dtext,
                          void* stream);
 /* prev-action (null token where masks == 0) + in-hand embeddings + sinusoidal time encoding
  * (allenact_dino_transformer.py:353-385; architecture/models/transformer_models/text_cond_visual_encoder.py:263-283). */
 int svla_decoder_embed_fwd(const svla_bf16* xf, long xf_row_stride, const float* act_tab, const float* hand_tab,
                            const float* div_term, const int64_t* prev_actions, const float* masks, const int64_t* hand,
-                           const int64_t* time_step, int T, int B, int n_actions, svla_bf16* out, void* stream);
+                           const int64_t* time_step, int T, int B, int n_actions, int D, svla_bf16* out, void* stream);
 int svla_decoder_embed_bwd(const svla_bf16* dout, const int64_t* prev_actions, const float* masks, const int64_t* hand, int T,
-                           int B, int n_actions, svla_bf16* dxf, long dxf_row_stride, float* d_act_tab, float* d_hand_tab,
+                           int B, int n_actions, int D, svla_bf16* dxf, long dxf_row_stride, float* d_act_tab, float* d_hand_tab,
                            void* stream);
-/* dst[r,:] += src[r,:] on 512-wide rows with independent row strides: adds the position-0 gradients of the last fusion layer
- * (allenact_dino_transformer.py:708 keeps only x[:, 0]) into the [R,S,512] input gradient. */
+/* dst[r,:] += src[r,:] on D-wide rows with independent row strides: adds the position-0 gradients of the last fusion layer
+ * (allenact_dino_transformer.py:708 keeps only x[:, 0]) into the [R,S,D] input gradient. */
 int svla_rows_add_bf16(svla_bf16* dst, long dst_ld, const svla_bf16* src, long src_ld, int rows, int D, void* stream);
 /* Zero `bytes` bytes at p on the stream: the scratch the text-gradient scatter (allenact_dino_transformer.py:591-605 backward, svla_fusion_text_bwd)
  * accumulates into -- part of the launch sequence rather than a framework-side fill. */
@@ -306,14 +307,14 @@ int svla_attn_bwd_f32(const float* Q, const float* K, const float* V, long ld, c
                       long lddo, float* dQ, float* dK, float* dV, long ldd, int rows, int S, int H, int head_dim, float scale, int mask_mode,
                       const int* traj, const unsigned char* kvalid, int Sq, long ldq, long lddq, const svla_dropout* drop, void* stream);
 int svla_feat_to_tokens_f32(const float* feat, int R, int C, int P, int cam, int ncam, float* out, void* stream);
-int svla_fusion_fill_f32(const float* fusion_token, const float* text, const int* gid, int R, int S, int L, int text_off, float* x0,
+int svla_fusion_fill_f32(const float* fusion_token, const float* text, const int* gid, int R, int S, int L, int text_off, int D, float* x0,
                          void* stream);
-int svla_fusion_text_bwd_f32(const float* dx0, const int* gid, int T, int B, int S, int L, int text_off, float* dtext, void* stream);
+int svla_fusion_text_bwd_f32(const float* dx0, const int* gid, int T, int B, int S, int L, int text_off, int D, float* dtext, void* stream);
 int svla_decoder_embed_fwd_f32(const float* xf, long xf_row_stride, const float* act_tab, const float* hand_tab, const float* div_term,
                                const int64_t* prev_actions, const float* masks, const int64_t* hand, const int64_t* time_step, int T, int B,
-                               int n_actions, float* out, void* stream);
+                               int n_actions, int D, float* out, void* stream);
 int svla_decoder_embed_bwd_f32(const float* dout, const int64_t* prev_actions, const float* masks, const int64_t* hand, int T, int B,
-                               int n_actions, float* dxf, long dxf_row_stride, float* d_act_tab, float* d_hand_tab, void* stream);
+                               int n_actions, int D, float* dxf, long dxf_row_stride, float* d_act_tab, float* d_hand_tab, void* stream);
 int svla_rows_add_f32(float* dst, long dst_ld, const float* src, long src_ld, int rows, int D, void* stream);
 int svla_swiglu_fwd_f32(const float* ab, long M, int Hd, float* g, void* stream);
 int svla_swiglu_bwd_f32(const float* ab, const float* dg, long M, int Hd, float* dab, void* stream);

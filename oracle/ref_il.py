@@ -19,11 +19,12 @@ NAV, MANIP = "raw_navigation_camera", "raw_manipulation_camera"
 
 
 class RefEarlyFusion(nn.Module):
-    def __init__(self, max_length=1000, max_batch=8, n_fusion_layers=3, n_decoder_layers=3, dino_dim=384, text_encoder="t5-small"):
+    def __init__(self, max_length=1000, max_batch=8, n_fusion_layers=3, n_decoder_layers=3, dino_dim=384, text_encoder="t5-small", d_model=512, n_heads=8):
         """defaults = ``small_3``; (6, 6, 384) = ``small_6``; (3, 3, 768) = ``base_3``; (3, 3, 768, "SigLIPBase") = ``siglip_base_3``;
-        (3, 3, 1024, "SigLIPLarge") = ``siglip_large_3``; (3, 3, 2048) = ``clip_resnet_50_3`` (early_fusion_tsfm_models.py:221-312)."""
+        (3, 3, 1024, "SigLIPLarge") = ``siglip_large_3``; (3, 3, 2048) = ``clip_resnet_50_3``; (6, 3, 768, "SigLIPBase", 768, 12) = ``siglip_base_6_3``
+        (early_fusion_tsfm_models.py:221-312)."""
         super().__init__()
-        d = 512
+        d = d_model
         self.siglip = text_encoder != "t5-small"
         te, td = None, 512
         if self.siglip:
@@ -31,8 +32,8 @@ class RefEarlyFusion(nn.Module):
             cfg = {"SigLIPBase": dict(width=768, heads=12, layers=12), "SigLIPLarge": dict(width=1024, heads=16, layers=24)}[text_encoder]
             te, td = RefSigLIPText(**cfg), cfg["width"]
             te.output_tokens = True                                                # text_cond_visual_encoder.py:39
-        self.visual_encoder = RefGoalEncoder(tokenizer=None, n_layers=n_fusion_layers, dino_dim=dino_dim, text_encoder=te, text_dim=td)
-        self.decoder = RefLlamaDecoder(d, n_decoder_layers, 8, 1e-5, max_batch, max_length)
+        self.visual_encoder = RefGoalEncoder(tokenizer=None, d=d, n_heads=n_heads, n_layers=n_fusion_layers, dino_dim=dino_dim, text_encoder=te, text_dim=td)
+        self.decoder = RefLlamaDecoder(d, n_decoder_layers, n_heads, 1e-5, max_batch, max_length)
         self.actor = nn.Linear(d, N_ACTIONS)
         self.time_encoder = RefPositionalEncoder(d)
         self.last_actions_embed = nn.Embedding(N_ACTIONS + 2, d, padding_idx=N_ACTIONS + 1)

@@ -288,7 +288,7 @@ extern "C" int svla_attn_bwd_f32(const float* Q, const float* K, const float* V,
 }
 
 // ================================================================================================ glue (fp32 twins of misc.hip)
-// Same arithmetic and argument meaning as the bf16 entry points of the same name; activations are fp32, one wave per 512-wide row.
+// Same arithmetic and argument meaning as the bf16 entry points of the same name; activations are fp32, D-wide rows.
 __global__ void feat_to_tokens_f32_kernel(const float* __restrict__ feat, int R, int C, int P, int cam, int ncam, float* __restrict__ out) {
     const long n = (long)R * C * P;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -305,39 +305,39 @@ extern "C" int svla_feat_to_tokens_f32(const float* feat, int R, int C, int P, i
 }
 
 __global__ void fusion_fill_f32_kernel(const float* __restrict__ fusion_token, const float* __restrict__ text, const int* __restrict__ gid,
-                                       int R, int S, int L, int text_off, float* __restrict__ x0) {
+                                       int R, int S, int L, int text_off, int D, float* __restrict__ x0) {
     const int r = blockIdx.x;
-    float* row = x0 + (size_t)r * S * 512;
-    const float* tsrc = text + (size_t)gid[r] * L * 512;
-    for (int c = threadIdx.x; c < 512; c += blockDim.x) {
+    float* row = x0 + (size_t)r * S * D;
+    const float* tsrc = text + (size_t)gid[r] * L * D;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
         row[c] = fusion_token[c];
-        for (int j = 0; j < L; ++j) row[(size_t)(text_off + j) * 512 + c] = tsrc[(size_t)j * 512 + c];
+        for (int j = 0; j < L; ++j) row[(size_t)(text_off + j) * D + c] = tsrc[(size_t)j * D + c];
     }
 }
 extern "C" int svla_fusion_fill_f32(const float* fusion_token, const float* text, const int* gid, int R, int S, int L, int text_off,
-                                    float* x0, void* stream) {
-    if (R <= 0 || text_off + L > S) return SVLA_EINVAL;
-    hipLaunchKernelGGL(fusion_fill_f32_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, fusion_token, text, gid, R, S, L, text_off, x0);
+                                    int D, float* x0, void* stream) {
+    if (R <= 0 || text_off + L > S || D <= 0) return SVLA_EINVAL;
+    hipLaunchKernelGGL(fusion_fill_f32_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, fusion_token, text, gid, R, S, L, text_off, D, x0);
     return svla_launch_status();
 }
 
 __global__ void fusion_text_bwd_f32_kernel(const float* __restrict__ dx0, const int* __restrict__ gid, int T, int B, int S, int L,
-                                           int text_off, float* __restrict__ dtext) {
+                                           int text_off, int D, float* __restrict__ dtext) {
     const int b = blockIdx.x, j = blockIdx.y;
-    for (int c = threadIdx.x; c < 512; c += blockDim.x) {
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
         float acc = 0.f;
         int cur = gid[b];
         for (int t = 0; t < T; ++t) {
             const int r = t * B + b, g = gid[r];
-            if (g != cur) { atomicAdd(dtext + ((size_t)cur * L + j) * 512 + c, acc); acc = 0.f; cur = g; }
-            acc += dx0[((size_t)r * S + text_off + j) * 512 + c];
+            if (g != cur) { atomicAdd(dtext + ((size_t)cur * L + j) * D + c, acc); acc = 0.f; cur = g; }
+            acc += dx0[((size_t)r * S + text_off + j) * D + c];
         }
-        atomicAdd(dtext + ((size_t)cur * L + j) * 512 + c, acc);
+        atomicAdd(dtext + ((size_t)cur * L + j) * D + c, acc);
     }
 }
-extern "C" int svla_fusion_text_bwd_f32(const float* dx0, const int* gid, int T, int B, int S, int L, int text_off, float* dtext, void* stream) {
-    if (T <= 0 || B <= 0 || L <= 0) return SVLA_EINVAL;
-    hipLaunchKernelGGL(fusion_text_bwd_f32_kernel, dim3(B, L), dim3(256), 0, (hipStream_t)stream, dx0, gid, T, B, S, L, text_off, dtext);
+extern "C" int svla_fusion_text_bwd_f32(const float* dx0, const int* gid, int T, int B, int S, int L, int text_off, int D, float* dtext, void* stream) {
+    if (T <= 0 || B <= 0 || L <= 0 || D <= 0) return SVLA_EINVAL;
+    hipLaunchKernelGGL(fusion_text_bwd_f32_kernel, dim3(B, L), dim3(256), 0, (hipStream_t)stream, dx0, gid, T, B, S, L, text_off, D, dtext);
     return svla_launch_status();
 }
 
@@ -345,48 +345,48 @@ __global__ void decoder_embed_f32_kernel(const float* __restrict__ xf, long xf_r
                                          const float* __restrict__ hand_tab, const float* __restrict__ div_term,
                                          const int64_t* __restrict__ prev_actions, const float* __restrict__ masks,
                                          const int64_t* __restrict__ hand, const int64_t* __restrict__ time_step, int T, int B, int n_actions,
-                                         float* __restrict__ out) {
+                                         int D, float* __restrict__ out) {
     const int row = blockIdx.x;            // (t*B + b)
     const int t = row / B, b = row % B;
     const int64_t a = masks[row] != 0.f ? prev_actions[row] : (int64_t)n_actions;
     const float pos = (float)time_step[row];
-    for (int c = threadIdx.x; c < 512; c += blockDim.x) {
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
         const float ang = pos * div_term[c >> 1];
         const float pe = (c & 1) ? cosf(ang) : sinf(ang);
         // reference order: time_enc + ((obs + prev_action_emb) + in_hand_emb)
-        out[((size_t)b * T + t) * 512 + c] = pe + ((xf[(size_t)row * xf_row_stride + c] + act_tab[(size_t)a * 512 + c]) + hand_tab[(size_t)hand[row] * 512 + c]);
+        out[((size_t)b * T + t) * D + c] = pe + ((xf[(size_t)row * xf_row_stride + c] + act_tab[(size_t)a * D + c]) + hand_tab[(size_t)hand[row] * D + c]);
     }
 }
 extern "C" int svla_decoder_embed_fwd_f32(const float* xf, long xf_row_stride, const float* act_tab, const float* hand_tab,
                                           const float* div_term, const int64_t* prev_actions, const float* masks, const int64_t* hand,
-                                          const int64_t* time_step, int T, int B, int n_actions, float* out, void* stream) {
-    if (T <= 0 || B <= 0) return SVLA_EINVAL;
+                                          const int64_t* time_step, int T, int B, int n_actions, int D, float* out, void* stream) {
+    if (T <= 0 || B <= 0 || D <= 0) return SVLA_EINVAL;
     hipLaunchKernelGGL(decoder_embed_f32_kernel, dim3(T * B), dim3(256), 0, (hipStream_t)stream, xf, xf_row_stride, act_tab, hand_tab, div_term,
-                       prev_actions, masks, hand, time_step, T, B, n_actions, out);
+                       prev_actions, masks, hand, time_step, T, B, n_actions, D, out);
     return svla_launch_status();
 }
 
 __global__ void decoder_embed_bwd_f32_kernel(const float* __restrict__ dout, const int64_t* __restrict__ prev_actions,
-                                             const float* __restrict__ masks, const int64_t* __restrict__ hand, int T, int B, int n_actions,
+                                             const float* __restrict__ masks, const int64_t* __restrict__ hand, int T, int B, int n_actions, int D,
                                              float* __restrict__ dxf, long dxf_row_stride, float* __restrict__ d_act_tab,
                                              float* __restrict__ d_hand_tab) {
     const int row = blockIdx.x;
     const int t = row / B, b = row % B;
     const int a = masks[row] != 0.f ? (int)prev_actions[row] : n_actions;
     const int hh = (int)hand[row];
-    for (int c = threadIdx.x; c < 512; c += blockDim.x) {
-        const float v = dout[((size_t)b * T + t) * 512 + c];
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        const float v = dout[((size_t)b * T + t) * D + c];
         dxf[(size_t)row * dxf_row_stride + c] = v;
-        atomicAdd(d_act_tab + (size_t)a * 512 + c, v);
-        atomicAdd(d_hand_tab + (size_t)hh * 512 + c, v);
+        atomicAdd(d_act_tab + (size_t)a * D + c, v);
+        atomicAdd(d_hand_tab + (size_t)hh * D + c, v);
     }
 }
 extern "C" int svla_decoder_embed_bwd_f32(const float* dout, const int64_t* prev_actions, const float* masks, const int64_t* hand, int T,
-                                          int B, int n_actions, float* dxf, long dxf_row_stride, float* d_act_tab, float* d_hand_tab,
+                                          int B, int n_actions, int D, float* dxf, long dxf_row_stride, float* d_act_tab, float* d_hand_tab,
                                           void* stream) {
-    if (T <= 0 || B <= 0) return SVLA_EINVAL;
+    if (T <= 0 || B <= 0 || D <= 0) return SVLA_EINVAL;
     hipLaunchKernelGGL(decoder_embed_bwd_f32_kernel, dim3(T * B), dim3(256), 0, (hipStream_t)stream, dout, prev_actions, masks, hand, T, B,
-                       n_actions, dxf, dxf_row_stride, d_act_tab, d_hand_tab);
+                       n_actions, D, dxf, dxf_row_stride, d_act_tab, d_hand_tab);
     return svla_launch_status();
 }
 

@@ -1792,12 +1792,15 @@ __global__ void colsum_bf16_kernel(const bf16_t* __restrict__ dY, long ldy, int 
 
 // row m is read at memory row m*row_stride (row_stride > 1: e.g. token 0 of every [S, D] group)
 extern "C" int svla_colsum_bf16(const bf16_t* dY, long ldy, int M, int N, int row_stride, float* db, void* stream) {
-    if (M <= 0 || N <= 0 || (N % 8) || N / 8 > 256 || (ldy % 8)) return SVLA_EINVAL;
+    if (M <= 0 || N <= 0 || (N % 8) || (ldy % 8)) return SVLA_EINVAL;
     const int threads = 256;
-    const int rpp = threads / (N / 8);
-    int blocks = (M + rpp - 1) / rpp;
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(blocks), dim3(threads), threads * 8 * sizeof(float), (hipStream_t)stream, dY, ldy,
-                       M, N, row_stride > 0 ? row_stride : 1, db, g_svla_det);
+    for (int c0 = 0; c0 < N; c0 += 2048) {        // one launch per 2048 columns (256 threads x 8): only the fused QKV gradient of the 768-wide presets (N = 2304) needs two
+        const int n = N - c0 < 2048 ? N - c0 : 2048;
+        const int rpp = threads / (n / 8);
+        int blocks = (M + rpp - 1) / rpp;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(colsum_bf16_kernel, dim3(blocks), dim3(threads), threads * 8 * sizeof(float), (hipStream_t)stream, dY + c0, ldy,
+                           M, n, row_stride > 0 ? row_stride : 1, db + c0, g_svla_det);
+    }
     return svla_launch_status();
 }

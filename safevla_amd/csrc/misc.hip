@@ -34,54 +34,58 @@ extern "C" int svla_feat_to_tokens(const float* feat, int R, int C, int P, int c
 // ------------------------------------------------------------------------------------------------
 // x0[r, 0, :] = fusion_token; x0[r, text_off + j, :] = text[gid[r], j, :]   (allenact_dino_transformer.py:672-692)
 __global__ void fusion_fill_kernel(const float* __restrict__ fusion_token, const bf16_t* __restrict__ text,
-                                   const int* __restrict__ gid, int R, int S, int L, int text_off, bf16_t* __restrict__ x0) {
-    const int r = blockIdx.x, lane = threadIdx.x;  // 64 threads x 8 elements = 512
-    bf16_t* row = x0 + (size_t)r * S * 512;
-    u32x4 w;
+                                   const int* __restrict__ gid, int R, int S, int L, int text_off, int D, bf16_t* __restrict__ x0) {
+    const int r = blockIdx.x, lane = threadIdx.x;  // 64 threads x 8 elements per 512-wide slice of the row (D = 512: one slice)
+    bf16_t* row = x0 + (size_t)r * S * D;
+    const bf16_t* tsrc = text + (size_t)gid[r] * L * D;
+    for (int c = lane * 8; c < D; c += 512) {
+        u32x4 w;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) w[e] = pack_bf2(fusion_token[lane * 8 + 2 * e], fusion_token[lane * 8 + 2 * e + 1]);
-    *(u32x4*)(row + lane * 8) = w;
-    const bf16_t* tsrc = text + (size_t)gid[r] * L * 512;
-    for (int j = 0; j < L; ++j)
-        *(u32x4*)(row + (size_t)(text_off + j) * 512 + lane * 8) = *(const u32x4*)(tsrc + (size_t)j * 512 + lane * 8);
+        for (int e = 0; e < 4; ++e) w[e] = pack_bf2(fusion_token[c + 2 * e], fusion_token[c + 2 * e + 1]);
+        *(u32x4*)(row + c) = w;
+        for (int j = 0; j < L; ++j)
+            *(u32x4*)(row + (size_t)(text_off + j) * D + c) = *(const u32x4*)(tsrc + (size_t)j * D + c);
+    }
 }
 
 extern "C" int svla_fusion_fill(const float* fusion_token, const bf16_t* text, const int* gid, int R, int S, int L,
-                                int text_off, bf16_t* x0, void* stream) {
-    if (R <= 0 || text_off + L > S) return SVLA_EINVAL;
-    hipLaunchKernelGGL(fusion_fill_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, fusion_token, text, gid, R, S, L, text_off, x0);
+                                int text_off, int D, bf16_t* x0, void* stream) {
+    if (R <= 0 || text_off + L > S || D <= 0 || (D % 8)) return SVLA_EINVAL;
+    hipLaunchKernelGGL(fusion_fill_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, fusion_token, text, gid, R, S, L, text_off, D, x0);
     return svla_launch_status();
 }
 
 // dtext[gid[r], j, :] += dx0[r, text_off + j, :].  Rows are (t*B + b); an env's goal is constant over an episode,
 // so one workgroup walks one env over t and flushes a register accumulator only when the goal id changes.
 __global__ void fusion_text_bwd_kernel(const bf16_t* __restrict__ dx0, const int* __restrict__ gid, int T, int B, int S,
-                                       int L, int text_off, float* __restrict__ dtext, DetCfg det) {
+                                       int L, int text_off, int D, float* __restrict__ dtext, DetCfg det) {
     const int b = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
+    const int c = blockIdx.z * 512 + lane * 8;      // one 512-wide slice of the row per blockIdx.z (D = 512: one slice)
+    if (c >= D) return;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int cur = gid[b];
     for (int t = 0; t < T; ++t) {
         const int r = t * B + b;
         const int g = gid[r];
         if (g != cur) {
-            float* d = dtext + ((size_t)cur * L + j) * 512 + lane * 8;
+            float* d = dtext + ((size_t)cur * L + j) * D + c;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { grad_add(det, d + e, acc[e]); acc[e] = 0.f; }
             cur = g;
         }
-        const u32x4 w = *(const u32x4*)(dx0 + ((size_t)r * S + text_off + j) * 512 + lane * 8);
+        const u32x4 w = *(const u32x4*)(dx0 + ((size_t)r * S + text_off + j) * D + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(w[e]); acc[2 * e + 1] += bf_hi(w[e]); }
     }
-    float* d = dtext + ((size_t)cur * L + j) * 512 + lane * 8;
+    float* d = dtext + ((size_t)cur * L + j) * D + c;
 #pragma unroll
     for (int e = 0; e < 8; ++e) grad_add(det, d + e, acc[e]);
 }
 
-extern "C" int svla_fusion_text_bwd(const bf16_t* dx0, const int* gid, int T, int B, int S, int L, int text_off, float* dtext,
+extern "C" int svla_fusion_text_bwd(const bf16_t* dx0, const int* gid, int T, int B, int S, int L, int text_off, int D, float* dtext,
                                     void* stream) {
-    if (T <= 0 || B <= 0 || L <= 0) return SVLA_EINVAL;
-    hipLaunchKernelGGL(fusion_text_bwd_kernel, dim3(B, L), dim3(64), 0, (hipStream_t)stream, dx0, gid, T, B, S, L, text_off, dtext, g_svla_det);
+    if (T <= 0 || B <= 0 || L <= 0 || D <= 0 || (D % 8)) return SVLA_EINVAL;
+    hipLaunchKernelGGL(fusion_text_bwd_kernel, dim3(B, L, (D + 511) / 512), dim3(64), 0, (hipStream_t)stream, dx0, gid, T, B, S, L, text_off, D, dtext, g_svla_det);
     return svla_launch_status();
 }
 
@@ -93,36 +97,38 @@ __global__ void decoder_embed_kernel(const bf16_t* __restrict__ xf, long xf_row_
                                      const float* __restrict__ hand_tab, const float* __restrict__ div_term,
                                      const int64_t* __restrict__ prev_actions, const float* __restrict__ masks,
                                      const int64_t* __restrict__ hand, const int64_t* __restrict__ time_step, int T, int B,
-                                     int n_actions, bf16_t* __restrict__ out) {
+                                     int n_actions, int D, bf16_t* __restrict__ out) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= T * B) return;
     const int t = wave / B, b = wave % B;
     const int64_t a = masks[wave] != 0.f ? prev_actions[wave] : (int64_t)n_actions;
     const float pos = (float)time_step[wave];
-    const u32x4 w = *(const u32x4*)(xf + (size_t)wave * xf_row_stride + lane * 8);
-    const float* at = act_tab + (size_t)a * 512 + lane * 8;
-    const float* ht = hand_tab + (size_t)hand[wave] * 512 + lane * 8;
-    float v[8];
+    for (int c = lane * 8; c < D; c += 512) {       // D = 512: one trip
+        const u32x4 w = *(const u32x4*)(xf + (size_t)wave * xf_row_stride + c);
+        const float* at = act_tab + (size_t)a * D + c;
+        const float* ht = hand_tab + (size_t)hand[wave] * D + c;
+        float v[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float ang = pos * div_term[lane * 4 + e];
-        // reference order: time_enc + ((obs + prev_action_emb) + in_hand_emb)
-        v[2 * e] = sinf(ang) + ((bf_lo(w[e]) + at[2 * e]) + ht[2 * e]);
-        v[2 * e + 1] = cosf(ang) + ((bf_hi(w[e]) + at[2 * e + 1]) + ht[2 * e + 1]);
+        for (int e = 0; e < 4; ++e) {
+            const float ang = pos * div_term[c / 2 + e];
+            // reference order: time_enc + ((obs + prev_action_emb) + in_hand_emb)
+            v[2 * e] = sinf(ang) + ((bf_lo(w[e]) + at[2 * e]) + ht[2 * e]);
+            v[2 * e + 1] = cosf(ang) + ((bf_hi(w[e]) + at[2 * e + 1]) + ht[2 * e + 1]);
+        }
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+        *(u32x4*)(out + ((size_t)b * T + t) * D + c) = o;
     }
-    u32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
-    *(u32x4*)(out + ((size_t)b * T + t) * 512 + lane * 8) = o;
 }
 
 extern "C" int svla_decoder_embed_fwd(const bf16_t* xf, long xf_row_stride, const float* act_tab, const float* hand_tab,
                                       const float* div_term, const int64_t* prev_actions, const float* masks,
-                                      const int64_t* hand, const int64_t* time_step, int T, int B, int n_actions, bf16_t* out,
+                                      const int64_t* hand, const int64_t* time_step, int T, int B, int n_actions, int D, bf16_t* out,
                                       void* stream) {
-    if (T <= 0 || B <= 0) return SVLA_EINVAL;
+    if (T <= 0 || B <= 0 || D <= 0 || (D % 8)) return SVLA_EINVAL;
     hipLaunchKernelGGL(decoder_embed_kernel, dim3((T * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, xf, xf_row_stride, act_tab,
-                       hand_tab, div_term, prev_actions, masks, hand, time_step, T, B, n_actions, out);
+                       hand_tab, div_term, prev_actions, masks, hand, time_step, T, B, n_actions, D, out);
     return svla_launch_status();
 }
 
@@ -131,69 +137,71 @@ extern "C" int svla_decoder_embed_fwd(const bf16_t* xf, long xf_row_stride, cons
 template <bool DET>
 __global__ void decoder_embed_bwd_kernel(const bf16_t* __restrict__ dout, const int64_t* __restrict__ prev_actions,
                                          const float* __restrict__ masks, const int64_t* __restrict__ hand, int T, int B,
-                                         int n_actions, bf16_t* __restrict__ dxf, long dxf_row_stride,
+                                         int n_actions, int D, bf16_t* __restrict__ dxf, long dxf_row_stride,
                                          float* __restrict__ d_act_tab, float* __restrict__ d_hand_tab, DetCfg det) {
-    extern __shared__ __attribute__((aligned(16))) char tab_raw[];  // [(n_actions + 2) + 3][512] float (or 64-bit fixed point)
+    extern __shared__ __attribute__((aligned(16))) char tab_raw[];  // [(n_actions + 2) + 3][D] float (or 64-bit fixed point)
     typedef typename std::conditional<DET, unsigned long long, float>::type acc_t;
     acc_t* tab = (acc_t*)tab_raw;
     const int nrows_tab = n_actions + 2 + 3;
-    for (int i = threadIdx.x; i < nrows_tab * 512; i += blockDim.x) tab[i] = (acc_t)0;
+    for (int i = threadIdx.x; i < nrows_tab * D; i += blockDim.x) tab[i] = (acc_t)0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int nw = (gridDim.x * blockDim.x) >> 6;
     auto add = [&](int idx, float v) {
         if constexpr (DET) {
             if (fabsf(v) < DET_PARTIAL_MAX) atomicAdd(&tab[idx], det_fixed(v));      // < 8192 rows per block: the table cannot wrap
-            else atomicAdd(idx < (n_actions + 2) * 512 ? &d_act_tab[idx] : &d_hand_tab[idx - (n_actions + 2) * 512], v);      // NaN / Inf / huge: straight to fp32, visible
+            else atomicAdd(idx < (n_actions + 2) * D ? &d_act_tab[idx] : &d_hand_tab[idx - (n_actions + 2) * D], v);      // NaN / Inf / huge: straight to fp32, visible
         } else atomicAdd(&tab[idx], v);
     };
     for (int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wave < T * B; wave += nw) {
         const int t = wave / B, b = wave % B;
-        const u32x4 w = *(const u32x4*)(dout + ((size_t)b * T + t) * 512 + lane * 8);
-        *(u32x4*)(dxf + (size_t)wave * dxf_row_stride + lane * 8) = w;
         const int a = masks[wave] != 0.f ? (int)prev_actions[wave] : n_actions;
         const int hh = n_actions + 2 + (int)hand[wave];
+        for (int c = lane * 8; c < D; c += 512) {       // D = 512: one trip
+            const u32x4 w = *(const u32x4*)(dout + ((size_t)b * T + t) * D + c);
+            *(u32x4*)(dxf + (size_t)wave * dxf_row_stride + c) = w;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float lo = bf_lo(w[e]), hi = bf_hi(w[e]);
-            add(a * 512 + lane * 8 + 2 * e, lo);
-            add(a * 512 + lane * 8 + 2 * e + 1, hi);
-            add(hh * 512 + lane * 8 + 2 * e, lo);
-            add(hh * 512 + lane * 8 + 2 * e + 1, hi);
+            for (int e = 0; e < 4; ++e) {
+                const float lo = bf_lo(w[e]), hi = bf_hi(w[e]);
+                add(a * D + c + 2 * e, lo);
+                add(a * D + c + 2 * e + 1, hi);
+                add(hh * D + c + 2 * e, lo);
+                add(hh * D + c + 2 * e + 1, hi);
+            }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nrows_tab * 512; i += blockDim.x) {
+    for (int i = threadIdx.x; i < nrows_tab * D; i += blockDim.x) {
         float v;
         if constexpr (DET) v = (float)((double)(long long)tab[i] * DET_UNSCALE); else v = tab[i];
         if (v != 0.f) {
-            if (i < (n_actions + 2) * 512) grad_add(det, &d_act_tab[i], v);
-            else grad_add(det, &d_hand_tab[i - (n_actions + 2) * 512], v);
+            if (i < (n_actions + 2) * D) grad_add(det, &d_act_tab[i], v);
+            else grad_add(det, &d_hand_tab[i - (n_actions + 2) * D], v);
         }
     }
 }
 
 extern "C" int svla_decoder_embed_bwd(const bf16_t* dout, const int64_t* prev_actions, const float* masks, const int64_t* hand,
-                                      int T, int B, int n_actions, bf16_t* dxf, long dxf_row_stride, float* d_act_tab,
+                                      int T, int B, int n_actions, int D, bf16_t* dxf, long dxf_row_stride, float* d_act_tab,
                                       float* d_hand_tab, void* stream) {
-    if (T <= 0 || B <= 0) return SVLA_EINVAL;
+    if (T <= 0 || B <= 0 || D <= 0 || (D % 8)) return SVLA_EINVAL;
     const bool det = g_svla_det.i64[0] != nullptr || g_svla_det.i64[1] != nullptr;
-    const size_t lds = (size_t)(n_actions + 5) * 512 * (det ? sizeof(unsigned long long) : sizeof(float));
+    const size_t lds = (size_t)(n_actions + 5) * D * (det ? sizeof(unsigned long long) : sizeof(float));
+    if (lds > 160 * 1024) return SVLA_EINVAL;
     int blocks = (T * B + 63) / 64;
     if (blocks > 128) blocks = 128;
     static bool attr = false;
     if (!attr) {
-        const int cap = (n_actions + 5) * 512 * 8;
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)decoder_embed_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)decoder_embed_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)decoder_embed_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)decoder_embed_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     if (det)
         hipLaunchKernelGGL(decoder_embed_bwd_kernel<true>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, dout, prev_actions, masks, hand,
-                           T, B, n_actions, dxf, dxf_row_stride, d_act_tab, d_hand_tab, g_svla_det);
+                           T, B, n_actions, D, dxf, dxf_row_stride, d_act_tab, d_hand_tab, g_svla_det);
     else
         hipLaunchKernelGGL(decoder_embed_bwd_kernel<false>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, dout, prev_actions, masks, hand,
-                           T, B, n_actions, dxf, dxf_row_stride, d_act_tab, d_hand_tab, g_svla_det);
+                           T, B, n_actions, D, dxf, dxf_row_stride, d_act_tab, d_hand_tab, g_svla_det);
     return svla_launch_status();
 }
 
@@ -426,19 +434,21 @@ extern "C" int svla_row_hash_u8(const unsigned char* rows, long n_rows, int row_
     return svla_launch_status();
 }
 
-// dst[r, :] += src[r, :] for 512-wide bf16 rows with independent row strides (token-0 rows of a [R, S, 512] gradient)
-__global__ void rows_add_kernel(bf16_t* __restrict__ dst, long dst_ld, const bf16_t* __restrict__ src, long src_ld, int rows) {
+// dst[r, :] += src[r, :] for D-wide bf16 rows with independent row strides (token-0 rows of a [R, S, D] gradient)
+__global__ void rows_add_kernel(bf16_t* __restrict__ dst, long dst_ld, const bf16_t* __restrict__ src, long src_ld, int rows, int D) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= rows) return;
-    u32x4 a = *(const u32x4*)(dst + (size_t)wave * dst_ld + lane * 8);
-    const u32x4 b = *(const u32x4*)(src + (size_t)wave * src_ld + lane * 8);
+    for (int c = lane * 8; c < D; c += 512) {       // D = 512: one trip
+        u32x4 a = *(const u32x4*)(dst + (size_t)wave * dst_ld + c);
+        const u32x4 b = *(const u32x4*)(src + (size_t)wave * src_ld + c);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) a[e] = pack_bf2(bf_lo(a[e]) + bf_lo(b[e]), bf_hi(a[e]) + bf_hi(b[e]));
-    *(u32x4*)(dst + (size_t)wave * dst_ld + lane * 8) = a;
+        for (int e = 0; e < 4; ++e) a[e] = pack_bf2(bf_lo(a[e]) + bf_lo(b[e]), bf_hi(a[e]) + bf_hi(b[e]));
+        *(u32x4*)(dst + (size_t)wave * dst_ld + c) = a;
+    }
 }
 extern "C" int svla_rows_add_bf16(bf16_t* dst, long dst_ld, const bf16_t* src, long src_ld, int rows, int D, void* stream) {
-    if (rows <= 0 || D != 512 || (dst_ld % 8) || (src_ld % 8)) return SVLA_EINVAL;
-    hipLaunchKernelGGL(rows_add_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dst, dst_ld, src, src_ld, rows);
+    if (rows <= 0 || D <= 0 || (D % 8) || (dst_ld % 8) || (src_ld % 8)) return SVLA_EINVAL;
+    hipLaunchKernelGGL(rows_add_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dst, dst_ld, src, src_ld, rows, D);
     return svla_launch_status();
 }
 

@@ -231,12 +231,15 @@ static int norm_bwd_launch(const T* dy, int dyG, int dyGS, int dyOFF, const T* x
                            const float* beta, const float* mean, const float* rstd, int rows, int D, int rms, int relu, int tok_group,
                            const T* dres, T* dx, int dxG, int dxGS, int dxOFF, float* dgamma, float* dbeta, float* dtok, T* dx_drop,
                            const svla_dropout* drop, void* stream) {
-    if (rows <= 0 || D != 512) return SVLA_EINVAL;
+    if (rows <= 0 || (D != 512 && D != 768)) return SVLA_EINVAL;
     if (dtok && tok_group <= 0) return SVLA_EINVAL;
     RowMap dym{dyG, dyGS, dyOFF}, xm{xG, xGS, xOFF}, dxm{dxG, dxGS, dxOFF};
     const int blocks = norm_grid(rows, 4096);   // measured (tools/norm_bw.py, 2.97 M rows): 5.09 TB/s at 1 024 workgroups, 5.23 at 4 096 (each ends with up to 4*D atomics)
-    hipLaunchKernelGGL((norm_bwd_kernel<T, 512>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, dym, x, xm, gamma, beta, mean,
-                       rstd, rows, rms, relu, tok_group > 0 ? tok_group : 1, dres, dx, dxm, dgamma, dbeta, dtok, dx_drop, drop_cfg(drop), g_svla_det);
+#define NORM_BWD_CASE(DD) hipLaunchKernelGGL((norm_bwd_kernel<T, DD>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, dym, x, xm, gamma, beta, mean, \
+                       rstd, rows, rms, relu, tok_group > 0 ? tok_group : 1, dres, dx, dxm, dgamma, dbeta, dtok, dx_drop, drop_cfg(drop), g_svla_det)
+    if (D == 512) NORM_BWD_CASE(512);       // the policy
+    else NORM_BWD_CASE(768);                // the 768-wide imitation-learning presets (early_fusion_tsfm_models.py:275-294)
+#undef NORM_BWD_CASE
     return svla_launch_status();
 }
 

@@ -319,22 +319,37 @@ extern "C" int svla_ce_loss_fwd_bwd_f32(const float* logits, const long* target,
 
 // ------------------------------------------------------------------------------------------------
 // Small heads on fp32 beliefs (AllenAct LinearActorHead / LinearCriticHead [3P]): out[r, n] = x[r,:].W[n,:] + b[n],
-// D = 512 (8 values per lane, one wave per row), N <= 32.  ``row_perm_T``/``row_perm_B`` > 0: x rows are stored
-// (b*T + t) (decoder layout) while out rows are (t*B + b) (the [step, sampler] layout of the API).
+// D <= 1024 in 512-wide slices (8 values per lane and slice, one wave per row; the policy's D = 512 is one slice), N <= 32.  ``row_perm_T``/``row_perm_B`` > 0:
+// x rows are stored (b*T + t) (decoder layout) while out rows are (t*B + b) (the [step, sampler] layout of the API).
 template <int N_MAX>
 __global__ void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                        const float* __restrict__ bias, int rows, int N, int T, int B,
+                                        const float* __restrict__ bias, int rows, int N, int D, int T, int B,
                                         float* __restrict__ out) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= rows) return;
     int src = wave;
     if (T > 0) { const int t = wave / B, b = wave % B; src = b * T + t; }
-    const float4* xp = (const float4*)(x + (size_t)src * 512 + lane * 8);
-    const float4 x0 = xp[0], x1 = xp[1];
+    float4 xv[2][2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        const int c = ch * 512 + lane * 8;
+        const float4* xp = (const float4*)(x + (size_t)src * D + c);
+        xv[ch][0] = c < D ? xp[0] : float4{0.f, 0.f, 0.f, 0.f};
+        xv[ch][1] = c < D ? xp[1] : float4{0.f, 0.f, 0.f, 0.f};
+    }
     for (int n = 0; n < N; ++n) {
-        const float4* wp = (const float4*)(W + (size_t)n * 512 + lane * 8);
-        const float4 w0 = wp[0], w1 = wp[1];
-        float s = x0.x * w0.x + x0.y * w0.y + x0.z * w0.z + x0.w * w0.w + x1.x * w1.x + x1.y * w1.y + x1.z * w1.z + x1.w * w1.w;
+        float s = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int c = ch * 512 + lane * 8;
+            if (c < D) {
+                const float4* wp = (const float4*)(W + (size_t)n * D + c);
+                const float4 w0 = wp[0], w1 = wp[1], x0 = xv[ch][0], x1 = xv[ch][1];
+                // (D = 512: the same expression, in the same order, as the one-slice kernel of earlier rounds)
+                const float p = x0.x * w0.x + x0.y * w0.y + x0.z * w0.z + x0.w * w0.w + x1.x * w1.x + x1.y * w1.y + x1.z * w1.z + x1.w * w1.w;
+                s = ch == 0 ? p : s + p;
+            }
+        }
         s = wave_sum(s);
         if (lane == 0) out[(size_t)wave * N + n] = s + (bias ? bias[n] : 0.f);
     }
@@ -343,9 +358,11 @@ __global__ void small_linear_fwd_kernel(const float* __restrict__ x, const float
 // dx[src_row,:] (+)= sum_n dout[r,n] W[n,:]; dW[n,:] += sum_r dout[r,n] x[src_row,:]; db[n] += sum_r dout[r,n]
 template <int N_MAX>
 __global__ void small_linear_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                        const float* __restrict__ dout, int rows, int N, int T, int B, int accumulate_dx,
+                                        const float* __restrict__ dout, int rows, int N, int D, int T, int B, int accumulate_dx,
                                         float* __restrict__ dx, float* __restrict__ dW, float* __restrict__ db, DetCfg det) {
     const int lane = threadIdx.x & 63;
+    const int c0 = blockIdx.y * 512 + lane * 8;         // this block's 512-wide column slice (D = 512: the only one)
+    if (c0 >= D) return;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     float gw[N_MAX][8];
@@ -359,7 +376,7 @@ __global__ void small_linear_bwd_kernel(const float* __restrict__ x, const float
     for (int r = wave; r < rows; r += nwaves) {
         int src = r;
         if (T > 0) { const int t = r / B, b = r % B; src = b * T + t; }
-        const float4* xp = (const float4*)(x + (size_t)src * 512 + lane * 8);
+        const float4* xp = (const float4*)(x + (size_t)src * D + c0);
         const float4 x0 = xp[0], x1 = xp[1];
         const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -367,7 +384,7 @@ __global__ void small_linear_bwd_kernel(const float* __restrict__ x, const float
         for (int n = 0; n < N_MAX; ++n) {
             if (n < N) {
                 const float g = dout[(size_t)r * N + n];
-                const float4* wp = (const float4*)(W + (size_t)n * 512 + lane * 8);
+                const float4* wp = (const float4*)(W + (size_t)n * D + c0);
                 const float4 w0 = wp[0], w1 = wp[1];
                 const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
@@ -375,7 +392,7 @@ __global__ void small_linear_bwd_kernel(const float* __restrict__ x, const float
                 gb[n] += g;
             }
         }
-        float* dp = dx + (size_t)src * 512 + lane * 8;
+        float* dp = dx + (size_t)src * D + c0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) dp[k] = accumulate_dx ? dp[k] + acc[k] : acc[k];
     }
@@ -383,32 +400,33 @@ __global__ void small_linear_bwd_kernel(const float* __restrict__ x, const float
     for (int n = 0; n < N_MAX; ++n) {
         if (n < N) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) grad_add(det, &dW[(size_t)n * 512 + lane * 8 + k], gw[n][k]);
-            if (lane == 0 && db) grad_add(det, &db[n], gb[n]);
+            for (int k = 0; k < 8; ++k) grad_add(det, &dW[(size_t)n * D + c0 + k], gw[n][k]);
+            if (lane == 0 && blockIdx.y == 0 && db) grad_add(det, &db[n], gb[n]);
         }
     }
 }
 
 extern "C" int svla_small_linear_fwd_f32(const float* x, const float* W, const float* bias, int rows, int N, int D, int T,
                                          int B, float* out, void* stream) {
-    if (D != 512 || N <= 0 || N > 32 || rows <= 0) return SVLA_EINVAL;
+    if (D <= 0 || D > 1024 || (D % 8) || N <= 0 || N > 32 || rows <= 0) return SVLA_EINVAL;
     if (T > 0 && T * B != rows) return SVLA_EINVAL;
     hipLaunchKernelGGL(small_linear_fwd_kernel<32>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, bias,
-                       rows, N, T, B, out);
+                       rows, N, D, T, B, out);
     return svla_launch_status();
 }
 
 extern "C" int svla_small_linear_bwd_f32(const float* x, const float* W, const float* dout, int rows, int N, int D, int T,
                                          int B, int accumulate_dx, float* dx, float* dW, float* db, void* stream) {
-    if (D != 512 || N <= 0 || N > 20 || rows <= 0) return SVLA_EINVAL;
+    if (D <= 0 || D > 1024 || (D % 8) || N <= 0 || N > 20 || rows <= 0) return SVLA_EINVAL;
     if (T > 0 && T * B != rows) return SVLA_EINVAL;
     int blocks = (rows + 3) / 4;
     if (blocks > 256) blocks = 256;
+    const dim3 grid(blocks, (D + 511) / 512);
     if (N <= 1)
-        hipLaunchKernelGGL(small_linear_bwd_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, W, dout, rows, N,
+        hipLaunchKernelGGL(small_linear_bwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, W, dout, rows, N, D,
                            T, B, accumulate_dx, dx, dW, db, g_svla_det);
     else
-        hipLaunchKernelGGL(small_linear_bwd_kernel<20>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, W, dout, rows,
-                           N, T, B, accumulate_dx, dx, dW, db, g_svla_det);
+        hipLaunchKernelGGL(small_linear_bwd_kernel<20>, grid, dim3(256), 0, (hipStream_t)stream, x, W, dout, rows,
+                           N, D, T, B, accumulate_dx, dx, dW, db, g_svla_det);
     return svla_launch_status();
 }

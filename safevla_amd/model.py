@@ -129,8 +129,15 @@ class Tower(nn.Module):
     """``DinoLLAMATxNavActorCritic`` (full-sensor configuration of dinov2_vits_tsfm_base.py:234-270)."""
 
     def __init__(self, arena: _Arena, device, n_fusion_layers=3, n_decoder_layers=3, max_steps=500, critic_type="linear",
-                 precision="bf16", dino_dim=DINO, text_encoder="t5-small"):
+                 precision="bf16", dino_dim=DINO, text_encoder="t5-small", d_model=512, n_heads=8):
         super().__init__()
+        # transformer width of the fusion encoder AND the decoder (512 x 8 heads everywhere in the RL towers, allenact_dino_transformer.py:101-117; the imitation-
+        # learning presets also use 768 x 12, early_fusion_tsfm_models.py:275-294); llama's SwiGLU hidden size follows from it (llama_model.py:330-334)
+        if d_model % 64 or d_model // n_heads != 64 or d_model > 1024:
+            raise NotImplementedError(f"transformer width {d_model} with {n_heads} heads: the attention kernels are built for 64-wide heads")
+        D = self.D = d_model
+        H = self.H = n_heads
+        HD = self.dec_hidden = 256 * ((int(2 * 4 * d_model / 3) + 255) // 256)
         self.dino_dim = dino_dim          # channel width of the frozen image features: 384 (ViT-S/14), 768 (ViT-B/14, SigLIP-B), 1024 (ViT-L), 2048 (CLIP RN50)
         # frozen text encoder and the width of its features (text_cond_visual_encoder.py:24-45 ``TEXT_ENCODER_DIMS`` / ``create_text_encoder``): the RL towers
         # and the t5 presets of the IL model use t5-small; the IL model's ``siglip_*`` presets the SigLIP text tower (tokens + pooled token, siglip_text.py)
@@ -201,14 +208,14 @@ class Tower(nn.Module):
         for _ in range(n_decoder_layers):
             l = _NS()
             l.attention = _NS()
-            for n in ("wq", "wk", "wv"):                                   # adjacent: fused [1536, 512] QKV weight
+            for n in ("wq", "wk", "wv"):                                   # adjacent: fused [3 D, D] QKV weight
                 setattr(l.attention, n, _NS()); dec(getattr(l.attention, n), "weight", (D, D), "lin")
             l.attention.wo = _NS(); dec(l.attention.wo, "weight", (D, D), "lin")
             l.feed_forward = _NS()
             l.feed_forward.w1 = _NS(); l.feed_forward.w2 = _NS(); l.feed_forward.w3 = _NS()
-            dec(l.feed_forward.w1, "weight", (1536, D), "lin")             # w1, w3 adjacent: fused [3072, 512]
-            dec(l.feed_forward.w3, "weight", (1536, D), "lin")
-            dec(l.feed_forward.w2, "weight", (D, 1536), "lin")
+            dec(l.feed_forward.w1, "weight", (HD, D), "lin")             # w1, w3 adjacent: fused [2 HD, D]
+            dec(l.feed_forward.w3, "weight", (HD, D), "lin")
+            dec(l.feed_forward.w2, "weight", (D, HD), "lin")
             l.attention_norm = _NS(); dec(l.attention_norm, "weight", (D,), "ones")
             l.ffn_norm = _NS(); dec(l.ffn_norm, "weight", (D,), "ones")
             self.decoder.layers.append(l)
@@ -235,6 +242,7 @@ class Tower(nn.Module):
     # ---- weight views -------------------------------------------------------------------------------------
     def _gemm_weights(self):
         """(key, parameter(s), [N, K]) for every MFMA GEMM weight of the tower."""
+        D, H, HD = self.D, self.H, self.dec_hidden
         ve = self.visual_encoder
         out = [("c1", [ve.visual_compressor[0].weight], (D, self.dino_dim)), ("c2", [ve.visual_compressor[2].weight], (D, D)),
                ("va", [ve.visual_adapter[0].weight], (D, D)), ("ta", [ve.text_adapter[0].weight], (D, self.text_dim))]
@@ -244,12 +252,13 @@ class Tower(nn.Module):
         for i, l in enumerate(self.decoder.layers):
             a, f = l.attention, l.feed_forward
             out += [(f"d{i}.qkv", [a.wq.weight, a.wk.weight, a.wv.weight], (3 * D, D)), (f"d{i}.wo", [a.wo.weight], (D, D)),
-                    (f"d{i}.w13", [f.w1.weight, f.w3.weight], (3072, D)), (f"d{i}.w2", [f.w2.weight], (D, 1536))]
+                    (f"d{i}.w13", [f.w1.weight, f.w3.weight], (2 * HD, D)), (f"d{i}.w2", [f.w2.weight], (D, HD))]
         out.append(("dout", [self.decoder.output.weight], (D, D)))
         return out
 
     def bind(self):
         """Create bf16 / fp32-grad views into the arena (call once after arena.build)."""
+        D, H, HD = self.D, self.H, self.dec_hidden
         ar = self.arena
         self._w, self._dw = {}, {}
         for key, ps, (n, k) in self._gemm_weights():
@@ -273,6 +282,7 @@ class Tower(nn.Module):
         """W * gamma[None, :] (bf16) of the llama decoder's pre-norm linears -- RMSNorm(x) @ W^T = rstd(x) * (x @ (W gamma)^T) -- for the acting step's norm-fused
         GEMMs (ops.gemm_nt_rmsa).  Persistent buffers refreshed IN PLACE (recorded acting steps hold their addresses), lazily: only an acting step after an
         optimiser step / load_state_dict pays for it."""
+        D, H, HD = self.D, self.H, self.dec_hidden
         if self.adt != BF16 or not getattr(self, "_wg_dirty", True):
             return
         ar = self.arena
@@ -280,7 +290,7 @@ class Tower(nn.Module):
             self._wg = {}
         for i, l in enumerate(self.decoder.layers):
             a, f = l.attention, l.feed_forward
-            for key, first, n, gamma in ((f"d{i}.qkv", a.wq.weight, 3 * D, l.attention_norm.weight), (f"d{i}.w13", f.w1.weight, 3072, l.ffn_norm.weight)):
+            for key, first, n, gamma in ((f"d{i}.qkv", a.wq.weight, 3 * D, l.attention_norm.weight), (f"d{i}.w13", f.w1.weight, 2 * HD, l.ffn_norm.weight)):
                 off, _ = ar.offsets[id(first)]
                 w32 = ar.flat_p[off:off + n * D].view(n, D)
                 if key not in self._wg:
@@ -309,6 +319,7 @@ class Tower(nn.Module):
     # ---- forward ----------------------------------------------------------------------------------------------
     # ---- acting path state (llama KV caches, llama/model.py:224-247; counter semantics allenact_dino_transformer.py:376-406)
     def _ensure_caches(self, B: int):
+        D, H, HD = self.D, self.H, self.dec_hidden
         if getattr(self, "_kv", None) is None or self._kv[0].shape[0] < B:
             self._kv_version = getattr(self, "_kv_version", 0) + 1        # recorded steps hold pointers into the caches: new caches, new plans
             self._kv = [torch.zeros(B, self.max_steps, 2 * D, device=self.device_, dtype=self.adt) for _ in self.decoder.layers]
@@ -320,6 +331,7 @@ class Tower(nn.Module):
             self._kv_version = getattr(self, "_kv_version", 0) + 1
 
     def run_forward(self, prep: "Prep", need_grad: bool):
+        D, H, HD = self.D, self.H, self.dec_hidden
         T, B, R, S, L, U = prep.T, prep.B, prep.R, prep.S, prep.L, prep.U
         if T > 1 or self.time_step_counter >= self.max_steps:
             self.time_step_counter = 0
@@ -338,7 +350,7 @@ class Tower(nn.Module):
         a1 = ops.gemm_nt(c2, w["va"], M2, D, D, bias=ve.visual_adapter[0].bias)
         x = torch.empty(R, S, D, device=self.device_, dtype=self.adt)
         _, va_mean, va_rstd = ops.norm_fwd(a1, ve.visual_adapter[1].weight, ve.visual_adapter[1].bias, 1e-5, M2, relu=True,
-                                           tok=self._camtok, tok_group=NPATCH, y=x, ymap=(2 * NPATCH, S, 1))
+                                           tok=self._camtok, tok_group=NPATCH, y=x, ymap=(2 * NPATCH, S, 1), D=D)
         t5_seed = c["drop_seed"] if self.t5_dropout else None
         key = getattr(prep, "ids_key", None)
         if t5_seed is None and key is not None and getattr(self, "_t5_cache", (None, None))[0] == key:
@@ -349,7 +361,7 @@ class Tower(nn.Module):
                                         seed_dev=getattr(self, "_seed_dev", None))   # [U*L, text_dim], frozen (SigLIP: ids are [U, L - 1], the pooled token is row L - 1)
             self._t5_cache = (key, t5) if (t5_seed is None and key is not None) else (None, None)
         ta = ops.gemm_nt(t5, w["ta"], U * L, D, self.text_dim, bias=ve.text_adapter[0].bias)
-        tf, ta_mean, ta_rstd = ops.norm_fwd(ta, ve.text_adapter[1].weight, ve.text_adapter[1].bias, 1e-5, U * L, relu=True)
+        tf, ta_mean, ta_rstd = ops.norm_fwd(ta, ve.text_adapter[1].weight, ve.text_adapter[1].bias, 1e-5, U * L, relu=True, D=D)
         ops.fusion_fill(ve.fusion_token, tf, prep.gid, x, R, S, L, TEXT_OFF)
         c.update(c1=c1, c2=c2, c1b=c1b, c2b=c2b, a1=a1, va=(va_mean, va_rstd), t5=t5, ta=ta, ta_stats=(ta_mean, ta_rstd))
         xf = x.view(M, D)
@@ -364,12 +376,12 @@ class Tower(nn.Module):
                 b_in = l.self_attn.in_proj_bias
                 kv = ops.gemm_nt(xf, w[f"f{i}.in"][D:], M, 2 * D, D, bias=b_in[D:])
                 q0 = ops.gemm_nt(xf, w[f"f{i}.in"][:D], R, D, D, bias=b_in[:D], lda=S * D)
-                ao, lse = ops.attn_fwd(q0, kv, kv[:, D:], 2 * D, R, S, 8, 0.125, save_lse=need_grad, Sq=1, ldq=D, drop=site(i, 0))
+                ao, lse = ops.attn_fwd(q0, kv, kv[:, D:], 2 * D, R, S, H, 0.125, save_lse=need_grad, Sq=1, ldq=D, drop=site(i, 0))
                 h1 = ops.gemm_nt(ao, w[f"f{i}.out"], R, D, D, bias=l.self_attn.out_proj.bias, residual=xf, ldr=S * D, drop=site(i, 1, S))
-                x1, m1, r1 = ops.norm_fwd(h1, l.norm1.weight, l.norm1.bias, 1e-5, R, save_stats=need_grad)
+                x1, m1, r1 = ops.norm_fwd(h1, l.norm1.weight, l.norm1.bias, 1e-5, R, save_stats=need_grad, D=D)
                 f1 = ops.gemm_nt(x1, w[f"f{i}.l1"], R, 2048, D, bias=l.linear1.bias, act=ops.ACT_RELU, drop=site(i, 2, S))
                 h2 = ops.gemm_nt(f1, w[f"f{i}.l2"], R, D, 2048, bias=l.linear2.bias, residual=x1, drop=site(i, 3, S))
-                xo, m2, r2 = ops.norm_fwd(h2, l.norm2.weight, l.norm2.bias, 1e-5, R, save_stats=need_grad)
+                xo, m2, r2 = ops.norm_fwd(h2, l.norm2.weight, l.norm2.bias, 1e-5, R, save_stats=need_grad, D=D)
                 if need_grad:
                     fl.append(dict(pruned=True, x=xf, kv=kv, q0=q0, ao=ao, lse=lse, h1=h1, x1=x1, n1=(m1, r1), f1=f1, h2=h2, n2=(m2, r2)))
                 xf, xf_stride = xo, D
@@ -377,18 +389,18 @@ class Tower(nn.Module):
             qkv = ops.gemm_nt(xf, w[f"f{i}.in"], M, 3 * D, D, bias=l.self_attn.in_proj_bias)
             f8 = None
             if self.fp8_attention and self.adt == BF16 and S <= 256:
-                f8 = ops.attn_fp8_quant(qkv, 3 * D, R, S, 8)
+                f8 = ops.attn_fp8_quant(qkv, 3 * D, R, S, H)
                 ao, lse = ops.attn_fp8_fwd(f8, 0.125, save_lse=need_grad, drop=site(i, 0))
                 qkv = None                       # the backward reads the e4m3 copies
             else:
-                ao, lse = ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, R, S, 8, 0.125, save_lse=need_grad, drop=site(i, 0))
+                ao, lse = ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, R, S, H, 0.125, save_lse=need_grad, drop=site(i, 0))
             h1 = ops.gemm_nt(ao, w[f"f{i}.out"], M, D, D, bias=l.self_attn.out_proj.bias, residual=xf, drop=site(i, 1))
-            x1, m1, r1 = ops.norm_fwd(h1, l.norm1.weight, l.norm1.bias, 1e-5, M, save_stats=need_grad)
+            x1, m1, r1 = ops.norm_fwd(h1, l.norm1.weight, l.norm1.bias, 1e-5, M, save_stats=need_grad, D=D)
             # the ReLU derivative is kept as 1 bit per element (M x 256 bytes): the input-gradient GEMM then reads 16x fewer mask bytes
             f1b = torch.empty(ops.relu_bits_bytes(M, 2048), device=x1.device, dtype=torch.uint8) if (need_grad and self.adt == BF16) else None
             f1 = ops.gemm_nt(x1, w[f"f{i}.l1"], M, 2048, D, bias=l.linear1.bias, act=ops.ACT_RELU, relu_bits_out=f1b, drop=site(i, 2))
             h2 = ops.gemm_nt(f1, w[f"f{i}.l2"], M, D, 2048, bias=l.linear2.bias, residual=x1, drop=site(i, 3))
-            xo, m2, r2 = ops.norm_fwd(h2, l.norm2.weight, l.norm2.bias, 1e-5, M, save_stats=need_grad)
+            xo, m2, r2 = ops.norm_fwd(h2, l.norm2.weight, l.norm2.bias, 1e-5, M, save_stats=need_grad, D=D)
             if need_grad:
                 fl.append(dict(pruned=False, x=xf, qkv=qkv, f8=f8, ao=ao, lse=lse, h1=h1, x1=x1, n1=(m1, r1), f1=f1, f1b=f1b, h2=h2, n2=(m2, r2)))
             xf = xo
@@ -424,7 +436,7 @@ class Tower(nn.Module):
                 if fused:
                     qkv = ops.gemm_nt_rmsa(xd, self._wg[f"d{i}.qkv"], B, 3 * D, D, 1e-5)
                 else:
-                    n1, _, _ = ops.norm_fwd(xd, l.attention_norm.weight, None, 1e-5, B, rms=True, save_stats=False)
+                    n1, _, _ = ops.norm_fwd(xd, l.attention_norm.weight, None, 1e-5, B, rms=True, save_stats=False, D=D)
                     qkv = ops.gemm_nt(n1, w[f"d{i}.qkv"], B, 3 * D, D)
                 cache = self._kv[i]
                 if t_dev is None:
@@ -434,32 +446,32 @@ class Tower(nn.Module):
                 else:
                     cache[:B].index_copy_(1, t_dev.view(1), qkv[:, D:].unsqueeze(1))
                 cv = cache.view(-1, 2 * D)
-                ao, _ = ops.attn_fwd(qkv, cv, cv[:, D:], 2 * D, B, S_att, 8, 0.125, kvalid=kvalid, save_lse=False, Sq=1, ldq=3 * D,
+                ao, _ = ops.attn_fwd(qkv, cv, cv[:, D:], 2 * D, B, S_att, H, 0.125, kvalid=kvalid, save_lse=False, Sq=1, ldq=3 * D,
                                      kv_rows=self.max_steps)
                 h = ops.gemm_nt(ao, w[f"d{i}.wo"], B, D, D, residual=xd)
                 if fused:
-                    ab = ops.gemm_nt_rmsa(h, self._wg[f"d{i}.w13"], B, 3072, D, 1e-5)
+                    ab = ops.gemm_nt_rmsa(h, self._wg[f"d{i}.w13"], B, 2 * HD, D, 1e-5)
                 else:
-                    n2, _, _ = ops.norm_fwd(h, l.ffn_norm.weight, None, 1e-5, B, rms=True, save_stats=False)
-                    ab = ops.gemm_nt(n2, w[f"d{i}.w13"], B, 3072, D)
-                gg = ops.swiglu_fwd(ab, B, 1536)
-                xd = ops.gemm_nt(gg, w[f"d{i}.w2"], B, D, 1536, residual=h)
+                    n2, _, _ = ops.norm_fwd(h, l.ffn_norm.weight, None, 1e-5, B, rms=True, save_stats=False, D=D)
+                    ab = ops.gemm_nt(n2, w[f"d{i}.w13"], B, 2 * HD, D)
+                gg = ops.swiglu_fwd(ab, B, HD)
+                xd = ops.gemm_nt(gg, w[f"d{i}.w2"], B, D, HD, residual=h)
             self.time_step_counter += 1
         else:
           for i, l in enumerate(self.decoder.layers):
-            n1, _, r1 = ops.norm_fwd(xd, l.attention_norm.weight, None, 1e-5, R, rms=True, save_stats=need_grad)
+            n1, _, r1 = ops.norm_fwd(xd, l.attention_norm.weight, None, 1e-5, R, rms=True, save_stats=need_grad, D=D)
             qkv = ops.gemm_nt(n1, w[f"d{i}.qkv"], R, 3 * D, D)
-            ao, lse = ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B, T, 8, 0.125, mask_mode=ops.MASK_BLOCK_CAUSAL,
+            ao, lse = ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B, T, H, 0.125, mask_mode=ops.MASK_BLOCK_CAUSAL,
                                    traj=prep.traj_bt, save_lse=need_grad)
             h = ops.gemm_nt(ao, w[f"d{i}.wo"], R, D, D, residual=xd)
-            n2, _, r2 = ops.norm_fwd(h, l.ffn_norm.weight, None, 1e-5, R, rms=True, save_stats=need_grad)
-            ab = ops.gemm_nt(n2, w[f"d{i}.w13"], R, 3072, D)
-            gg = ops.swiglu_fwd(ab, R, 1536)
-            xo = ops.gemm_nt(gg, w[f"d{i}.w2"], R, D, 1536, residual=h)
+            n2, _, r2 = ops.norm_fwd(h, l.ffn_norm.weight, None, 1e-5, R, rms=True, save_stats=need_grad, D=D)
+            ab = ops.gemm_nt(n2, w[f"d{i}.w13"], R, 2 * HD, D)
+            gg = ops.swiglu_fwd(ab, R, HD)
+            xo = ops.gemm_nt(gg, w[f"d{i}.w2"], R, D, HD, residual=h)
             if need_grad:
                 dl.append(dict(x=xd, n1=n1, r1=r1, qkv=qkv, ao=ao, lse=lse, h=h, n2=n2, r2=r2, ab=ab, g=gg))
             xd = xo
-        nf, _, rf = ops.norm_fwd(xd, self.decoder.norm.weight, None, 1e-5, R, rms=True, save_stats=need_grad)
+        nf, _, rf = ops.norm_fwd(xd, self.decoder.norm.weight, None, 1e-5, R, rms=True, save_stats=need_grad, D=D)
         beliefs = ops.gemm_nt(nf, w["dout"], R, D, D, out_f32=True)             # fp32, rows (b*T + t)
         logits = ops.small_linear_fwd(beliefs, self.actor.linear.weight, self.actor.linear.bias, T, B)   # rows (t*B + b)
         full_logits = None
@@ -514,6 +526,7 @@ class Tower(nn.Module):
                      dfull_logits: Optional[torch.Tensor] = None):
         """Accumulates parameter gradients into the arena's flat grad buffer.  ``dfull_logits``: gradient of the discrete critic's
         bin logits (HL-Gauss loss), critic_type == "discrete" only."""
+        D, H, HD = self.D, self.H, self.dec_hidden
         T, B, R, S, L, U = prep.T, prep.B, prep.R, prep.S, prep.L, prep.U
         ve, w, wt, dw, g = self.visual_encoder, self._w, self._wt, self._dw, self.g
         M2, M = R * 2 * NPATCH, R * S
@@ -538,24 +551,24 @@ class Tower(nn.Module):
         ops.cast_bf16(dbel, dy)
         ops.gemm_tn_acc(dy, c["nf"], dw["dout"], R, D, D)
         dnf = ops.gemm_nt(dy, wt["dout"], R, D, D)
-        dx = ops.norm_bwd(dnf, c["xd_last"], self.decoder.norm.weight, None, None, c["rf"], R, g(self.decoder.norm.weight), None, rms=True)
+        dx = ops.norm_bwd(dnf, c["xd_last"], self.decoder.norm.weight, None, None, c["rf"], R, g(self.decoder.norm.weight), None, rms=True, D=D)
         for i in reversed(range(len(self.decoder.layers))):
             l, a = self.decoder.layers[i], c["dec"][i]
-            ops.gemm_tn_acc(dx, a["g"], dw[f"d{i}.w2"], R, D, 1536)
-            dg = ops.gemm_nt(dx, wt[f"d{i}.w2"], R, 1536, D)
-            dab = ops.swiglu_bwd(a["ab"], dg, R, 1536)
-            ops.gemm_tn_acc(dab, a["n2"], dw[f"d{i}.w13"], R, 3072, D)
-            dn2 = ops.gemm_nt(dab, wt[f"d{i}.w13"], R, D, 3072)
-            dh = ops.norm_bwd(dn2, a["h"], l.ffn_norm.weight, None, None, a["r2"], R, g(l.ffn_norm.weight), None, rms=True, dres=dx)
+            ops.gemm_tn_acc(dx, a["g"], dw[f"d{i}.w2"], R, D, HD)
+            dg = ops.gemm_nt(dx, wt[f"d{i}.w2"], R, HD, D)
+            dab = ops.swiglu_bwd(a["ab"], dg, R, HD)
+            ops.gemm_tn_acc(dab, a["n2"], dw[f"d{i}.w13"], R, 2 * HD, D)
+            dn2 = ops.gemm_nt(dab, wt[f"d{i}.w13"], R, D, 2 * HD)
+            dh = ops.norm_bwd(dn2, a["h"], l.ffn_norm.weight, None, None, a["r2"], R, g(l.ffn_norm.weight), None, rms=True, dres=dx, D=D)
             ops.gemm_tn_acc(dh, a["ao"], dw[f"d{i}.wo"], R, D, D)
             dao = ops.gemm_nt(dh, wt[f"d{i}.wo"], R, D, D)
             dqkv = torch.empty(R, 3 * D, device=dev, dtype=self.adt)
             q = a["qkv"]
             ops.attn_bwd(q, q[:, D:], q[:, 2 * D:], 3 * D, a["ao"], D, a["lse"], dao, D, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D,
-                         B, T, 8, 0.125, mask_mode=ops.MASK_BLOCK_CAUSAL, traj=prep.traj_bt)
+                         B, T, H, 0.125, mask_mode=ops.MASK_BLOCK_CAUSAL, traj=prep.traj_bt)
             ops.gemm_tn_acc(dqkv, a["n1"], dw[f"d{i}.qkv"], R, 3 * D, D)
             dn1 = ops.gemm_nt(dqkv, wt[f"d{i}.qkv"], R, D, 3 * D)
-            dx = ops.norm_bwd(dn1, a["x"], l.attention_norm.weight, None, None, a["r1"], R, g(l.attention_norm.weight), None, rms=True, dres=dh)
+            dx = ops.norm_bwd(dn1, a["x"], l.attention_norm.weight, None, None, a["r1"], R, g(l.attention_norm.weight), None, rms=True, dres=dh, D=D)
         pruned = bool(c["fusion"]) and c["fusion"][-1]["pruned"]
         if pruned:
             dxf = torch.empty(R, D, device=dev, dtype=self.adt)        # gradient of the position-0 outputs only
@@ -577,7 +590,7 @@ class Tower(nn.Module):
                 d3, d1 = site(i, 3, S), site(i, 1, S)
                 df = masked_like(a["h2"], d3 is not None)
                 dh2 = ops.norm_bwd(dyf, a["h2"], l.norm2.weight, l.norm2.bias, a["n2"][0], a["n2"][1], R, g(l.norm2.weight), g(l.norm2.bias),
-                                   dx_drop=df, drop=d3)
+                                   dx_drop=df, drop=d3, D=D)
                 df = dh2 if df is None else df           # grad of linear2's output (through dropout2); dh2 = residual-path grad
                 ops.gemm_tn_acc(df, a["f1"], dw[f"f{i}.l2"], R, D, 2048, db=g(l.linear2.bias))
                 # f1 is stored after ReLU and dropout: f1 > 0 <=> (pre-activation > 0 and kept); alpha = the dropout scale
@@ -586,27 +599,27 @@ class Tower(nn.Module):
                 dx1 = ops.gemm_nt(df1, wt[f"f{i}.l1"], R, D, 2048, residual=dh2)
                 da = masked_like(a["h1"], d1 is not None)
                 dh1 = ops.norm_bwd(dx1, a["h1"], l.norm1.weight, l.norm1.bias, a["n1"][0], a["n1"][1], R, g(l.norm1.weight), g(l.norm1.bias),
-                                   dx_drop=da, drop=d1)
+                                   dx_drop=da, drop=d1, D=D)
                 da = dh1 if da is None else da
                 ops.gemm_tn_acc(da, a["ao"], dw[f"f{i}.out"], R, D, D, db=g(l.self_attn.out_proj.bias))
                 dao = ops.gemm_nt(da, wt[f"f{i}.out"], R, D, D)
                 dq0 = torch.empty(R, D, device=dev, dtype=self.adt)
                 dkv = torch.empty(M, 2 * D, device=dev, dtype=self.adt)
                 kv = a["kv"]
-                ops.attn_bwd(a["q0"], kv, kv[:, D:], 2 * D, a["ao"], D, a["lse"], dao, D, dq0, dkv, dkv[:, D:], 2 * D, R, S, 8, 0.125,
+                ops.attn_bwd(a["q0"], kv, kv[:, D:], 2 * D, a["ao"], D, a["lse"], dao, D, dq0, dkv, dkv[:, D:], 2 * D, R, S, H, 0.125,
                              Sq=1, ldq=D, lddq=D, drop=site(i, 0))
                 gb = g(l.self_attn.in_proj_bias)
                 ops.gemm_tn_acc(dkv, a["x"], dw[f"f{i}.in"][D:], M, 2 * D, D, db=gb[D:])
                 ops.gemm_tn_acc(dq0, a["x"], dw[f"f{i}.in"][:D], R, D, D, ldx=S * D, db=gb[:D])
                 dyf = ops.gemm_nt(dkv, wt[f"f{i}.in"][:, D:], M, D, 2 * D)                       # dX through K and V, all tokens
                 t0 = ops.gemm_nt(dq0, wt[f"f{i}.in"][:, :D], R, D, D, residual=dh1)             # position 0: Q path + residual path
-                ops.rows_add(dyf, S * D, t0, D, R)
+                ops.rows_add(dyf, S * D, t0, D, R, D)
                 c["fusion"][i] = None
                 continue
             d3, d1 = site(i, 3), site(i, 1)
             df = masked_like(a["h2"], d3 is not None)
             dh2 = ops.norm_bwd(dyf, a["h2"], l.norm2.weight, l.norm2.bias, a["n2"][0], a["n2"][1], M, g(l.norm2.weight), g(l.norm2.bias),
-                               dx_drop=df, drop=d3)
+                               dx_drop=df, drop=d3, D=D)
             df = dh2 if df is None else df               # grad of linear2's output (through dropout2); dh2 = residual-path grad
             ops.gemm_tn_acc(df, a["f1"], dw[f"f{i}.l2"], M, D, 2048, db=g(l.linear2.bias))
             # the sign bits were taken after ReLU and dropout: bit <=> (pre-activation > 0 and kept); alpha = the dropout scale
@@ -619,7 +632,7 @@ class Tower(nn.Module):
             del df1, df
             da = masked_like(a["h1"], d1 is not None)
             dh1 = ops.norm_bwd(dx1, a["h1"], l.norm1.weight, l.norm1.bias, a["n1"][0], a["n1"][1], M, g(l.norm1.weight), g(l.norm1.bias),
-                               dx_drop=da, drop=d1)
+                               dx_drop=da, drop=d1, D=D)
             da = dh1 if da is None else da
             ops.gemm_tn_acc(da, a["ao"], dw[f"f{i}.out"], M, D, D, db=g(l.self_attn.out_proj.bias))
             dao = ops.gemm_nt(da, wt[f"f{i}.out"], M, D, D)
@@ -629,7 +642,7 @@ class Tower(nn.Module):
                 ops.attn_fp8_bwd(a["f8"], a["ao"], a["lse"], dao, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D, 0.125, drop=site(i, 0))
             else:
                 ops.attn_bwd(q, q[:, D:], q[:, 2 * D:], 3 * D, a["ao"], D, a["lse"], dao, D, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D,
-                             R, S, 8, 0.125, drop=site(i, 0))
+                             R, S, H, 0.125, drop=site(i, 0))
             ops.gemm_tn_acc(dqkv, a["x"], dw[f"f{i}.in"], M, 3 * D, D, db=g(l.self_attn.in_proj_bias))
             dyf = ops.gemm_nt(dqkv, wt[f"f{i}.in"], M, D, 3 * D, residual=dh1)
             c["fusion"][i] = None
@@ -650,12 +663,12 @@ class Tower(nn.Module):
         dtf_b = torch.empty(U * L, D, device=dev, dtype=self.adt)
         ops.cast_bf16(dtf, dtf_b)
         dta = ops.norm_bwd(dtf_b, c["ta"], ve.text_adapter[1].weight, ve.text_adapter[1].bias, c["ta_stats"][0], c["ta_stats"][1], U * L,
-                           g(ve.text_adapter[1].weight), g(ve.text_adapter[1].bias), relu=True)
+                           g(ve.text_adapter[1].weight), g(ve.text_adapter[1].bias), relu=True, D=D)
         ops.gemm_tn_acc(dta, c["t5"], dw["ta"], U * L, D, self.text_dim, db=g(ve.text_adapter[0].bias))
         # visual adapter + compressor (both cameras in one batch)
         da1 = ops.norm_bwd(dx0, c["a1"], ve.visual_adapter[1].weight, ve.visual_adapter[1].bias, c["va"][0], c["va"][1], M2,
                            g(ve.visual_adapter[1].weight), g(ve.visual_adapter[1].bias), relu=True, dtok=self._dcamtok,
-                           tok_group=NPATCH, dymap=(2 * NPATCH, S, 1))
+                           tok_group=NPATCH, dymap=(2 * NPATCH, S, 1), D=D)
         ops.gemm_tn_acc(da1, c["c2"], dw["va"], M2, D, D, db=g(ve.visual_adapter[0].bias))
         dc2 = ops.gemm_nt(da1, wt["va"], M2, D, D, relu_bits=c["c2b"]) if c.get("c2b") is not None else ops.gemm_nt(da1, wt["va"], M2, D, D, relu_mask=c["c2"])
         ops.gemm_tn_acc(dc2, c["c1"], dw["c2"], M2, D, D, db=g(ve.visual_compressor[2].bias))

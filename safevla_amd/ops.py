@@ -458,26 +458,26 @@ def feat_to_tokens(feat, out, cam, ncam=2):
 
 
 def fusion_fill(fusion_token, text, gid, x0, R, S, L, text_off):
-    lib().call("svla_fusion_fill_f32" if x0.dtype == F32 else "svla_fusion_fill", _p(fusion_token), _p(text), _p(gid), R, S, L, text_off, _p(x0), _stream())
+    lib().call("svla_fusion_fill_f32" if x0.dtype == F32 else "svla_fusion_fill", _p(fusion_token), _p(text), _p(gid), R, S, L, text_off, int(x0.shape[-1]), _p(x0), _stream())
 
 
 def fusion_text_bwd(dx0, gid, T, B, S, L, text_off, dtext):
-    lib().call("svla_fusion_text_bwd_f32" if dx0.dtype == F32 else "svla_fusion_text_bwd", _p(dx0), _p(gid), T, B, S, L, text_off, _p(dtext), _stream())
+    lib().call("svla_fusion_text_bwd_f32" if dx0.dtype == F32 else "svla_fusion_text_bwd", _p(dx0), _p(gid), T, B, S, L, text_off, int(dtext.shape[-1]), _p(dtext), _stream())
 
 
 def decoder_embed_fwd(xf, xf_row_stride, act_tab, hand_tab, div_term, prev_actions, masks, hand, time_step, T, B, out,
                       n_actions=20):
     lib().call("svla_decoder_embed_fwd_f32" if out.dtype == F32 else "svla_decoder_embed_fwd", _p(xf), xf_row_stride, _p(act_tab), _p(hand_tab), _p(div_term), _p(prev_actions),
-               _p(masks), _p(hand), _p(time_step), T, B, n_actions, _p(out), _stream())
+               _p(masks), _p(hand), _p(time_step), T, B, n_actions, int(out.shape[-1]), _p(out), _stream())
 
 
 def decoder_embed_bwd(dout, prev_actions, masks, hand, T, B, dxf, dxf_row_stride, d_act_tab, d_hand_tab, n_actions=20):
-    lib().call("svla_decoder_embed_bwd_f32" if dout.dtype == F32 else "svla_decoder_embed_bwd", _p(dout), _p(prev_actions), _p(masks), _p(hand), T, B, n_actions, _p(dxf),
+    lib().call("svla_decoder_embed_bwd_f32" if dout.dtype == F32 else "svla_decoder_embed_bwd", _p(dout), _p(prev_actions), _p(masks), _p(hand), T, B, n_actions, int(dout.shape[-1]), _p(dxf),
                dxf_row_stride, _p(d_act_tab), _p(d_hand_tab), _stream())
 
 
-def rows_add(dst, dst_ld, src, src_ld, rows):
-    lib().call("svla_rows_add_f32" if dst.dtype == F32 else "svla_rows_add_bf16", _p(dst), dst_ld, _p(src), src_ld, rows, 512, _stream())
+def rows_add(dst, dst_ld, src, src_ld, rows, D=512):
+    lib().call("svla_rows_add_f32" if dst.dtype == F32 else "svla_rows_add_bf16", _p(dst), dst_ld, _p(src), src_ld, rows, D, _stream())
 
 
 def zeros(*shape, device, dtype):

@@ -118,70 +118,73 @@ def test_value_mse(ops):
     close(dv, vv.grad, 1e-5, 1e-9, "dv")
 
 
+@pytest.mark.parametrize("W_", [512, 768])
 @pytest.mark.parametrize("N,T,B", [(20, 0, 0), (1, 0, 0), (20, 7, 5), (1, 7, 5)])
-def test_small_linear(ops, N, T, B):
+def test_small_linear(ops, N, T, B, W_):
     rows = T * B if T else 37
-    x, W, b = rnd(rows, 512, seed=1), rnd(N, 512, seed=2, scale=0.05), rnd(N, seed=3)
+    x, W, b = rnd(rows, W_, seed=1), rnd(N, W_, seed=2, scale=0.05), rnd(N, seed=3)
     out = ops.small_linear_fwd(x.to(DEV), W.to(DEV), b.to(DEV), T, B)
-    xs = x.view(B, T, 512).permute(1, 0, 2).reshape(rows, 512) if T else x  # (b*T+t) storage -> (t*B+b) rows
+    xs = x.view(B, T, W_).permute(1, 0, 2).reshape(rows, W_) if T else x  # (b*T+t) storage -> (t*B+b) rows
     want = xs @ W.t() + b
     close(out, want, 1e-4, 1e-5, "fwd")
     dout = rnd(rows, N, seed=4)
-    dx = torch.zeros(rows, 512, device=DEV)
-    dW = torch.ones(N, 512, device=DEV)
+    dx = torch.zeros(rows, W_, device=DEV)
+    dW = torch.ones(N, W_, device=DEV)
     db = torch.ones(N, device=DEV)
     ops.small_linear_bwd(x.to(DEV), W.to(DEV), dout.to(DEV), dx, dW, db, T, B)
     dxs = dout @ W
     if T:
-        dxs = dxs.view(T, B, 512).permute(1, 0, 2).reshape(rows, 512)
+        dxs = dxs.view(T, B, W_).permute(1, 0, 2).reshape(rows, W_)
     close(dx, dxs, 1e-4, 1e-5, "dx")
     close(dW, 1 + dout.t() @ xs, 1e-4, 1e-4, "dW")
     close(db, 1 + dout.sum(0), 1e-4, 1e-4, "db")
 
 
 # ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("W_", [512, 768])
 @pytest.mark.parametrize("rms", [False, True])
-def test_norm_fwd_bwd_plain(ops, rms):
+def test_norm_fwd_bwd_plain(ops, rms, W_):
     rows = 333
-    x = bf(rnd(rows, 512, seed=1) * 2 + 0.3)
-    gma, bta = 1 + 0.1 * rnd(512, seed=2), 0.1 * rnd(512, seed=3)
+    x = bf(rnd(rows, W_, seed=1) * 2 + 0.3)
+    gma, bta = 1 + 0.1 * rnd(W_, seed=2), 0.1 * rnd(W_, seed=3)
     eps = 1e-5
     xr = x.clone().requires_grad_(True)
     gr, br = gma.clone().requires_grad_(True), bta.clone().requires_grad_(True)
     if rms:
         want = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + eps) * gr
     else:
-        want = F.layer_norm(xr, (512,), gr, br, eps)
-    y, mean, rstd = ops.norm_fwd(x.to(DEV).bfloat16(), gma.to(DEV), bta.to(DEV), eps, rows, rms=rms)
+        want = F.layer_norm(xr, (W_,), gr, br, eps)
+    y, mean, rstd = ops.norm_fwd(x.to(DEV).bfloat16(), gma.to(DEV), bta.to(DEV), eps, rows, rms=rms, D=W_)
     close(y.float(), want, 8e-3, 8e-3, "y")
-    dy = bf(rnd(rows, 512, seed=4))
+    dy = bf(rnd(rows, W_, seed=4))
     want.backward(dy)
-    dg, db = torch.zeros(512, device=DEV), torch.zeros(512, device=DEV)
-    dx = ops.norm_bwd(dy.to(DEV).bfloat16(), x.to(DEV).bfloat16(), gma.to(DEV), bta.to(DEV), mean, rstd, rows, dg, db, rms=rms)
+    dg, db = torch.zeros(W_, device=DEV), torch.zeros(W_, device=DEV)
+    dx = ops.norm_bwd(dy.to(DEV).bfloat16(), x.to(DEV).bfloat16(), gma.to(DEV), bta.to(DEV), mean, rstd, rows, dg, db, rms=rms, D=W_)
     close(dx.float(), xr.grad, 1e-2, 1e-2, "dx")
     close(dg, gr.grad, 2e-3, 2e-3 * gr.grad.abs().max().item(), "dgamma")
     if not rms:
         close(db, br.grad, 2e-3, 2e-3 * br.grad.abs().max().item(), "dbeta")
 
 
-def test_norm_adapter_rowmap_relu_tok(ops):
-    """Linear->LN->ReLU(+camera token) writing into the [R,S,512] fusion input: rows m=(r*2+cam)*84+p -> r*S+1+m%168."""
+@pytest.mark.parametrize("W_", [512, 768])
+def test_norm_adapter_rowmap_relu_tok(ops, W_):
+    """Linear->LN->ReLU(+camera token) writing into the [R,S,D] fusion input: rows m=(r*2+cam)*84+p -> r*S+1+m%168."""
     R, S, Gp = 5, 181, 168
     rows = R * Gp
-    x = bf(rnd(rows, 512, seed=1))
-    gma, bta, tok = 1 + 0.1 * rnd(512, seed=2), 0.1 * rnd(512, seed=3), rnd(2, 512, seed=4)
+    x = bf(rnd(rows, W_, seed=1))
+    gma, bta, tok = 1 + 0.1 * rnd(W_, seed=2), 0.1 * rnd(W_, seed=3), rnd(2, W_, seed=4)
     xr, gr, br, tr = [t.clone().requires_grad_(True) for t in (x, gma, bta, tok)]
-    z = F.relu(F.layer_norm(xr, (512,), gr, br, 1e-5)).view(R, 2, 84, 512) + tr.view(1, 2, 1, 512)
-    x0 = torch.full((R, S, 512), 7.0, device=DEV, dtype=torch.bfloat16)
+    z = F.relu(F.layer_norm(xr, (W_,), gr, br, 1e-5)).view(R, 2, 84, W_) + tr.view(1, 2, 1, W_)
+    x0 = torch.full((R, S, W_), 7.0, device=DEV, dtype=torch.bfloat16)
     _, mean, rstd = ops.norm_fwd(x.to(DEV).bfloat16(), gma.to(DEV), bta.to(DEV), 1e-5, rows, relu=True, tok=tok.to(DEV),
-                                 tok_group=84, y=x0, ymap=(Gp, S, 1))
-    close(x0[:, 1:169].float(), z.reshape(R, Gp, 512), 8e-3, 8e-3, "y slice")
+                                 tok_group=84, y=x0, ymap=(Gp, S, 1), D=W_)
+    close(x0[:, 1:169].float(), z.reshape(R, Gp, W_), 8e-3, 8e-3, "y slice")
     assert (x0[:, 0] == 7).all() and (x0[:, 169:] == 7).all()
-    dx0 = bf(rnd(R, S, 512, seed=5))
-    z.backward(dx0[:, 1:169].reshape(R, 2, 84, 512))
-    dg, db, dt = torch.zeros(512, device=DEV), torch.zeros(512, device=DEV), torch.zeros(2, 512, device=DEV)
+    dx0 = bf(rnd(R, S, W_, seed=5))
+    z.backward(dx0[:, 1:169].reshape(R, 2, 84, W_))
+    dg, db, dt = torch.zeros(W_, device=DEV), torch.zeros(W_, device=DEV), torch.zeros(2, W_, device=DEV)
     dx = ops.norm_bwd(dx0.to(DEV).bfloat16(), x.to(DEV).bfloat16(), gma.to(DEV), bta.to(DEV), mean, rstd, rows, dg, db, relu=True,
-                      dtok=dt, tok_group=84, dymap=(Gp, S, 1))
+                      dtok=dt, tok_group=84, dymap=(Gp, S, 1), D=W_)
     close(dx.float(), xr.grad, 1e-2, 1e-2, "dx")
     close(dg, gr.grad, 2e-3, 2e-3 * gr.grad.abs().max().item(), "dgamma")
     close(db, br.grad, 2e-3, 2e-3 * br.grad.abs().max().item(), "dbeta")
@@ -330,11 +333,12 @@ def test_attn_query_subset(ops, Sq):
         close(dkv[:, i * H * 64 : (i + 1) * H * 64].float().view(rows, S, H, 64), w, 2e-2, 2e-2 * w.abs().max().item() + 1e-3, n + " subset")
 
 
-def test_rows_add(ops):
+@pytest.mark.parametrize("W_", [512, 768])
+def test_rows_add(ops, W_):
     R, S = 37, 11
-    dst, src = bf(rnd(R, S, 512, seed=1)), bf(rnd(R, 512, seed=2))
+    dst, src = bf(rnd(R, S, W_, seed=1)), bf(rnd(R, W_, seed=2))
     d = dst.to(DEV).bfloat16()
-    ops.rows_add(d, S * 512, src.to(DEV).bfloat16(), 512, R)
+    ops.rows_add(d, S * W_, src.to(DEV).bfloat16(), W_, R, W_)
     want = dst.clone()
     want[:, 0] = bf(dst[:, 0] + src)
     assert torch.equal(d.float().cpu(), want)
@@ -431,10 +435,11 @@ def test_feat_to_tokens(ops):
     assert torch.equal(out.float().cpu(), bf(want))
 
 
-def test_fusion_fill_and_text_bwd(ops):
+@pytest.mark.parametrize("W_", [512, 768])
+def test_fusion_fill_and_text_bwd(ops, W_):
     T, B, L, S = 9, 4, 6, 181
     R, U = T * B, 5
-    ft, text = rnd(512, seed=1), bf(rnd(U, L, 512, seed=2))
+    ft, text = rnd(W_, seed=1), bf(rnd(U, L, W_, seed=2))
     g = torch.Generator().manual_seed(3)
     gid = torch.zeros(T, B, dtype=torch.int32)
     cur = torch.randint(0, U, (B,), generator=g)
@@ -442,46 +447,47 @@ def test_fusion_fill_and_text_bwd(ops):
         flip = torch.rand(B, generator=g) < 0.3
         cur = torch.where(flip, torch.randint(0, U, (B,), generator=g), cur)
         gid[t] = cur
-    x0 = torch.full((R, S, 512), 3.0, device=DEV, dtype=torch.bfloat16)
+    x0 = torch.full((R, S, W_), 3.0, device=DEV, dtype=torch.bfloat16)
     ops.fusion_fill(ft.to(DEV), text.to(DEV).bfloat16(), gid.reshape(R).to(DEV), x0, R, S, L, 169)
-    assert torch.equal(x0[:, 0].float().cpu(), bf(ft).expand(R, 512))
+    assert torch.equal(x0[:, 0].float().cpu(), bf(ft).expand(R, W_))
     assert torch.equal(x0[:, 169 : 169 + L].float().cpu(), text[gid.reshape(R).long()])
     assert (x0[:, 1:169] == 3).all() and (x0[:, 169 + L :] == 3).all()
-    dx0 = bf(rnd(R, S, 512, seed=4))
-    dtext = torch.zeros(U, L, 512, device=DEV)
+    dx0 = bf(rnd(R, S, W_, seed=4))
+    dtext = torch.zeros(U, L, W_, device=DEV)
     ops.fusion_text_bwd(dx0.to(DEV).bfloat16(), gid.reshape(R).to(DEV), T, B, S, L, 169, dtext)
-    want = torch.zeros(U, L, 512).index_add_(0, gid.reshape(R).long(), dx0[:, 169 : 169 + L])
+    want = torch.zeros(U, L, W_).index_add_(0, gid.reshape(R).long(), dx0[:, 169 : 169 + L])
     close(dtext, want, 1e-5, 1e-5, "dtext")
 
 
-def test_decoder_embed(ops):
+@pytest.mark.parametrize("W_", [512, 768])
+def test_decoder_embed(ops, W_):
     T, B, S = 6, 5, 181
     R = T * B
     g = torch.Generator().manual_seed(0)
-    xf = bf(rnd(R, S, 512, seed=1))
-    act, hand_t = rnd(22, 512, seed=2, scale=0.3), rnd(3, 512, seed=3, scale=0.3)
-    div = torch.exp(torch.arange(0, 512, 2) * (-math.log(10000.0) / 512))
+    xf = bf(rnd(R, S, W_, seed=1))
+    act, hand_t = rnd(22, W_, seed=2, scale=0.3), rnd(3, W_, seed=3, scale=0.3)
+    div = torch.exp(torch.arange(0, W_, 2) * (-math.log(10000.0) / W_))
     pa = torch.randint(0, 20, (T, B), generator=g)
     masks = (torch.rand(T, B, generator=g) > 0.3).float()
     hand = torch.randint(0, 2, (T, B), generator=g)
     ts = torch.randint(0, 500, (T, B), generator=g)
-    out = torch.empty(B * T, 512, device=DEV, dtype=torch.bfloat16)
-    ops.decoder_embed_fwd(xf.to(DEV).bfloat16(), S * 512, act.to(DEV), hand_t.to(DEV), div.to(DEV), pa.to(DEV), masks.to(DEV),
+    out = torch.empty(B * T, W_, device=DEV, dtype=torch.bfloat16)
+    ops.decoder_embed_fwd(xf.to(DEV).bfloat16(), S * W_, act.to(DEV), hand_t.to(DEV), div.to(DEV), pa.to(DEV), masks.to(DEV),
                           hand.to(DEV), ts.to(DEV), T, B, out)
-    pe = torch.zeros(T, B, 512)
+    pe = torch.zeros(T, B, W_)
     pe[..., 0::2] = torch.sin(ts.unsqueeze(-1) * div)
     pe[..., 1::2] = torch.cos(ts.unsqueeze(-1) * div)
     idx = torch.where(masks != 0, pa, torch.full_like(pa, 20))
-    want = pe + xf[:, 0].view(T, B, 512) + act[idx] + hand_t[hand]
-    close(out.float().view(B, T, 512).permute(1, 0, 2), want, 8e-3, 8e-3, "joint")
-    dout = bf(rnd(B * T, 512, seed=5))
-    dxf = torch.zeros(R, S, 512, device=DEV, dtype=torch.bfloat16)
-    da, dh = torch.zeros(22, 512, device=DEV), torch.zeros(3, 512, device=DEV)
-    ops.decoder_embed_bwd(dout.to(DEV).bfloat16(), pa.to(DEV), masks.to(DEV), hand.to(DEV), T, B, dxf, S * 512, da, dh)
-    d_tb = dout.view(B, T, 512).permute(1, 0, 2).reshape(R, 512)
+    want = pe + xf[:, 0].view(T, B, W_) + act[idx] + hand_t[hand]
+    close(out.float().view(B, T, W_).permute(1, 0, 2), want, 8e-3, 8e-3, "joint")
+    dout = bf(rnd(B * T, W_, seed=5))
+    dxf = torch.zeros(R, S, W_, device=DEV, dtype=torch.bfloat16)
+    da, dh = torch.zeros(22, W_, device=DEV), torch.zeros(3, W_, device=DEV)
+    ops.decoder_embed_bwd(dout.to(DEV).bfloat16(), pa.to(DEV), masks.to(DEV), hand.to(DEV), T, B, dxf, S * W_, da, dh)
+    d_tb = dout.view(B, T, W_).permute(1, 0, 2).reshape(R, W_)
     assert torch.equal(dxf[:, 0].float().cpu(), d_tb) and (dxf[:, 1:] == 0).all()
-    close(da, torch.zeros(22, 512).index_add_(0, idx.reshape(R), d_tb), 1e-5, 1e-4, "d act")
-    close(dh, torch.zeros(3, 512).index_add_(0, hand.reshape(R), d_tb), 1e-5, 1e-4, "d hand")
+    close(da, torch.zeros(22, W_).index_add_(0, idx.reshape(R), d_tb), 1e-5, 1e-4, "d act")
+    close(dh, torch.zeros(3, W_).index_add_(0, hand.reshape(R), d_tb), 1e-5, 1e-4, "d hand")
 
 
 def test_swiglu(ops):
