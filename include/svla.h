@@ -300,6 +300,8 @@ int svla_norm_bwd_f32(const float* dy, int dyG, int dyGS, int dyOFF, const float
                       const float* beta, const float* mean, const float* rstd, int rows, int D, int rms, int relu, int tok_group,
                       const float* dres, float* dx, int dxG, int dxGS, int dxOFF, float* dgamma, float* dbeta, float* dtok, float* dx_drop,
                       const svla_dropout* drop, void* stream);
+/* fp32 attention: head_dim <= 128 (64 for the policy; 96 for the imitation-learning presets with TransformerConfig(n, 768, 8), early_fusion_tsfm_models.py:236-240,275-279,
+ * whose bf16 activations take these kernels through fp32 copies: the MFMA kernels above are built for 64-wide heads), S <= 512. */
 int svla_attn_fwd_f32(const float* Q, const float* K, const float* V, long ld, float* O, long ldo, float* LSE, int rows, int S, int H,
                       int head_dim, float scale, int mask_mode, const int* traj, const float* bias, const unsigned char* kvalid, int Sq,
                       long ldq, int kv_rows, const svla_dropout* drop, void* stream);

@@ -19,7 +19,7 @@ NAV, MANIP = "raw_navigation_camera", "raw_manipulation_camera"
 
 
 class RefEarlyFusion(nn.Module):
-    def __init__(self, max_length=1000, max_batch=8, n_fusion_layers=3, n_decoder_layers=3, dino_dim=384, text_encoder="t5-small", d_model=512, n_heads=8):
+    def __init__(self, max_length=1000, max_batch=8, n_fusion_layers=3, n_decoder_layers=3, dino_dim=384, text_encoder="t5-small", d_model=512, n_heads=8, n_heads_decoder=None):
         """defaults = ``small_3``; (6, 6, 384) = ``small_6``; (3, 3, 768) = ``base_3``; (3, 3, 768, "SigLIPBase") = ``siglip_base_3``;
         (3, 3, 1024, "SigLIPLarge") = ``siglip_large_3``; (3, 3, 2048) = ``clip_resnet_50_3``; (6, 3, 768, "SigLIPBase", 768, 12) = ``siglip_base_6_3``
         (early_fusion_tsfm_models.py:221-312)."""
@@ -33,7 +33,7 @@ class RefEarlyFusion(nn.Module):
             te, td = RefSigLIPText(**cfg), cfg["width"]
             te.output_tokens = True                                                # text_cond_visual_encoder.py:39
         self.visual_encoder = RefGoalEncoder(tokenizer=None, d=d, n_heads=n_heads, n_layers=n_fusion_layers, dino_dim=dino_dim, text_encoder=te, text_dim=td)
-        self.decoder = RefLlamaDecoder(d, n_decoder_layers, n_heads, 1e-5, max_batch, max_length)
+        self.decoder = RefLlamaDecoder(d, n_decoder_layers, n_heads if n_heads_decoder is None else n_heads_decoder, 1e-5, max_batch, max_length)
         self.actor = nn.Linear(d, N_ACTIONS)
         self.time_encoder = RefPositionalEncoder(d)
         self.last_actions_embed = nn.Embedding(N_ACTIONS + 2, d, padding_idx=N_ACTIONS + 1)

@@ -125,9 +125,11 @@ struct AttnF32Args {
     const int* traj; const float* bias; const unsigned char* kvalid;
     int S, H, mask_mode; float scale; int kv_rows, Sq; long ldq, lddq;
     DropCfg drop;
+    int hd;           // head width: 64 everywhere in the policy; 96 in two imitation-learning presets (TransformerConfig(n, 768, 8)); <= 128, lane l owns dims l and l + 64
 };
 #define AF_MAXS 512
 #define AF_KPL (AF_MAXS / 64)
+#define AF_MAXHD 128
 
 __device__ __forceinline__ bool af_masked(const AttnF32Args& p, int r, int q, int k) {
     if (p.mask_mode == 1 && (k > q || p.traj[(size_t)r * p.S + k] != p.traj[(size_t)r * p.S + q])) return true;
@@ -140,13 +142,16 @@ __device__ __forceinline__ bool af_keep(const AttnF32Args& p, int r, int h, int 
     const unsigned x = drop_bits(p.drop.key, e >> 1);
     return ((e & 1) ? (x >> 16) : (x & 0xffffu)) >= p.drop.thr;
 }
+__device__ __forceinline__ float af_dot(const float* a, const float* b, int hd) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < hd; ++d) s = fmaf(a[d], b[d], s);
+    return s;
+}
 // scaled + biased score of (q, k), or -inf when masked
 __device__ __forceinline__ float af_score(const AttnF32Args& p, int r, int h, int q, int k, const float* qrow, const float* krow) {
     if (af_masked(p, r, q, k)) return -INFINITY;
-    float s = 0.f;
-#pragma unroll 8
-    for (int d = 0; d < 64; ++d) s = fmaf(qrow[d], krow[d], s);
-    s *= p.scale;
+    float s = af_dot(qrow, krow, p.hd) * p.scale;
     if (p.bias) s += p.bias[((size_t)h * p.S + q) * p.S + k];
     return s;
 }
@@ -154,14 +159,16 @@ __device__ __forceinline__ float af_score(const AttnF32Args& p, int r, int h, in
 __global__ void __launch_bounds__(256) attn_fwd_f32_kernel(AttnF32Args p) {
     p.drop = drop_resolve(p.drop);
     __shared__ float ps[4][AF_MAXS];
-    __shared__ float qs[4][64];
+    __shared__ float qs[4][AF_MAXHD];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int r = blockIdx.x / p.H, h = blockIdx.x % p.H;
-    const float* Kb = p.K + (size_t)r * p.kv_rows * p.ld + h * 64;
-    const float* Vb = p.V + (size_t)r * p.kv_rows * p.ld + h * 64;
+    const int r = blockIdx.x / p.H, h = blockIdx.x % p.H, hd = p.hd;
+    const bool hi = lane + 64 < hd;           // this lane also owns dim lane + 64
+    const float* Kb = p.K + (size_t)r * p.kv_rows * p.ld + h * hd;
+    const float* Vb = p.V + (size_t)r * p.kv_rows * p.ld + h * hd;
     for (int q = wid; q < p.Sq; q += 4) {
         const size_t qtok = (size_t)r * p.Sq + q;
-        qs[wid][lane] = p.Q[qtok * p.ldq + h * 64 + lane];
+        if (lane < hd) qs[wid][lane] = p.Q[qtok * p.ldq + h * hd + lane];
+        if (hi) qs[wid][lane + 64] = p.Q[qtok * p.ldq + h * hd + lane + 64];
         __builtin_amdgcn_wave_barrier();
         float sc[AF_KPL], mx = -INFINITY;
 #pragma unroll
@@ -183,9 +190,14 @@ __global__ void __launch_bounds__(256) attn_fwd_f32_kernel(AttnF32Args p) {
             if (k < p.S) ps[wid][k] = af_keep(p, r, h, q, k) ? sc[u] * inv * p.drop.scale : 0.f;
         }
         __builtin_amdgcn_wave_barrier();
-        float o = 0.f;
-        for (int k = 0; k < p.S; ++k) o = fmaf(ps[wid][k], Vb[(size_t)k * p.ld + lane], o);
-        p.O[qtok * p.ldo + h * 64 + lane] = o;
+        float o = 0.f, o2 = 0.f;
+        for (int k = 0; k < p.S; ++k) {
+            const float pk = ps[wid][k];
+            if (lane < hd) o = fmaf(pk, Vb[(size_t)k * p.ld + lane], o);
+            if (hi) o2 = fmaf(pk, Vb[(size_t)k * p.ld + lane + 64], o2);
+        }
+        if (lane < hd) p.O[qtok * p.ldo + h * hd + lane] = o;
+        if (hi) p.O[qtok * p.ldo + h * hd + lane + 64] = o2;
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -195,17 +207,28 @@ __global__ void __launch_bounds__(256) attn_bwd_f32_kernel(AttnF32Args p) {
     p.drop = drop_resolve(p.drop);
     __shared__ float ws[4][AF_MAXS], ws2[4][AF_MAXS];
     __shared__ float Dq[AF_MAXS];
-    __shared__ float vec[4][64], vec2[4][64];
+    __shared__ float vec[4][AF_MAXHD], vec2[4][AF_MAXHD];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int r = blockIdx.x / p.H, h = blockIdx.x % p.H;
-    const float* Kb = p.K + (size_t)r * p.S * p.ld + h * 64;
-    const float* Vb = p.V + (size_t)r * p.S * p.ld + h * 64;
+    const int r = blockIdx.x / p.H, h = blockIdx.x % p.H, hd = p.hd;
+    const bool lo = lane < hd, hi = lane + 64 < hd;
+    const float* Kb = p.K + (size_t)r * p.S * p.ld + h * hd;
+    const float* Vb = p.V + (size_t)r * p.S * p.ld + h * hd;
     for (int q = wid; q < p.Sq; q += 4) {
         const size_t qtok = (size_t)r * p.Sq + q;
-        vec[wid][lane] = p.Q[qtok * p.ldq + h * 64 + lane];
-        const float dov = p.dO[qtok * p.lddo + h * 64 + lane];
-        vec2[wid][lane] = dov;
-        const float D = wave_sum(dov * p.O[qtok * p.ldo + h * 64 + lane]);
+        float dsum = 0.f;
+        if (lo) {
+            vec[wid][lane] = p.Q[qtok * p.ldq + h * hd + lane];
+            const float dov = p.dO[qtok * p.lddo + h * hd + lane];
+            vec2[wid][lane] = dov;
+            dsum = dov * p.O[qtok * p.ldo + h * hd + lane];
+        }
+        if (hi) {
+            vec[wid][lane + 64] = p.Q[qtok * p.ldq + h * hd + lane + 64];
+            const float dov = p.dO[qtok * p.lddo + h * hd + lane + 64];
+            vec2[wid][lane + 64] = dov;
+            dsum += dov * p.O[qtok * p.ldo + h * hd + lane + 64];
+        }
+        const float D = wave_sum(dsum);
         if (lane == 0) Dq[q] = D;
         __builtin_amdgcn_wave_barrier();
         const float lse = p.LSE[((size_t)r * p.H + h) * p.Sq + q];
@@ -215,36 +238,35 @@ __global__ void __launch_bounds__(256) attn_bwd_f32_kernel(AttnF32Args p) {
             if (k < p.S) {
                 const float s = af_score(p, r, h, q, k, vec[wid], Kb + (size_t)k * p.ld);
                 const float pr = (s == -INFINITY) ? 0.f : expf(s - lse);
-                float dp = 0.f;
-                const float* vr = Vb + (size_t)k * p.ld;
-#pragma unroll 8
-                for (int d = 0; d < 64; ++d) dp = fmaf(vec2[wid][d], vr[d], dp);
+                float dp = af_dot(vec2[wid], Vb + (size_t)k * p.ld, hd);
                 dp = af_keep(p, r, h, q, k) ? dp * p.drop.scale : 0.f;
                 ws[wid][k] = pr * (dp - D) * p.scale;           // dS (scaled)
             }
         }
         __builtin_amdgcn_wave_barrier();
-        float dq = 0.f;
-        for (int k = 0; k < p.S; ++k) dq = fmaf(ws[wid][k], Kb[(size_t)k * p.ld + lane], dq);
-        p.dQ[qtok * p.lddq + h * 64 + lane] = dq;
+        float dq = 0.f, dq2 = 0.f;
+        for (int k = 0; k < p.S; ++k) {
+            const float w = ws[wid][k];
+            if (lo) dq = fmaf(w, Kb[(size_t)k * p.ld + lane], dq);
+            if (hi) dq2 = fmaf(w, Kb[(size_t)k * p.ld + lane + 64], dq2);
+        }
+        if (lo) p.dQ[qtok * p.lddq + h * hd + lane] = dq;
+        if (hi) p.dQ[qtok * p.lddq + h * hd + lane + 64] = dq2;
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     for (int k = wid; k < p.S; k += 4) {
-        vec[wid][lane] = Kb[(size_t)k * p.ld + lane];
-        vec2[wid][lane] = Vb[(size_t)k * p.ld + lane];
+        if (lo) { vec[wid][lane] = Kb[(size_t)k * p.ld + lane]; vec2[wid][lane] = Vb[(size_t)k * p.ld + lane]; }
+        if (hi) { vec[wid][lane + 64] = Kb[(size_t)k * p.ld + lane + 64]; vec2[wid][lane + 64] = Vb[(size_t)k * p.ld + lane + 64]; }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int u = 0; u < AF_KPL; ++u) {
             const int q = lane + 64 * u;
             if (q < p.Sq) {
                 const size_t qtok = (size_t)r * p.Sq + q;
-                const float s = af_score(p, r, h, q, k, p.Q + qtok * p.ldq + h * 64, vec[wid]);
+                const float s = af_score(p, r, h, q, k, p.Q + qtok * p.ldq + h * hd, vec[wid]);
                 const float pr = (s == -INFINITY) ? 0.f : expf(s - p.LSE[((size_t)r * p.H + h) * p.Sq + q]);
-                float dp = 0.f;
-                const float* dor = p.dO + qtok * p.lddo + h * 64;
-#pragma unroll 8
-                for (int d = 0; d < 64; ++d) dp = fmaf(dor[d], vec2[wid][d], dp);
+                float dp = af_dot(p.dO + qtok * p.lddo + h * hd, vec2[wid], hd);
                 const bool keep = af_keep(p, r, h, q, k);
                 dp = keep ? dp * p.drop.scale : 0.f;
                 ws[wid][q] = pr * (dp - Dq[q]) * p.scale;       // dS[q, k]
@@ -252,15 +274,16 @@ __global__ void __launch_bounds__(256) attn_bwd_f32_kernel(AttnF32Args p) {
             }
         }
         __builtin_amdgcn_wave_barrier();
-        float dk = 0.f, dv = 0.f;
+        float dk = 0.f, dv = 0.f, dk2 = 0.f, dv2 = 0.f;
         for (int q = 0; q < p.Sq; ++q) {
             const size_t qtok = (size_t)r * p.Sq + q;
-            dk = fmaf(ws[wid][q], p.Q[qtok * p.ldq + h * 64 + lane], dk);
-            dv = fmaf(ws2[wid][q], p.dO[qtok * p.lddo + h * 64 + lane], dv);
+            const float a = ws[wid][q], b = ws2[wid][q];
+            if (lo) { dk = fmaf(a, p.Q[qtok * p.ldq + h * hd + lane], dk); dv = fmaf(b, p.dO[qtok * p.lddo + h * hd + lane], dv); }
+            if (hi) { dk2 = fmaf(a, p.Q[qtok * p.ldq + h * hd + lane + 64], dk2); dv2 = fmaf(b, p.dO[qtok * p.lddo + h * hd + lane + 64], dv2); }
         }
         const size_t ktok = (size_t)r * p.S + k;
-        p.dK[ktok * p.ldd + h * 64 + lane] = dk;
-        p.dV[ktok * p.ldd + h * 64 + lane] = dv;
+        if (lo) { p.dK[ktok * p.ldd + h * hd + lane] = dk; p.dV[ktok * p.ldd + h * hd + lane] = dv; }
+        if (hi) { p.dK[ktok * p.ldd + h * hd + lane + 64] = dk2; p.dV[ktok * p.ldd + h * hd + lane + 64] = dv2; }
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -268,10 +291,10 @@ __global__ void __launch_bounds__(256) attn_bwd_f32_kernel(AttnF32Args p) {
 extern "C" int svla_attn_fwd_f32(const float* Q, const float* K, const float* V, long ld, float* O, long ldo, float* LSE, int rows, int S,
                                  int H, int head_dim, float scale, int mask_mode, const int* traj, const float* bias,
                                  const unsigned char* kvalid, int Sq, long ldq, int kv_rows, const svla_dropout* drop, void* stream) {
-    if (rows <= 0 || S <= 0 || S > AF_MAXS || H <= 0 || head_dim != 64 || (mask_mode == 1 && !traj) || Sq < 0 || Sq > S) return SVLA_EINVAL;
+    if (rows <= 0 || S <= 0 || S > AF_MAXS || H <= 0 || head_dim <= 0 || head_dim > AF_MAXHD || (mask_mode == 1 && !traj) || Sq < 0 || Sq > S) return SVLA_EINVAL;
     if (kv_rows && kv_rows < S) return SVLA_EINVAL;
     AttnF32Args p{Q, K, V, ld, O, ldo, LSE, nullptr, 0, nullptr, nullptr, nullptr, 0, traj, bias, kvalid, S, H, mask_mode, scale,
-                  kv_rows ? kv_rows : S, Sq ? Sq : S, Sq ? ldq : ld, 0, drop_cfg(drop)};
+                  kv_rows ? kv_rows : S, Sq ? Sq : S, Sq ? ldq : ld, 0, drop_cfg(drop), head_dim};
     hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(rows * H), dim3(256), 0, (hipStream_t)stream, p);
     return svla_launch_status();
 }
@@ -280,9 +303,9 @@ extern "C" int svla_attn_bwd_f32(const float* Q, const float* K, const float* V,
                                  const float* dO, long lddo, float* dQ, float* dK, float* dV, long ldd, int rows, int S, int H,
                                  int head_dim, float scale, int mask_mode, const int* traj, const unsigned char* kvalid, int Sq, long ldq,
                                  long lddq, const svla_dropout* drop, void* stream) {
-    if (rows <= 0 || S <= 0 || S > AF_MAXS || H <= 0 || head_dim != 64 || (mask_mode == 1 && !traj) || Sq < 0 || Sq > S || !LSE) return SVLA_EINVAL;
+    if (rows <= 0 || S <= 0 || S > AF_MAXS || H <= 0 || head_dim <= 0 || head_dim > AF_MAXHD || (mask_mode == 1 && !traj) || Sq < 0 || Sq > S || !LSE) return SVLA_EINVAL;
     AttnF32Args p{Q, K, V, ld, const_cast<float*>(O), ldo, const_cast<float*>(LSE), dO, lddo, dQ, dK, dV, ldd, traj, nullptr, kvalid, S, H,
-                  mask_mode, scale, S, Sq ? Sq : S, Sq ? ldq : ld, Sq ? lddq : ldd, drop_cfg(drop)};
+                  mask_mode, scale, S, Sq ? Sq : S, Sq ? ldq : ld, Sq ? lddq : ldd, drop_cfg(drop), head_dim};
     hipLaunchKernelGGL(attn_bwd_f32_kernel, dim3(rows * H), dim3(256), 0, (hipStream_t)stream, p);
     return svla_launch_status();
 }

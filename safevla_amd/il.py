@@ -1,6 +1,6 @@
 """Offline imitation-learning workload on the same kernels.
 
-Mirrors ``EarlyFusionCnnTransformer`` with the llama decoder, in every ``model_version`` whose transformers have 64-wide heads (512 x 8, 768 x 12)
+Mirrors ``EarlyFusionCnnTransformer`` with the llama decoder, in every ``model_version`` the reference can construct (512 x 8 and 768 x 12 on the MFMA attention kernels; 768 x 8 = heads of 96 on the fp32 ones)
 (/root/reference/architecture/models/transformer_models/early_fusion_tsfm_models.py:49-207,221-312; ``VERSIONS`` below): text-conditioned multi-camera
 encoder (text_cond_visual_encoder.py:56-268) -> + last-action / in-hand / time embeddings (:120-157) -> causal llama decoder ->
 ``actor`` -> ``nn.CrossEntropyLoss(ignore_index=-1)`` (:93,115-117); and the optimiser of ``training/offline/train_pl.py:283-287``
@@ -49,24 +49,27 @@ class EarlyFusionCnnTransformer(Tower):
     # fusion transformer and decoder are TransformerConfig(n, 512, 8), with the llama decoder (``use_llama_decoder`` defaults to True, :46):
     # DINOv2-S / -B, SigLIP-B / -L (image trunk + text tower) and CLIP RN50 (pre-encoded features only: its conv trunk is not built).
     # and the 768-wide presets whose heads are 64 wide (12 heads: siglip_base_6_3 / _6_6 / _12_12; same kernels at D = 768, llama hidden 2048).
-    # Not built: TransformerConfig(n, 768, 8) = heads of 96 (base_6, and the fusion transformer of siglip_base_3_6) and the nonTx encoders
-    # (small_3_nonTxEnc, siglip_base_3_nonTxEnc).  ``siglip_base_384_3`` / ``siglip_base_384_resize_3`` name image encoders that the reference's own
-    # IMAGE_ENCODERS table (image_encoders.py:103-112) does not contain -- they cannot be built there either.
+    # TransformerConfig(n, 768, 8) = heads of 96 (base_6, and the fusion transformer of siglip_base_3_6) builds too, with its attention on the fp32 kernels.
+    # Four more names cannot be constructed in the reference as shipped: small_3_nonTxEnc / siglip_base_3_nonTxEnc (``globals()["NonTxMultiCameraVisualEncoder"]``, :64, is a KeyError: the class is not
+    # imported into that module, :22-28) and siglip_base_384_3 / siglip_base_384_resize_3 (image encoders absent from IMAGE_ENCODERS, image_encoders.py:103-112).
     VERSIONS = {"small": (3, 3, 384, "t5-small"), "small_3": (3, 3, 384, "t5-small"), "small_6": (6, 6, 384, "t5-small"), "base_3": (3, 3, 768, "t5-small"),
                 "siglip_base_3": (3, 3, 768, "SigLIPBase"), "siglip_3": (3, 3, 768, "SigLIPBase"), "siglip_base_3_llama": (3, 3, 768, "SigLIPBase"),
                 "siglip_base_6": (6, 6, 768, "SigLIPBase"), "siglip_large_3": (3, 3, 1024, "SigLIPLarge"), "clip_resnet_50_3": (3, 3, 2048, "t5-small"),
                 "siglip_base_6_3": (6, 3, 768, "SigLIPBase", 768, 12), "siglip_base_6_6": (6, 6, 768, "SigLIPBase", 768, 12),
-                "siglip_base_12_12": (12, 12, 768, "SigLIPBase", 768, 12)}
+                "siglip_base_12_12": (12, 12, 768, "SigLIPBase", 768, 12),
+                # heads of 96 (768 / 8): attention on the fp32 kernels (ops.attn_fwd head_dim != 64), everything else as above -- a slow path
+                "base_6": (6, 6, 768, "t5-small", 768, 8), "siglip_base_3_6": (3, 6, 768, "SigLIPBase", 768, 8, 12)}
 
     def __init__(self, device="cuda", max_length: int = 1000, input_sensors=(NAV, MANIP, "last_actions", "an_object_is_in_hand"),
-                 image_preprocessor=None, n_fusion_layers: int = 3, n_decoder_layers: int = 3, dino_dim: int = DINO, text_encoder: str = "t5-small", d_model: int = 512, n_heads: int = 8):
+                 image_preprocessor=None, n_fusion_layers: int = 3, n_decoder_layers: int = 3, dino_dim: int = DINO, text_encoder: str = "t5-small", d_model: int = 512, n_heads: int = 8,
+                 n_heads_decoder: Optional[int] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("safevla_amd needs an MI355X: there is no CPU or eager fallback for the policy kernels")
         ops.lib()
         arena = _Arena()
         device = torch.device(device)
         super().__init__(arena, device, n_fusion_layers=n_fusion_layers, n_decoder_layers=n_decoder_layers, max_steps=max_length, dino_dim=dino_dim,
-                         text_encoder=text_encoder, d_model=d_model, n_heads=n_heads)
+                         text_encoder=text_encoder, d_model=d_model, n_heads=n_heads, n_heads_decoder=n_heads_decoder)
         arena.build(device)
         self.bind()
         self.towers = [self]
@@ -174,13 +177,21 @@ class EarlyFusionCnnTransformer(Tower):
         return out
 
     @classmethod
+    def version_config(cls, model_version):
+        """(fusion layers, decoder layers, image-feature width, text encoder, transformer width, fusion heads, decoder heads) of a preset"""
+        v = cls.VERSIONS[model_version]
+        v = v + (512, 8)[len(v) - 4:] if len(v) < 6 else v
+        return v if len(v) == 7 else v + (v[5],)
+
+    @classmethod
     def build_model(cls, model_version="small_3", input_sensors=(NAV, MANIP, "last_actions", "an_object_is_in_hand"), loss="action",
                     device="cuda", ckpt_pth: Optional[str] = None, ckpt_prefix: str = "model."):
         if model_version not in cls.VERSIONS:
             raise NotImplementedError(f"model_version {model_version!r}: built are {sorted(cls.VERSIONS)} (512-wide fusion transformer + llama decoder; "
                                       "early_fusion_tsfm_models.py:221-312)")
-        nf, nd, dd, te, dm, nh = (cls.VERSIONS[model_version] + (512, 8))[:6]
-        m = cls(device=device, input_sensors=input_sensors, n_fusion_layers=nf, n_decoder_layers=nd, dino_dim=dd, text_encoder=te, d_model=dm, n_heads=nh)
+        nf, nd, dd, te, dm, nh, nhd = cls.version_config(model_version)
+        m = cls(device=device, input_sensors=input_sensors, n_fusion_layers=nf, n_decoder_layers=nd, dino_dim=dd, text_encoder=te, d_model=dm, n_heads=nh,
+                n_heads_decoder=nhd)
         if ckpt_pth is not None:    # Lightning checkpoint (training/offline/train_utils.py:6-68)
             sd = torch.load(ckpt_pth, map_location="cpu")["state_dict"]
             m.load_state_dict({k[len(ckpt_prefix):]: v for k, v in sd.items() if k.startswith(ckpt_prefix)}, strict=False)

@@ -129,14 +129,19 @@ class Tower(nn.Module):
     """``DinoLLAMATxNavActorCritic`` (full-sensor configuration of dinov2_vits_tsfm_base.py:234-270)."""
 
     def __init__(self, arena: _Arena, device, n_fusion_layers=3, n_decoder_layers=3, max_steps=500, critic_type="linear",
-                 precision="bf16", dino_dim=DINO, text_encoder="t5-small", d_model=512, n_heads=8):
+                 precision="bf16", dino_dim=DINO, text_encoder="t5-small", d_model=512, n_heads=8, n_heads_decoder=None):
         super().__init__()
         # transformer width of the fusion encoder AND the decoder (512 x 8 heads everywhere in the RL towers, allenact_dino_transformer.py:101-117; the imitation-
         # learning presets also use 768 x 12, early_fusion_tsfm_models.py:275-294); llama's SwiGLU hidden size follows from it (llama_model.py:330-334)
-        if d_model % 64 or d_model // n_heads != 64 or d_model > 1024:
-            raise NotImplementedError(f"transformer width {d_model} with {n_heads} heads: the attention kernels are built for 64-wide heads")
+        n_heads_decoder = n_heads if n_heads_decoder is None else n_heads_decoder
+        if d_model % 64 or d_model > 1024 or d_model % n_heads or d_model % n_heads_decoder or max(d_model // n_heads, d_model // n_heads_decoder) > 128:
+            raise NotImplementedError(f"transformer width {d_model} with {n_heads} / {n_heads_decoder} heads")
         D = self.D = d_model
-        H = self.H = n_heads
+        H = self.H = n_heads                      # fusion transformer (nn.TransformerEncoderLayer nhead)
+        self.Hdec = n_heads_decoder               # llama decoder (ModelArgs.n_heads); TransformerConfig(3, 768, 8) + TransformerConfig(6, 768, 12) = siglip_base_3_6
+        # head widths: 64 everywhere on the MFMA attention kernels; any other width (96 = 768 / 8: base_6, siglip_base_3_6) takes the fp32 attention kernels
+        # through fp32 copies of the operands (ops.attn_fwd: a slow path)
+        self.hdim, self.hdim_dec = d_model // n_heads, d_model // n_heads_decoder
         HD = self.dec_hidden = 256 * ((int(2 * 4 * d_model / 3) + 255) // 256)
         self.dino_dim = dino_dim          # channel width of the frozen image features: 384 (ViT-S/14), 768 (ViT-B/14, SigLIP-B), 1024 (ViT-L), 2048 (CLIP RN50)
         # frozen text encoder and the width of its features (text_cond_visual_encoder.py:24-45 ``TEXT_ENCODER_DIMS`` / ``create_text_encoder``): the RL towers
@@ -332,6 +337,7 @@ class Tower(nn.Module):
 
     def run_forward(self, prep: "Prep", need_grad: bool):
         D, H, HD = self.D, self.H, self.dec_hidden
+        SCF, SCD = self.hdim ** -0.5, self.hdim_dec ** -0.5          # 0.125 for 64-wide heads
         T, B, R, S, L, U = prep.T, prep.B, prep.R, prep.S, prep.L, prep.U
         if T > 1 or self.time_step_counter >= self.max_steps:
             self.time_step_counter = 0
@@ -376,7 +382,7 @@ class Tower(nn.Module):
                 b_in = l.self_attn.in_proj_bias
                 kv = ops.gemm_nt(xf, w[f"f{i}.in"][D:], M, 2 * D, D, bias=b_in[D:])
                 q0 = ops.gemm_nt(xf, w[f"f{i}.in"][:D], R, D, D, bias=b_in[:D], lda=S * D)
-                ao, lse = ops.attn_fwd(q0, kv, kv[:, D:], 2 * D, R, S, H, 0.125, save_lse=need_grad, Sq=1, ldq=D, drop=site(i, 0))
+                ao, lse = ops.attn_fwd(q0, kv, kv[:, D:], 2 * D, R, S, H, SCF, save_lse=need_grad, Sq=1, ldq=D, drop=site(i, 0), head_dim=self.hdim)
                 h1 = ops.gemm_nt(ao, w[f"f{i}.out"], R, D, D, bias=l.self_attn.out_proj.bias, residual=xf, ldr=S * D, drop=site(i, 1, S))
                 x1, m1, r1 = ops.norm_fwd(h1, l.norm1.weight, l.norm1.bias, 1e-5, R, save_stats=need_grad, D=D)
                 f1 = ops.gemm_nt(x1, w[f"f{i}.l1"], R, 2048, D, bias=l.linear1.bias, act=ops.ACT_RELU, drop=site(i, 2, S))
@@ -388,12 +394,12 @@ class Tower(nn.Module):
                 continue
             qkv = ops.gemm_nt(xf, w[f"f{i}.in"], M, 3 * D, D, bias=l.self_attn.in_proj_bias)
             f8 = None
-            if self.fp8_attention and self.adt == BF16 and S <= 256:
+            if self.fp8_attention and self.adt == BF16 and S <= 256 and self.hdim == 64:
                 f8 = ops.attn_fp8_quant(qkv, 3 * D, R, S, H)
-                ao, lse = ops.attn_fp8_fwd(f8, 0.125, save_lse=need_grad, drop=site(i, 0))
+                ao, lse = ops.attn_fp8_fwd(f8, SCF, save_lse=need_grad, drop=site(i, 0))
                 qkv = None                       # the backward reads the e4m3 copies
             else:
-                ao, lse = ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, R, S, H, 0.125, save_lse=need_grad, drop=site(i, 0))
+                ao, lse = ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, R, S, H, SCF, save_lse=need_grad, drop=site(i, 0), head_dim=self.hdim)
             h1 = ops.gemm_nt(ao, w[f"f{i}.out"], M, D, D, bias=l.self_attn.out_proj.bias, residual=xf, drop=site(i, 1))
             x1, m1, r1 = ops.norm_fwd(h1, l.norm1.weight, l.norm1.bias, 1e-5, M, save_stats=need_grad, D=D)
             # the ReLU derivative is kept as 1 bit per element (M x 256 bytes): the input-gradient GEMM then reads 16x fewer mask bytes
@@ -414,6 +420,8 @@ class Tower(nn.Module):
         if T == 1:
             # acting: one new token per env against the KV cache; env b attends to cache slots >= max(counter - time_step_b, 0)
             # (its current episode), allenact_dino_transformer.py:388-397
+            if self.hdim_dec != 64:
+                raise NotImplementedError("KV-cached single steps need 64-wide decoder heads (MFMA / decode attention kernels)")
             t = self.time_step_counter
             self._ensure_caches(B)
             t_dev = getattr(self, "_t_dev", None)
@@ -446,7 +454,7 @@ class Tower(nn.Module):
                 else:
                     cache[:B].index_copy_(1, t_dev.view(1), qkv[:, D:].unsqueeze(1))
                 cv = cache.view(-1, 2 * D)
-                ao, _ = ops.attn_fwd(qkv, cv, cv[:, D:], 2 * D, B, S_att, H, 0.125, kvalid=kvalid, save_lse=False, Sq=1, ldq=3 * D,
+                ao, _ = ops.attn_fwd(qkv, cv, cv[:, D:], 2 * D, B, S_att, self.Hdec, SCD, kvalid=kvalid, save_lse=False, Sq=1, ldq=3 * D,
                                      kv_rows=self.max_steps)
                 h = ops.gemm_nt(ao, w[f"d{i}.wo"], B, D, D, residual=xd)
                 if fused:
@@ -461,7 +469,7 @@ class Tower(nn.Module):
           for i, l in enumerate(self.decoder.layers):
             n1, _, r1 = ops.norm_fwd(xd, l.attention_norm.weight, None, 1e-5, R, rms=True, save_stats=need_grad, D=D)
             qkv = ops.gemm_nt(n1, w[f"d{i}.qkv"], R, 3 * D, D)
-            ao, lse = ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B, T, H, 0.125, mask_mode=ops.MASK_BLOCK_CAUSAL,
+            ao, lse = ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B, T, self.Hdec, SCD, head_dim=self.hdim_dec, mask_mode=ops.MASK_BLOCK_CAUSAL,
                                    traj=prep.traj_bt, save_lse=need_grad)
             h = ops.gemm_nt(ao, w[f"d{i}.wo"], R, D, D, residual=xd)
             n2, _, r2 = ops.norm_fwd(h, l.ffn_norm.weight, None, 1e-5, R, rms=True, save_stats=need_grad, D=D)
@@ -527,6 +535,7 @@ class Tower(nn.Module):
         """Accumulates parameter gradients into the arena's flat grad buffer.  ``dfull_logits``: gradient of the discrete critic's
         bin logits (HL-Gauss loss), critic_type == "discrete" only."""
         D, H, HD = self.D, self.H, self.dec_hidden
+        SCF, SCD = self.hdim ** -0.5, self.hdim_dec ** -0.5          # 0.125 for 64-wide heads
         T, B, R, S, L, U = prep.T, prep.B, prep.R, prep.S, prep.L, prep.U
         ve, w, wt, dw, g = self.visual_encoder, self._w, self._wt, self._dw, self.g
         M2, M = R * 2 * NPATCH, R * S
@@ -565,7 +574,7 @@ class Tower(nn.Module):
             dqkv = torch.empty(R, 3 * D, device=dev, dtype=self.adt)
             q = a["qkv"]
             ops.attn_bwd(q, q[:, D:], q[:, 2 * D:], 3 * D, a["ao"], D, a["lse"], dao, D, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D,
-                         B, T, H, 0.125, mask_mode=ops.MASK_BLOCK_CAUSAL, traj=prep.traj_bt)
+                         B, T, self.Hdec, SCD, mask_mode=ops.MASK_BLOCK_CAUSAL, traj=prep.traj_bt, head_dim=self.hdim_dec)
             ops.gemm_tn_acc(dqkv, a["n1"], dw[f"d{i}.qkv"], R, 3 * D, D)
             dn1 = ops.gemm_nt(dqkv, wt[f"d{i}.qkv"], R, D, 3 * D)
             dx = ops.norm_bwd(dn1, a["x"], l.attention_norm.weight, None, None, a["r1"], R, g(l.attention_norm.weight), None, rms=True, dres=dh, D=D)
@@ -606,7 +615,7 @@ class Tower(nn.Module):
                 dq0 = torch.empty(R, D, device=dev, dtype=self.adt)
                 dkv = torch.empty(M, 2 * D, device=dev, dtype=self.adt)
                 kv = a["kv"]
-                ops.attn_bwd(a["q0"], kv, kv[:, D:], 2 * D, a["ao"], D, a["lse"], dao, D, dq0, dkv, dkv[:, D:], 2 * D, R, S, H, 0.125,
+                ops.attn_bwd(a["q0"], kv, kv[:, D:], 2 * D, a["ao"], D, a["lse"], dao, D, dq0, dkv, dkv[:, D:], 2 * D, R, S, H, SCF, head_dim=self.hdim,
                              Sq=1, ldq=D, lddq=D, drop=site(i, 0))
                 gb = g(l.self_attn.in_proj_bias)
                 ops.gemm_tn_acc(dkv, a["x"], dw[f"f{i}.in"][D:], M, 2 * D, D, db=gb[D:])
@@ -639,10 +648,10 @@ class Tower(nn.Module):
             dqkv = torch.empty(M, 3 * D, device=dev, dtype=self.adt)
             q = a["qkv"]
             if a.get("f8") is not None:
-                ops.attn_fp8_bwd(a["f8"], a["ao"], a["lse"], dao, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D, 0.125, drop=site(i, 0))
+                ops.attn_fp8_bwd(a["f8"], a["ao"], a["lse"], dao, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D, SCF, drop=site(i, 0))
             else:
                 ops.attn_bwd(q, q[:, D:], q[:, 2 * D:], 3 * D, a["ao"], D, a["lse"], dao, D, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D,
-                             R, S, H, 0.125, drop=site(i, 0))
+                             R, S, H, SCF, drop=site(i, 0), head_dim=self.hdim)
             ops.gemm_tn_acc(dqkv, a["x"], dw[f"f{i}.in"], M, 3 * D, D, db=g(l.self_attn.in_proj_bias))
             dyf = ops.gemm_nt(dqkv, wt[f"f{i}.in"], M, D, 3 * D, residual=dh1)
             c["fusion"][i] = None

@@ -358,24 +358,49 @@ def colsum_acc(dY, db, M, N, ldy=None, row_stride=1):
 
 
 # ------------------------------------------------------------------------------------------------ attention
+def _f32_cols(t, W):
+    """fp32 contiguous copy of the first W columns of a 2-D (possibly column-sliced) activation view"""
+    return t[:, :W].float().contiguous()
+
+
 def attn_fwd(q, k, v, ld, rows, S, H, scale, out=None, ldo=None, mask_mode=MASK_NONE, traj=None, bias=None, kvalid=None,
-             save_lse=True, Sq=0, ldq=0, kv_rows=0, drop=None):
+             save_lse=True, Sq=0, ldq=0, kv_rows=0, drop=None, head_dim=64):
     """q/k/v: bf16 views whose element (token, h*64+d) sits at token*ld + h*64 + d.  Sq > 0: only the first Sq queries of
-    every row (q then holds Sq rows per batch row with row stride ldq)."""
+    every row (q then holds Sq rows per batch row with row stride ldq).
+
+    ``head_dim`` != 64 (the two imitation-learning presets with TransformerConfig(n, 768, 8): heads of 96): the MFMA kernels are built for 64-wide heads;
+    those presets take the fp32 attention kernels (same masks, same dropout counters) through fp32 copies of the operands -- a slow path, not a tuned one."""
     nq = Sq if Sq > 0 else S
+    W = H * head_dim
+    if head_dim != 64 and q.dtype != F32:
+        q32, k32, v32 = _f32_cols(q, W), _f32_cols(k, W), _f32_cols(v, W)
+        o32, lse = attn_fwd(q32, k32, v32, W, rows, S, H, scale, mask_mode=mask_mode, traj=traj, bias=bias, kvalid=kvalid, save_lse=save_lse, Sq=Sq,
+                            ldq=W if Sq > 0 else 0, kv_rows=kv_rows, drop=drop, head_dim=head_dim)
+        if out is None:
+            return o32.to(q.dtype), lse
+        out[:, :W].copy_(o32)
+        return out, lse
     if out is None:
-        out = torch.empty(rows * nq, H * 64, device=q.device, dtype=q.dtype)
+        out = torch.empty(rows * nq, W, device=q.device, dtype=q.dtype)
     ldo = ldo if ldo is not None else out.stride(-2)
     lse = torch.empty(rows, H, nq, device=q.device, dtype=F32) if save_lse else None
-    lib().call("svla_attn_fwd_f32" if q.dtype == F32 else "svla_attn_fwd_bf16", _p(q), _p(k), _p(v), ld, _p(out), ldo, _p(lse), rows, S, H, 64, float(scale), mask_mode,
+    lib().call("svla_attn_fwd_f32" if q.dtype == F32 else "svla_attn_fwd_bf16", _p(q), _p(k), _p(v), ld, _p(out), ldo, _p(lse), rows, S, H, int(head_dim), float(scale), mask_mode,
                _p(traj), _p(bias), _p(kvalid), int(Sq), int(ldq), int(kv_rows), _d(drop), _stream())
     return out, lse
 
 
 def attn_bwd(q, k, v, ld, o, ldo, lse, do, lddo, dq, dk, dv, ldd, rows, S, H, scale, mask_mode=MASK_NONE, traj=None,
-             bias=None, kvalid=None, Sq=0, ldq=0, lddq=0, d_ws=None, drop=None):
+             bias=None, kvalid=None, Sq=0, ldq=0, lddq=0, d_ws=None, drop=None, head_dim=64):
+    if head_dim != 64 and q.dtype != F32:       # heads of 96: fp32 kernels through fp32 copies (see attn_fwd)
+        W = H * head_dim
+        q32, k32, v32, o32, do32 = (_f32_cols(t, W) for t in (q, k, v, o, do))
+        dq32, dk32, dv32 = torch.empty_like(q32), torch.empty_like(k32), torch.empty_like(v32)
+        attn_bwd(q32, k32, v32, W, o32, W, lse, do32, W, dq32, dk32, dv32, W, rows, S, H, scale, mask_mode=mask_mode, traj=traj, kvalid=kvalid, Sq=Sq,
+                 ldq=W if Sq > 0 else 0, lddq=W if Sq > 0 else 0, drop=drop, head_dim=head_dim)
+        dq[:, :W].copy_(dq32); dk[:, :W].copy_(dk32); dv[:, :W].copy_(dv32)
+        return
     if q.dtype == F32:
-        lib().call("svla_attn_bwd_f32", _p(q), _p(k), _p(v), ld, _p(o), ldo, _p(lse), _p(do), lddo, _p(dq), _p(dk), _p(dv), ldd, rows, S, H, 64,
+        lib().call("svla_attn_bwd_f32", _p(q), _p(k), _p(v), ld, _p(o), ldo, _p(lse), _p(do), lddo, _p(dq), _p(dk), _p(dv), ldd, rows, S, H, int(head_dim),
                    float(scale), mask_mode, _p(traj), _p(kvalid), int(Sq), int(ldq), int(lddq), _d(drop), _stream())
         return
     if d_ws is None:   # [rows, H, Sq] fp32 workspace: rowsum(dO * O), handed from the dQ kernel to the dK/dV kernel

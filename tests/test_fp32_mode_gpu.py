@@ -41,15 +41,20 @@ def rel(a, b):
 
 # ------------------------------------------------------------------------------------------------ kernels
 @pytest.mark.parametrize("S,Sq,mask_mode,p", [(37, 0, 0, 0.0), (181, 0, 0, 0.1), (64, 0, 1, 0.1), (181, 1, 0, 0.1), (50, 7, 0, 0.0)])
-def test_attn_f32_fwd_bwd(ops, S, Sq, mask_mode, p):
+@pytest.mark.parametrize("HD,via_bf16", [(64, False), (96, False), (96, True)])
+def test_attn_f32_fwd_bwd(ops, S, Sq, mask_mode, p, HD, via_bf16):
+    """HD = 96: the head width of TransformerConfig(n, 768, 8) (IL presets base_6 / siglip_base_3_6); ``via_bf16``: bf16 activations through the fp32 kernels
+    (ops.attn_fwd / attn_bwd with head_dim != 64), compared at bf16 tolerance."""
     from oracle.ref_model import hash_keep
 
-    rows, H, scale = 3, 8, 0.125
+    rows, H, scale = 3, 8, HD ** -0.5
+    cast = (lambda t: t.bfloat16()) if via_bf16 else (lambda t: t)
+    tol_f, tol_b = (2e-2, 3e-2) if via_bf16 else (2e-5, 5e-5)
     nq = Sq or S
-    kv = rnd(rows * S, 2 * H * 64, seed=1)
-    qs = rnd(rows * nq, H * 64, seed=2)
-    k, v = [kv[:, i * H * 64:(i + 1) * H * 64].view(rows, S, H, 64).transpose(1, 2).double().requires_grad_(True) for i in range(2)]
-    q = qs.view(rows, nq, H, 64).transpose(1, 2).double().requires_grad_(True)
+    kv = rnd(rows * S, 2 * H * HD, seed=1).bfloat16().float()
+    qs = rnd(rows * nq, H * HD, seed=2).bfloat16().float()
+    k, v = [kv[:, i * H * HD:(i + 1) * H * HD].view(rows, S, H, HD).transpose(1, 2).double().requires_grad_(True) for i in range(2)]
+    q = qs.view(rows, nq, H, HD).transpose(1, 2).double().requires_grad_(True)
     s = (q @ k.transpose(-1, -2)) * scale
     traj = None
     if mask_mode == 1:
@@ -66,29 +71,29 @@ def test_attn_f32_fwd_bwd(ops, S, Sq, mask_mode, p):
         keep = torch.from_numpy(hash_keep(0xBEEF, 4, p, idx))
         pr = pr * keep / (1.0 - float(np.float32(p)))
     want = pr @ v
-    d_kv, d_q = kv.to(DEV), qs.to(DEV)
-    kw = dict(mask_mode=mask_mode, traj=None if traj is None else traj.int().to(DEV), drop=drop)
+    d_kv, d_q = cast(kv.to(DEV)), cast(qs.to(DEV))
+    kw = dict(mask_mode=mask_mode, traj=None if traj is None else traj.int().to(DEV), drop=drop, head_dim=HD)
     if Sq:
-        out, lse = ops.attn_fwd(d_q, d_kv, d_kv[:, H * 64:], 2 * H * 64, rows, S, H, scale, Sq=Sq, ldq=H * 64, **kw)
+        out, lse = ops.attn_fwd(d_q, d_kv, d_kv[:, H * HD:], 2 * H * HD, rows, S, H, scale, Sq=Sq, ldq=H * HD, **kw)
     else:      # all queries: q laid out like k / v (one fused tensor)
-        qkv = torch.cat([qs, kv], 1).to(DEV)
-        out, lse = ops.attn_fwd(qkv, qkv[:, H * 64:], qkv[:, 2 * H * 64:], 3 * H * 64, rows, S, H, scale, **kw)
-    assert out.dtype == torch.float32
-    assert rel(out.view(rows, nq, H, 64).cpu(), want.transpose(1, 2).detach()) < 2e-5
-    do = rnd(rows * nq, H * 64, seed=5)
-    want.backward(do.view(rows, nq, H, 64).transpose(1, 2).double())
+        qkv = cast(torch.cat([qs, kv], 1).to(DEV))
+        out, lse = ops.attn_fwd(qkv, qkv[:, H * HD:], qkv[:, 2 * H * HD:], 3 * H * HD, rows, S, H, scale, **kw)
+    assert out.dtype == (torch.bfloat16 if via_bf16 else torch.float32)
+    assert rel(out.float().view(rows, nq, H, HD).cpu(), want.transpose(1, 2).detach()) < tol_f
+    do = rnd(rows * nq, H * HD, seed=5).bfloat16().float()
+    want.backward(do.view(rows, nq, H, HD).transpose(1, 2).double())
     if Sq:
         dq, dkv = torch.zeros_like(d_q), torch.zeros_like(d_kv)
-        ops.attn_bwd(d_q, d_kv, d_kv[:, H * 64:], 2 * H * 64, out, H * 64, lse, do.to(DEV), H * 64, dq, dkv, dkv[:, H * 64:], 2 * H * 64,
-                     rows, S, H, scale, Sq=Sq, ldq=H * 64, lddq=H * 64, **kw)
-        got = [dq.view(rows, nq, H, 64), dkv[:, :H * 64].view(rows, S, H, 64), dkv[:, H * 64:].view(rows, S, H, 64)]
+        ops.attn_bwd(d_q, d_kv, d_kv[:, H * HD:], 2 * H * HD, out, H * HD, lse, cast(do.to(DEV)), H * HD, dq, dkv, dkv[:, H * HD:], 2 * H * HD,
+                     rows, S, H, scale, Sq=Sq, ldq=H * HD, lddq=H * HD, **kw)
+        got = [dq.view(rows, nq, H, HD), dkv[:, :H * HD].view(rows, S, H, HD), dkv[:, H * HD:].view(rows, S, H, HD)]
     else:
         dqkv = torch.zeros_like(qkv)
-        ops.attn_bwd(qkv, qkv[:, H * 64:], qkv[:, 2 * H * 64:], 3 * H * 64, out, H * 64, lse, do.to(DEV), H * 64, dqkv, dqkv[:, H * 64:],
-                     dqkv[:, 2 * H * 64:], 3 * H * 64, rows, S, H, scale, **kw)
-        got = [dqkv[:, i * H * 64:(i + 1) * H * 64].view(rows, S, H, 64) for i in range(3)]
+        ops.attn_bwd(qkv, qkv[:, H * HD:], qkv[:, 2 * H * HD:], 3 * H * HD, out, H * HD, lse, cast(do.to(DEV)), H * HD, dqkv, dqkv[:, H * HD:],
+                     dqkv[:, 2 * H * HD:], 3 * H * HD, rows, S, H, scale, **kw)
+        got = [dqkv[:, i * H * HD:(i + 1) * H * HD].view(rows, S, H, HD) for i in range(3)]
     for g_, t, n in zip(got, (q, k, v), "QKV"):
-        assert rel(g_.cpu(), t.grad.transpose(1, 2)) < 5e-5, n
+        assert rel(g_.float().cpu(), t.grad.transpose(1, 2)) < tol_b, n
 
 
 def test_attn_f32_t5_bias_padding_and_kv_cache(ops):
