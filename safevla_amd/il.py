@@ -16,6 +16,7 @@ The frozen image encoder stays outside, as on the RL path: visual sensors are ei
 """
 from typing import Dict, Optional
 
+import numpy as np
 import torch
 
 from . import ops
@@ -177,6 +178,12 @@ class EarlyFusionCnnTransformer(Tower):
         return out
 
     @classmethod
+    def build_agent(cls, model_version="small_3", input_sensors=(NAV, MANIP, "last_actions", "an_object_is_in_hand"), loss="action", device="cuda",
+                    sampling="greedy", ckpt_pth: Optional[str] = None, **kw):
+        """``build_agent`` of early_fusion_tsfm_models.py:352-363: the model of ``build_model`` wrapped in its online agent."""
+        return EarlyFusionCnnTransformerAgent(cls.build_model(model_version, input_sensors, loss, device=device, ckpt_pth=ckpt_pth), device, sampling, **kw)
+
+    @classmethod
     def version_config(cls, model_version):
         """(fusion layers, decoder layers, image-feature width, text encoder, transformer width, fusion heads, decoder heads) of a preset"""
         v = cls.VERSIONS[model_version]
@@ -220,3 +227,82 @@ class ILTrainer:
     def state_dict(self):
         ar = self.model.arena
         return dict(step=self.step_count, exp_avg=ar.flat_m.clone(), exp_avg_sq=ar.flat_v.clone())
+
+
+class EarlyFusionCnnTransformerAgent:
+    """Online agent of the imitation-learning model: ``EarlyFusionCnnTransformerAgent`` of early_fusion_tsfm_models.py:366-520 behind ``AbstractAgent``
+    (architecture/agent.py:5-51) -- ``reset()``, ``get_action_list()``, ``get_action(observations, goal_spec) -> (action_str, action_probs)``.
+
+    One call = the step's sensors (uint8 frames -> the preset's frozen image trunk, or pre-encoded features) + the cached goal -> a single-step forward of the tower
+    against the llama KV caches (the acting path of ``model.Tower``: the reference re-embeds the step, appends it to ``cache["embedded_features"]`` and calls the
+    decoder with ``start_pos = curr_t``, :476-499 -- the same per-step arithmetic) -> greedy or sampled action; the previous action fed to the next step is the
+    chosen action index (:512-513), the first step's is the start token (:416-420).
+
+    ``goal_spec``: a string (tokenised by ``tokenizer``: for the t5 presets ``text.GoalTokenizer`` -- the real ``t5-small`` vocabulary through its ``spiece_model`` --,
+    for the SigLIP presets any callable ``tokenizer([text], context_length=64) -> ids [1, 64]`` like open_clip's; neither vocabulary ships offline) or already
+    tokenised ids (``{"input_ids", "attention_mask"}`` / an id tensor).  ``max_seq_len`` = the KV-cache window: 512 here (the single-query attention kernel's
+    limit; the reference's tasks end at 500 steps, training/online/base.py:129) against the reference's 1000; an episode that outlives it restarts the window (the
+    reference slides it)."""
+
+    def __init__(self, model: EarlyFusionCnnTransformer, device="cuda", sampling: str = "greedy", max_seq_len: int = 512, tokenizer=None,
+                 generator: Optional[torch.Generator] = None):
+        from .agent import ALL_STRETCH_ACTIONS
+        if sampling not in ("greedy", "sample"):
+            raise NotImplementedError(f"sampling {sampling!r}: 'greedy' (argmax) or 'sample' (categorical), utils/nn_utils.py sample_action_index_from_logits")
+        self.model, self.device, self.sampling, self.max_seq_len = model, torch.device(device), sampling, min(max_seq_len, 512, model.max_steps)
+        self.action_list = list(ALL_STRETCH_ACTIONS)
+        self.generator = generator
+        if tokenizer is None and model.text_encoder_name == "t5-small":
+            from .text import GoalTokenizer
+            tokenizer = GoalTokenizer()
+        self.tokenizer = tokenizer
+        self.model.eval()
+        self.reset()
+
+    def reset(self):
+        self.curr_t = 0
+        self.cache = dict()
+        self.model.time_step_counter = 0          # KV-cache slot of the next step; the caches themselves are overwritten slot by slot
+
+    def get_action_list(self):
+        return self.action_list
+
+    def _goal(self, goal_spec):
+        if isinstance(goal_spec, str):
+            if self.tokenizer is None:
+                raise ValueError("a string goal needs a tokenizer (SigLIP presets: open_clip's tokenizer is not available offline; pass ids or tokenizer=)")
+            if self.model.text_encoder_name == "t5-small":
+                enc = self.tokenizer([goal_spec], return_tensors="pt")
+                return {k: v.to(self.device) for k, v in enc.items()}
+            return torch.as_tensor(self.tokenizer([goal_spec], context_length=64)).to(self.device)
+        if isinstance(goal_spec, dict):
+            return {k: torch.as_tensor(v).to(self.device).reshape(1, -1) for k, v in goal_spec.items()}
+        return torch.as_tensor(goal_spec).to(self.device).reshape(1, -1)
+
+    @torch.no_grad()
+    def get_action(self, observations: Dict, goal_spec):
+        m, dev = self.model, self.device
+        if self.curr_t == 0:
+            self.cache["goal"] = self._goal(goal_spec)
+            g = self.cache["goal"]
+            ids = g["input_ids"] if isinstance(g, dict) else g
+            self.cache["goal_key"] = tuple(int(v) for v in ids.reshape(-1).tolist())
+        slot = self.curr_t % self.max_seq_len
+        if slot == 0:
+            m.time_step_counter = 0
+        one = lambda v, dt: torch.as_tensor(np.asarray(v)).to(dev).to(dt).reshape(1, 1)
+        batch = {"goals": self.cache["goal"], "time_ids": one(slot, torch.int64),
+                 "last_actions": one(START_TOKEN if self.curr_t == 0 else self.cache["last_actions"], torch.int64),
+                 "an_object_is_in_hand": one(np.asarray(observations.get("an_object_is_in_hand", 0)).reshape(-1)[0], torch.int64)}
+        for key in (NAV, MANIP):
+            x = torch.as_tensor(np.ascontiguousarray(observations[key])).to(dev)
+            batch[key] = x.reshape((1, 1) + tuple(x.shape))
+        prep = m.prepare(batch)
+        prep.ids_key = self.cache["goal_key"]          # eval mode: the frozen text encoder runs once per episode (the reference caches text_feats at t = 0, :459-465)
+        logits, _, _ = m.run_forward(prep, need_grad=False)
+        curr = logits.reshape(-1).float()
+        probs = torch.softmax(curr, -1)
+        idx = int(torch.argmax(curr)) if self.sampling == "greedy" else int(torch.multinomial(probs, 1, generator=self.generator))
+        self.cache["last_actions"] = idx
+        self.curr_t += 1
+        return self.action_list[idx], probs

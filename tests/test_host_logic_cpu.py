@@ -201,3 +201,34 @@ def test_polynomial_erf_gelu_of_the_kernels_against_scipy():
     hdr = G.c_header()
     cs = [float(v) for v in re.search(r"SVLA_GELU_COEFS \{(.*)\}", hdr).group(1).replace("f", "").split(",")]
     assert [struct.unpack("<I", struct.pack("<f", v))[0] for v in cs] == G.COEF_BITS
+
+
+def test_il_preset_table_matches_the_reference_source():
+    """il.EarlyFusionCnnTransformer.VERSIONS against the reference's own preset table, read from its source where the build container has it
+    (early_fusion_tsfm_models.py:221-312): layers / width / heads of the fusion transformer and of the decoder, image and text encoder of every
+    preset that the reference can construct."""
+    import os
+    import re
+    path = "/root/reference/architecture/models/transformer_models/early_fusion_tsfm_models.py"
+    if not os.path.exists(path):
+        pytest.skip("the reference tree is only present in the build container")
+    from safevla_amd.il import EarlyFusionCnnTransformer as M
+    src = open(path).read()
+    src = src[src.index("def build_model"):src.index("model = EarlyFusionCnnTransformer(model_cfg)")]
+    feat = {"Dinov2Small": 384, "Dinov2Base": 768, "SigLIPBase": 768, "SigLIPLarge": 1024, "ClipResNet50": 2048}
+    seen = {}
+    for blk in re.split(r"\n\s+(?:if|elif) model_version == ", src)[1:]:
+        names = re.findall(r'"([a-zA-Z0-9_]+)"', blk.split(":")[0])
+        img = re.search(r'image_encoder = "(\w+)"', blk).group(1)
+        txt = re.search(r'text_encoder = "([\w-]+)"', blk).group(1)
+        fus = re.search(r"fusion_xformer = TransformerConfig\((\d+), (\d+), (\d+)\)", blk)
+        dec = re.search(r"model_cfg.decoder = TransformerConfig\((\d+), (\d+), (\d+)\)", blk)
+        for n in names:
+            seen[n] = (img, txt, tuple(map(int, fus.groups())) if fus else None, tuple(map(int, dec.groups())))
+    assert len(seen) == 19
+    dead = {"small_3_nonTxEnc", "siglip_base_3_nonTxEnc", "siglip_base_384_3", "siglip_base_384_resize_3"}     # cannot be constructed in the reference (il.VERSIONS)
+    assert set(seen) - dead == set(M.VERSIONS)
+    for n in M.VERSIONS:
+        img, txt, fus, dec = seen[n]
+        nf, nd, dd, te, dm, nh, nhd = M.version_config(n)
+        assert (nf, dm, nh) == fus and (nd, dm, nhd) == dec and dd == feat[img] and te == txt, n
