@@ -785,7 +785,7 @@ def main():
             cpu["parity_gate"] = {"error": repr(e)[:200]}
     if rank == 0:
         out = {"metric": "env-steps/sec through PPO-Lagrangian update", "value": round(env_steps / (ms * 1e-3), 1), "unit": "env-steps/s",
-               "n_gpus": world, "rccl_ranks": (torch.distributed.get_world_size() if world > 1 else 1),
+               "n_gpus": world, "rccl_ranks": (torch.distributed.get_world_size() if parallel.is_dist() else 1),
                "collective_preflight": pre, "ms_per_step_per_rank": {"min": round(min(per_rank_ms), 2), "max": round(max(per_rank_ms), 2)},
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
                "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -812,7 +812,7 @@ def main():
             out["parity_ok"] = bool("error" not in pg and pg.get("fp32", {}).get("passed") and pg.get("bf16", {}).get("passed"))
             parity_failed = not out["parity_ok"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if parallel.is_dist():
         parallel.barrier()
         torch.distributed.destroy_process_group()
     if parity_failed:

@@ -30,8 +30,15 @@ def shard_envs(num_envs: int, world: int, rank: int) -> Tuple[int, int]:
     return sum(bins[:rank]), bins[rank]
 
 
+def force_dist() -> bool:
+    """SVLA_FORCE_DIST=1: a SINGLE rank still initialises the backend and sends every exchange step through its collectives (RCCL
+    communicator, asynchronous handles on the tower streams, fp64 reductions) -- the 1-GPU test boxes' way to execute the RCCL code path
+    (tests/test_dp_gpu.py::test_single_rank_through_rccl); results must equal the non-distributed run bit for bit."""
+    return os.environ.get("SVLA_FORCE_DIST") == "1"
+
+
 def is_dist() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_dist())
 
 
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
@@ -39,7 +46,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_dist()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

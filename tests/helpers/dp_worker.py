@@ -55,8 +55,10 @@ def main():
         w.wait()
     eng._pending = []
     parallel.allreduce_sum_(eng._sums)
+    if "--expect-backend" in sys.argv:
+        assert torch.distributed.get_backend() == sys.argv[sys.argv.index("--expect-backend") + 1], torch.distributed.get_backend()
     if rank == 0:
-        torch.save({"flat_g": m.arena.flat_g.cpu(), "sums": eng._sums.cpu()}, out)
+        torch.save({"flat_g": m.arena.flat_g.cpu(), "sums": eng._sums.cpu(), "backend": torch.distributed.get_backend(), "world": world, "pending": 3}, out)
     parallel.barrier()
 
 

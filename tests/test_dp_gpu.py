@@ -102,3 +102,54 @@ def test_bench_eight_ranks_strong_scaling_fetch_plumbing():
     assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["scaling"] == "strong"
     assert out["config"]["global_envs"] == 250 and out["loss"]["env_steps"] == 4 * 250
     assert out["value"] > 0 and all(v == v for v in out["loss"].values() if isinstance(v, float))
+
+
+def test_single_rank_through_rccl(tmp_path):
+    """The RCCL code path EXECUTED on a 1-GPU box: ``SVLA_FORCE_DIST=1`` makes a single rank initialise the "nccl" (= RCCL) backend and send every
+    exchange step of the engine through it -- communicator creation, the three asynchronous per-tower all-reduces of the fp32 gradient arena issued
+    behind each tower's backward, the fp64 count / cost reductions, the broadcast of every parameter and buffer, the barrier.  With one rank every
+    SUM is the identity, so the result must equal the non-distributed gradient of the same rows BIT FOR BIT (eval mode, same kernels, same order).
+    What this cannot show is the xGMI exchange itself (that needs one GPU per rank: the "rccl" variant above)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    T, B = 5, 4
+    out = str(tmp_path / "dp1.pt")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SVLA_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.pop("SVLA_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "dp_worker.py"), out, str(T), str(B), "--expect-backend", "nccl"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = torch.load(out)
+    assert got["backend"] == "nccl" and got["world"] == 1 and got["pending"] == 3
+    sys.path.insert(0, os.path.join(ROOT, "tests", "helpers"))
+    import dp_worker
+
+    m, eng, st = dp_worker.build(torch.device("cuda"), T, B)
+    m.zero_grad()
+    eng._sums.zero_()
+    eng._accumulate(st.batch_slice(0, B), T * B, 0.25)
+    assert torch.allclose(got["sums"], eng._sums.cpu(), rtol=1e-6, atol=1e-9)
+    # same rows, same kernels; only the arrival order of the fp32 weight-gradient atomics differs between two runs
+    want_g = m.arena.flat_g.cpu()
+    err = (got["flat_g"] - want_g).abs().max().item() / want_g.abs().max().item()
+    assert err < 1e-4, err
+
+
+def test_bench_single_rank_through_rccl():
+    """bench.py with its one rank forced through RCCL (SVLA_FORCE_DIST=1): the collective pre-flight, the per-tower asynchronous all-reduces inside the
+    timed update and the MAX-over-ranks clock all run on the "nccl" backend; the line says so (``collective_preflight.backend``)."""
+    import json
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SVLA_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.pop("SVLA_DIST_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--T", "8", "--envs-per-gpu", "4",
+           "--no-cpu-baseline", "--no-secondary", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["collective_preflight"]["backend"] == "nccl"
+    assert out["collective_preflight"]["tower_ranges_checked"] == 3 and out["loss"]["env_steps"] == 32 and out["value"] > 0

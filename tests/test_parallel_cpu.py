@@ -91,3 +91,30 @@ def test_two_rank_gloo_equals_single_process():
     want = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy()
     np.testing.assert_allclose(flat, want, rtol=1e-5, atol=1e-7)
     assert n_ep == 4.0 and abs(jc - (3.0 + 6.0) / 4.0) < 1e-12
+
+
+def test_forced_single_rank_goes_through_the_backend():
+    """SVLA_FORCE_DIST=1 (the 1-GPU boxes' way to execute the RCCL path, tests/test_dp_gpu.py): a single rank still initialises a process group and
+    every helper of safevla_amd.parallel calls the backend's collectives; here on gloo."""
+    import subprocess
+
+    code = ("import torch\nfrom safevla_amd import parallel\n"
+            "r, l, w = parallel.init_from_env(backend='gloo')\n"
+            "assert (r, w) == (0, 1) and parallel.is_dist() and torch.distributed.get_backend() == 'gloo'\n"
+            "t = torch.arange(6.0)\nh = parallel.allreduce_sum_async(t)\nassert h.wait() and t.tolist() == [0, 1, 2, 3, 4, 5]\n"
+            "assert parallel.global_counts([3, 9], 'cpu') == [3, 9] and parallel.mean_episode_cost(4.0, 2.0, 'cpu') == (2.0, 2.0)\n"
+            "class A:\n    flat_g = torch.zeros(30)\n    tower_ranges = [(0, 10), (10, 30)]\n"
+            "class M:\n    arena = A()\n"
+            "pre = parallel.preflight(M(), 'cpu')\nassert pre['ranks'] == 1 and pre['backend'] == 'gloo' and pre['tower_ranges_checked'] == 2\n"
+            "parallel.barrier()\nprint('ok')\n")
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, SVLA_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    env.pop("SVLA_FORCE_DIST")
+    r = subprocess.run([sys.executable, "-c", "from safevla_amd import parallel\nprint(parallel.init_from_env(), parallel.is_dist())"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "(0, 0, 1) False" in r.stdout, r.stdout + r.stderr[-2000:]
