@@ -23,3 +23,13 @@ def test_fuzz_kernels_fixed_seed(seed):
     # the campaign reached the assembly kernels, both tile kernels and every mask kind
     for key in ("svla_nt_as_", "svla_nt_os_", "gemm_nt8p_bf16_kernel", "gemm_nt_bf16_kernel", "svla_tn_os", "causal", "t5"):
         assert key in r.stdout, (key, r.stdout[-3000:])
+
+
+def test_fuzz_engine_fixed_seed():
+    """tools/fuzz_engine.py: random (T, B, L, task, env-chunk, minibatch count) rollouts through the engine on the bf16 product path vs the fp32 verification mode, then a full
+    update each; the first two configurations are ONE-step rollouts (round 5: a T = 1 update batch used to take the decoder's KV-cached acting branch and die in the backward)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_engine.py"), "--seed", "3", "--cases", "12"], cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert "0 failing configuration(s) of 12" in r.stdout and r.stdout.count("ok   T=1 ") >= 2, r.stdout[-3000:]
