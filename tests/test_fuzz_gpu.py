@@ -33,3 +33,13 @@ def test_fuzz_engine_fixed_seed():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_engine.py"), "--seed", "3", "--cases", "12"], cwd=ROOT, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     assert "0 failing configuration(s) of 12" in r.stdout and r.stdout.count("ok   T=1 ") >= 2, r.stdout[-3000:]
+
+
+def test_fuzz_acting_across_the_cache_window():
+    """tools/fuzz_acting.py: models with a 5 / 8 / 17-slot KV window stepped through up to three windows of single-step forwards (episodes shorter than the window and outliving
+    it): recorded launch plans == eager issue step for step, bf16 path vs fp32 mode on the ladder -- the counter wrap, which a dozen steps inside the 500-slot window never reach."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_acting.py"), "--seed", "2", "--cases", "6"], cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert "0 failing rollout(s) of 6" in r.stdout, r.stdout[-3000:]
