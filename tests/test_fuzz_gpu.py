@@ -43,3 +43,12 @@ def test_fuzz_acting_across_the_cache_window():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_acting.py"), "--seed", "2", "--cases", "6"], cwd=ROOT, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     assert "0 failing rollout(s) of 6" in r.stdout, r.stdout[-3000:]
+
+
+def test_fuzz_vit_batch_invariance():
+    """tools/fuzz_vit.py: a frame's features do not depend on its batch -- 1 ... 130 frames through the frozen DINOv2 ViT-S/14 (two frame geometries) and the SigLIP ViT-B/16 trunk
+    (padded token rows, tile / panel / mid-M kernels by row count) against the same frames alone."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vit.py"), "--seed", "1"], cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "0 failing batch size(s)" in r.stdout, r.stdout[-4000:] + r.stderr[-2000:]
