@@ -46,8 +46,9 @@ def main():
                 for i, ref in single.items():
                     if i < B:
                         worst = max(worst, float((tok[i:i + 1] - ref).abs().max()) / max(1e-6, float(ref.abs().max())))
-                ok = worst < 4e-2 and      # the tolerance of the oracle comparison (tests/test_preproc_gpu.py): from ~31 frames up the K = 384 GEMMs run on the assembly kernels, one bf16 rounding per layer apart (measured 1.6-2.0e-2 after 12 layers)
-                 bool(torch.isfinite(tok).all()) and tok.shape[0] == B
+                # tolerance of the oracle comparison (tests/test_preproc_gpu.py): from ~31 frames up the K = 384 GEMMs run on the assembly kernels, one bf16 rounding per
+                # layer apart (measured 1.6-2.0e-2 after 12 layers)
+                ok = worst < 4e-2 and bool(torch.isfinite(tok).all()) and tok.shape[0] == B
                 bad += 0 if ok else 1
                 print(f"{'ok  ' if ok else 'FAIL'} {name} B={B} ({tok.shape[1]} tokens x {tok.shape[2]}): worst per-frame deviation from the single-frame features {worst:.2e} (relative to max)", flush=True)
         del pre
