@@ -126,6 +126,7 @@ class EarlyFusionCnnTransformer(Tower):
         R = T * B
         p = Prep()
         p.T, p.B, p.R = T, B, R
+        p.acting = False                                         # forward(batch): whole windows, also when T = 1 (the agent's single steps set it)
         p.tokens = torch.empty(R, 2, NPATCH, self.dino_dim, device=dev, dtype=BF16)
         for cam, key in enumerate((NAV, MANIP)):
             x = batch[key].to(dev)
@@ -298,6 +299,7 @@ class EarlyFusionCnnTransformerAgent:
             x = torch.as_tensor(np.ascontiguousarray(observations[key])).to(dev)
             batch[key] = x.reshape((1, 1) + tuple(x.shape))
         prep = m.prepare(batch)
+        prep.acting = True                             # a single step against the llama KV caches
         prep.ids_key = self.cache["goal_key"]          # eval mode: the frozen text encoder runs once per episode (the reference caches text_feats at t = 0, :459-465)
         logits, _, _ = m.run_forward(prep, need_grad=False)
         curr = logits.reshape(-1).float()

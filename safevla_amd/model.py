@@ -339,7 +339,7 @@ class Tower(nn.Module):
         D, H, HD = self.D, self.H, self.dec_hidden
         SCF, SCD = self.hdim ** -0.5, self.hdim_dec ** -0.5          # 0.125 for 64-wide heads
         T, B, R, S, L, U = prep.T, prep.B, prep.R, prep.S, prep.L, prep.U
-        if T > 1 or need_grad or self.time_step_counter >= self.max_steps:
+        if T > 1 or need_grad or not getattr(prep, "acting", True) or self.time_step_counter >= self.max_steps:
             self.time_step_counter = 0
         ve, w = self.visual_encoder, self._w
         M2, M = R * 2 * NPATCH, R * S
@@ -417,10 +417,12 @@ class Tower(nn.Module):
                               self.time_encoder.div_term, prep.prev_actions, prep.masks, prep.hand, prep.time_step, T, B, j)
         xd = j
         dl = []
-        if T == 1 and not need_grad:
+        if T == 1 and not need_grad and getattr(prep, "acting", True):
             # acting: one new token per env against the KV cache; env b attends to cache slots >= max(counter - time_step_b, 0)
             # (its current episode), allenact_dino_transformer.py:388-397.  A one-step UPDATE batch (need_grad: engine / fused-loss path on a T = 1 rollout)
-            # takes the sequence branch below instead -- a sequence of length one has no history to attend to, and the backward needs the saved activations
+            # takes the sequence branch below instead -- a sequence of length one has no history to attend to, and the backward needs the saved activations --
+            # and so does a batch whose Prep says ``acting = False`` (the imitation-learning model's ``forward(batch)`` on one-step windows: independent
+            # sequences, never the cache of an earlier call; its online agent sets ``acting = True``)
             if self.hdim_dec != 64:
                 raise NotImplementedError("KV-cached single steps need 64-wide decoder heads (MFMA / decode attention kernels)")
             t = self.time_step_counter
