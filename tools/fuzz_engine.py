@@ -77,9 +77,18 @@ def main():
             ok = (cos > 0.999 and rel < 5e-2 if T * B >= 64 else cos > 0.99) and bool((ds <= tol).all()) and bool(torch.isfinite(g16).all())
             # one complete update on the product path: train mode (dropout), random minibatch count (recorded / replayed small minibatches)
             m16.train()
-            eng = PPOLagEngine(m16, PPOLagConfig(env_chunk=chunk, num_mini_batch=min(nmb, B)))
-            info = eng.update(st, nxt["next_value"], nxt["next_c_value"], ep["episode_cost_sum"], ep["n_episodes"])
-            m16.eval()
+            # ... with the switches a deployment can flip, at random: fp8 MFMA attention (BASELINE configs[4]), the reference-faithful per-row T5 dropout, bitwise-repeatable accumulation
+            fp8, per_row, det = rng.random() < 0.25, rng.random() < 0.3, rng.random() < 0.25
+            m16.set_fp8_attention(fp8)
+            m16.t5_dropout_per_row = per_row
+            try:
+                eng = PPOLagEngine(m16, PPOLagConfig(env_chunk=chunk, num_mini_batch=min(nmb, B), deterministic=det))
+                info = eng.update(st, nxt["next_value"], nxt["next_c_value"], ep["episode_cost_sum"], ep["n_episodes"])
+            finally:
+                m16.set_fp8_attention(False)
+                m16.t5_dropout_per_row = False
+                m16.eval()
+            tag += f" | update: fp8={int(fp8)} t5_per_row={int(per_row)} deterministic={int(det)}"
             fin = bool(torch.isfinite(m16.arena.flat_p).all()) and all(np.isfinite(v) for v in info.values() if isinstance(v, float))
             ok = ok and fin and info["env_steps"] == T * B
             print(f"{'ok  ' if ok else 'FAIL'} {tag}: gradient cosine {cos:.6f}, rel L2 {rel:.2e}, loss-sum diffs {np.array2string(ds, precision=2)}; update finite={fin}, ppo_total {info['ppo_total']:.4f}", flush=True)
