@@ -223,7 +223,7 @@ class ILTrainer:
         ops.adam_step(ar.flat_p, ar.flat_g, ar.flat_m, ar.flat_v, ar.flat_bf16, self.lr, self.step_count, self.betas[0], self.betas[1],
                       self.eps, weight_decay=self.wd)
         m.refresh_transposes()
-        return {"loss": float(out["loss"])}
+        return {"loss": float(out["loss"].detach())}
 
     def state_dict(self):
         ar = self.model.arena
