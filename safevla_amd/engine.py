@@ -257,6 +257,8 @@ class PPOLagEngine:
                episode_cost_sum: float, n_episodes: float, generator: Optional[torch.Generator] = None) -> Dict[str, float]:
         cfg, m = self.cfg, self.model
         dev = m.device_
+        if not parallel.is_dist() and cfg.num_mini_batch > storage.B:       # refused before anything (returns, multiplier) is touched; the data-parallel form of the check follows the count all-reduce
+            raise ValueError(f"num_mini_batch = {cfg.num_mini_batch} leaves a minibatch without environments ({storage.B} env(s))")
         self._chunk_cache.clear()             # a new rollout: recorded sequences of the previous update refer to other inputs
         storage.compute_returns(next_value, next_c_value, True, cfg.gamma, cfg.gae_lambda)
         Jc, n_ep = parallel.mean_episode_cost(episode_cost_sum, n_episodes, dev)
@@ -266,6 +268,10 @@ class PPOLagEngine:
         n_mb = 0
         bounds = [round(i * B / cfg.num_mini_batch) for i in range(cfg.num_mini_batch + 1)]
         counts = self._global_rows([T * (bounds[i + 1] - bounds[i]) for i in range(cfg.num_mini_batch)] + [T * B], dev)
+        if min(counts[:-1]) <= 0:
+            # more minibatches than environments on EVERY rank together: a minibatch without a row has no gradient and no loss (AllenAct refuses the same
+            # configuration when it builds its samplers); a rank-local empty minibatch under data parallelism is legal and handled below
+            raise ValueError(f"num_mini_batch = {cfg.num_mini_batch} leaves a minibatch without environments ({B} local env(s); global rows per minibatch {counts[:-1]})")
         if parallel.is_dist() and cfg.num_mini_batch > 1:
             # the i-th minibatch of every rank forms ONE global minibatch: all ranks must walk them in the same order
             generator = torch.Generator().manual_seed(0x5AFE + self.opt_step)

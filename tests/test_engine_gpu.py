@@ -136,6 +136,14 @@ def test_full_update_lambda_adam_clip(setup):
     # second update keeps lambda state moving in the same direction (Jc > limit)
     info2 = eng.update(st, torch.zeros(B, 1, device=DEV), torch.zeros(B, 1, device=DEV), episode_cost_sum=30.0, n_episodes=6.0)
     assert info2["lagrangian_multiplier"] > info["lagrangian_multiplier"]
+    # more minibatches than environments: refused with a message before anything is touched, not a 0 / 0 in the loss bookkeeping
+    with pytest.raises(ValueError, match="without environments"):
+        e2 = PPOLagEngine(model, PPOLagConfig(update_repeats=1, num_mini_batch=B + 1))
+        lam0 = e2.lagrange.lagrangian_multiplier
+        try:
+            e2.update(st, torch.zeros(B, 1, device=DEV), torch.zeros(B, 1, device=DEV), 30.0, 6.0)
+        finally:
+            assert e2.lagrange.lagrangian_multiplier == lam0 and e2.opt_step == 0
     # restore weights for other tests
     model.arena.flat_p.copy_(p0)
     model.sync_weights(frozen=False)
