@@ -6,7 +6,7 @@ small minibatches are recorded in the first epoch and replayed in the others) wh
 for the (T, B, L, chunk) combination nobody listed: T = 1, B = 1, one goal token, 64 goal tokens (S = 233: other attention tiles), ragged last env-chunk, more minibatches
 than chunks.  One line per configuration, exit code 1 on any violation.
 
-    python tools/fuzz_engine.py [--seed 0] [--cases 24]
+    python tools/fuzz_engine.py [--seed 0] [--cases 24] [--critic-type linear|discrete|mlp]
 """
 import argparse
 import os
@@ -40,11 +40,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cases", type=int, default=24)
+    ap.add_argument("--critic-type", default="linear", choices=["linear", "discrete", "mlp"], help="critic heads of both value towers (allenact_dino_transformer.py:147-162,720-766)")
     args = ap.parse_args()
     rng = random.Random(args.seed)
     torch.manual_seed(args.seed)
-    m16 = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV).eval()
-    m32 = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV, precision="fp32").eval()
+    m16 = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV, critic_type=args.critic_type).eval()
+    m32 = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV, precision="fp32", critic_type=args.critic_type).eval()
     sd0 = {k: v.detach().clone() for k, v in m16.state_dict().items()}
     m32.load_state_dict(sd0)
     bad = 0
@@ -73,8 +74,11 @@ def main():
             ds = np.abs(s16.cpu().numpy()[[0, 1, 2, 4]] - s32.cpu().numpy()[[0, 1, 2, 4]])
             tol = 1e-2 * np.abs(s32.cpu().numpy()[[0, 1, 2, 4]]) + 2e-3 * T * B + 2e-2 * np.sqrt(T * B)      # per-row bf16 error of v enters (v - R)^2 linearly: ~1e-2 per row, averaging as sqrt(rows)
             # a handful of rows: the value towers' gradient is a sum of few (v - R) terms, each carrying the bf16 forward's ~1e-2 relative error of v undamped by
-            # averaging (per-tower relative error 0.1-0.25 at 2-25 rows, 5e-3 from ~100 rows up): direction only below 64 rows
-            ok = (cos > 0.999 and rel < 5e-2 if T * B >= 64 else cos > 0.99) and bool((ds <= tol).all()) and bool(torch.isfinite(g16).all())
+            # averaging (per-tower relative error 0.1-0.25 at 2-25 rows -- more with the MLP critic head --, 5e-3 from ~100 rows up).  The actor tower has no such
+            # cancellation (its gradient is advantage x d log pi): it is held to the tight bound at every size, the whole gradient from 64 rows up
+            lo, hi = m16.arena.tower_ranges[0]
+            cos_actor = torch.nn.functional.cosine_similarity(g16[lo:hi], g32[lo:hi], dim=0).item()
+            ok = (cos_actor > 0.999 and (cos > 0.999 and rel < 5e-2 if T * B >= 64 else cos > 0.95)) and bool((ds <= tol).all()) and bool(torch.isfinite(g16).all())
             # one complete update on the product path: train mode (dropout), random minibatch count (recorded / replayed small minibatches)
             m16.train()
             # ... with the switches a deployment can flip, at random: fp8 MFMA attention (BASELINE configs[4]), the reference-faithful per-row T5 dropout, bitwise-repeatable accumulation
@@ -91,7 +95,7 @@ def main():
             tag += f" | update: fp8={int(fp8)} t5_per_row={int(per_row)} deterministic={int(det)}"
             fin = bool(torch.isfinite(m16.arena.flat_p).all()) and all(np.isfinite(v) for v in info.values() if isinstance(v, float))
             ok = ok and fin and info["env_steps"] == T * B
-            print(f"{'ok  ' if ok else 'FAIL'} {tag}: gradient cosine {cos:.6f}, rel L2 {rel:.2e}, loss-sum diffs {np.array2string(ds, precision=2)}; update finite={fin}, ppo_total {info['ppo_total']:.4f}", flush=True)
+            print(f"{'ok  ' if ok else 'FAIL'} {tag}: gradient cosine {cos:.6f} (actor tower {cos_actor:.6f}), rel L2 {rel:.2e}, loss-sum diffs {np.array2string(ds, precision=2)}; update finite={fin}, ppo_total {info['ppo_total']:.4f}", flush=True)
             bad += 0 if ok else 1
         except Exception as e:
             bad += 1
@@ -99,7 +103,7 @@ def main():
             m16.eval()
         del st, nxt
         torch.cuda.empty_cache()
-    print(f"{bad} failing configuration(s) of {args.cases} (seed {args.seed})")
+    print(f"{bad} failing configuration(s) of {args.cases} (seed {args.seed}, critic_type {args.critic_type})")
     sys.exit(1 if bad else 0)
 
 
