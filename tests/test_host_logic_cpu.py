@@ -236,10 +236,11 @@ def test_il_preset_table_matches_the_reference_source():
 
 def test_bench_flop_accounting_matches_the_survey():
     """bench.py's reference-schedule FLOPs per update (the denominator of every "fraction of peak" on the reference's schedule) == SURVEY.md section 8(d):
-    C2 (4 096 rows, S = 181) 573 TFLOP, C3 (16 384 rows) 2.29 PFLOP per update of 3 towers x (fwd + 2 bwd) x 4 epochs; linear in rows and epochs."""
+    C2 (4 096 rows, S = 181) 573 TFLOP, C3 (16 384 rows) 2.29 PFLOP per update of 3 towers x (fwd + 2 bwd) x 4 epochs; linear in rows (up to the per-goal text adapter) and in epochs."""
     import bench
 
     c2, c3 = bench.flops_per_update(4096, 181, 12, 32, 4), bench.flops_per_update(16384, 181, 12, 64, 4)
     assert abs(c2 / 1e12 - 573) < 1.0 and abs(c3 / 1e15 - 2.29) < 0.005
-    assert abs(c3 / c2 - 4.0) < 1e-9 and abs(bench.flops_per_update(4096, 181, 12, 32, 1) * 4 - c2) < 1e-6 * c2
+    assert abs(c3 / c2 - 4.0) < 1e-4 and abs(      # (the text adapter is counted per unique goal, not per row)
+               bench.flops_per_update(4096, 181, 12, 32, 1) * 4 - c2) < 1e-6 * c2
     assert bench.flops_per_update(4096, 233, 64, 32, 4) > 1.25 * c2        # 64-token instructions: S = 233
