@@ -604,6 +604,11 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (the reference trains with the policy in train() mode: default here too)")
     ap.add_argument("--cpu-c1-full", action="store_true", help="only time BASELINE configs[0] (4 envs x 32 steps) IN FULL on the host CPU and exit")
+    ap.add_argument("--fp8-attention", action="store_true", help="fusion-encoder attention on the e4m3 / e5m2 MFMA kernels in the HEADLINE run (BASELINE configs[4]: "
+                    "--gpus 8 --scaling strong --global-envs 256 --task Mixed --L 64 --fp8-attention)")
+    ap.add_argument("--t5-dropout-per-row", action="store_true", help="headline run with the reference's train-mode T5 statistics: one dropout realisation per (t, b) row and tower "
+                    "(default: one per unique goal and pass; both figures are in the default line)")
+    ap.add_argument("--grad-allreduce-bf16", action="store_true", help="the three per-tower gradient all-reduces cross xGMI as bf16 (126 MB instead of 252 MB per optimiser step)")
     args = ap.parse_args()
 
     if args.cpu_c1_full:
@@ -625,6 +630,9 @@ def main():
     torch.manual_seed(1234)          # identical frozen text encoder / initial weights on every rank ...
     model = SafeDinoLLAMATxNavActorCriticSeparate(device=dev)
     model.train(not args.eval_mode)
+    if args.fp8_attention:
+        model.set_fp8_attention(True)
+    model.t5_dropout_per_row = bool(args.t5_dropout_per_row)
     if world > 1:                    # ... and made certain by a broadcast of every parameter and buffer
         parallel.broadcast_model_(model)
     # N > 1: the update's collectives on sentinels, checked on every rank BEFORE anything is timed (one async all-reduce per tower range of the
@@ -639,7 +647,8 @@ def main():
         if B <= 0:
             raise SystemExit(f"bench.py --scaling strong: {args.global_envs} envs cannot feed {world} ranks")
     chunk = args.env_chunk if 0 < args.env_chunk < B else None
-    cfg = PPOLagConfig(env_chunk=chunk, cost_limit=args.cost_limit, deterministic=args.deterministic)
+    wire = "bf16" if args.grad_allreduce_bf16 else "fp32"
+    cfg = PPOLagConfig(env_chunk=chunk, cost_limit=args.cost_limit, deterministic=args.deterministic, grad_allreduce_dtype=wire)
     eng = PPOLagEngine(model, cfg)
     st, nxt, ep = fill_synthetic_rollout(model, SynthSpec(T=T, B=B, L=args.L, task=args.task, seed=1234 + rank), device=dev)
 
@@ -653,7 +662,7 @@ def main():
         del eng
         torch.cuda.empty_cache()
         chunk = 32 if B > 32 else max(1, B // 2)
-        cfg = PPOLagConfig(env_chunk=chunk, cost_limit=args.cost_limit, deterministic=args.deterministic)
+        cfg = PPOLagConfig(env_chunk=chunk, cost_limit=args.cost_limit, deterministic=args.deterministic, grad_allreduce_dtype=wire)
         eng = PPOLagEngine(model, cfg)
         ms, info, step = timed_updates(eng, st, nxt, ep, args.steps, args.warmup, world, dev)
     per_rank_ms = list(timed_updates.per_rank_ms)
@@ -752,6 +761,8 @@ def main():
                 return {"error": repr(e)[:300]}
 
         del eng, step
+        model.set_fp8_attention(False)         # the secondary legs choose their own attention / dropout variants
+        model.t5_dropout_per_row = False
         acting = guarded(acting_bench, model, st, B, dev)
         del st, nxt
         torch.cuda.empty_cache()
@@ -788,16 +799,25 @@ def main():
                "n_gpus": world, "rccl_ranks": (torch.distributed.get_world_size() if parallel.is_dist() else 1),
                "collective_preflight": pre, "ms_per_step_per_rank": {"min": round(min(per_rank_ms), 2), "max": round(max(per_rank_ms), 2)},
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
-               "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": (f"C4: {args.task}, {args.global_envs} envs sharded over {world} GPU(s) ({B} on rank 0) x T={T}-step rollout "
-                                       f"(BASELINE configs[3], strong scaling), cost_limit {args.cost_limit}, " if args.scaling == "strong" else
+               "scaling": args.scaling,
+               # a scaling CURVE needs this command at N = 1, 2, 4, 8 on a multi-GPU node (the driver's SCALE run): one line is one point, and only a line whose
+               # ranks sat on distinct GPUs behind RCCL is a point of it (gloo ranks sharing one GPU are plumbing tests)
+               "scaling_measured": bool(world > 1 and pre.get("backend") == "nccl" and torch.cuda.device_count() >= world),
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": ((f"C5: {args.task} task sampler, {args.global_envs} envs sharded over {world} GPU(s) ({B} on rank 0) x T={T}-step rollout, "
+                                        f"fp8 MFMA attention (BASELINE configs[4], strong scaling), cost_limit {args.cost_limit}, "
+                                        if (args.fp8_attention and args.task == "Mixed") else
+                                        f"C4: {args.task}, {args.global_envs} envs sharded over {world} GPU(s) ({B} on rank 0) x T={T}-step rollout "
+                                        f"(BASELINE configs[3], strong scaling), cost_limit {args.cost_limit}, ") if args.scaling == "strong" else
                                        f"C3: {args.task}, {B} envs/GPU x T={T}-step rollout, cost constraint active (cost_limit {args.cost_limit}) "
                                        f"(BASELINE configs[2]{'' if world == 1 else ', replicated per GPU: weak scaling'}), ") +
                                       f"L={args.L} goal tokens, S={S} fusion tokens, 3 towers x 4 epochs x 1 minibatch"
                                       f"{'' if chunk is None else f' in {B // chunk} env-chunks of {chunk}'}, Adam+clip",
                           "global_envs": args.global_envs if args.scaling == "strong" else B * world, "rollout_steps": T, "rows_per_gpu": R, "parallelism": f"dp{world}", "env_chunk": chunk,
                           "stage_losses": list(cfg.stage_losses), "weights": "random-init, reference geometry (168.9 M params)",
-                          "dropout": 0.0 if args.eval_mode else 0.1, "deterministic_accumulation": bool(args.deterministic)},
+                          "dropout": 0.0 if args.eval_mode else 0.1, "deterministic_accumulation": bool(args.deterministic),
+                          "attention": "fp8 (e4m3 / e5m2 MFMA)" if args.fp8_attention else "bf16", "t5_dropout": "per (t, b) row and tower (reference statistics)" if args.t5_dropout_per_row
+                          else "per unique goal and pass", "grad_allreduce_dtype": wire},
                "reference_equivalent_tflop_per_update": round(algo / 1e12, 1),
                "note": "reference_equivalent counts SURVEY 8(d) FLOPs of the reference's schedule; the engine executes fewer (last fusion "
                        "layer only for the consumed token, T5 once per unique goal) -- see roofline.executed_mfma_*",

@@ -58,6 +58,7 @@ class PPOLagConfig:
     adam_betas: Tuple[float, float] = (0.9, 0.999)
     adam_eps: float = 1e-8
     deterministic: bool = False           # bitwise-repeatable gradients: cross-workgroup accumulation in 64-bit fixed point (svla_det_config)
+    grad_allreduce_dtype: str = "fp32"    # "bf16": the per-tower gradient ranges cross xGMI as bf16 (126 MB instead of 252 MB per step; parallel._Bf16Exchange)
 
 
 class PPOLagEngine:
@@ -98,7 +99,8 @@ class PPOLagEngine:
     def _reduce_tower_async(self, k: int):
         if parallel.is_dist():
             a, b = self.model.arena.tower_ranges[k]
-            self._pending.append(parallel.allreduce_sum_async(self.model.arena.flat_g[a:b]))
+            wire = torch.bfloat16 if self.cfg.grad_allreduce_dtype == "bf16" else None
+            self._pending.append(parallel.allreduce_sum_async(self.model.arena.flat_g[a:b], wire_dtype=wire))
 
     def _accumulate(self, batch: Dict, n_total: int, lam: float, last: bool = False, cache_key=None):
         """``last``: this is the final env-chunk of the minibatch -- each tower's gradient range is handed to the asynchronous
@@ -227,7 +229,10 @@ class PPOLagEngine:
             for k, on in enumerate(active):
                 if on:
                     a, b = ar.tower_ranges[k]
-                    parallel.allreduce_sum_(ar.flat_g[a:b])
+                    if cfg.grad_allreduce_dtype == "bf16":
+                        parallel.allreduce_sum_async(ar.flat_g[a:b], wire_dtype=torch.bfloat16).wait()
+                    else:
+                        parallel.allreduce_sum_(ar.flat_g[a:b])
         self._pending = []
         self._gnorm_sq.zero_()
         for k, on in enumerate(active):       # clip_grad_norm_ sees the parameters that have a gradient

@@ -82,7 +82,8 @@ def test_bench_two_ranks_well_formed_line(scaling):
     assert out["roofline"] is not None and "frac" in out["roofline"]
 
 
-def test_bench_eight_ranks_strong_scaling_fetch_plumbing():
+@pytest.mark.parametrize("variant", ["c4_fetch", "c5_mixed_fp8_bf16wire"])
+def test_bench_eight_ranks_strong_scaling_fetch_plumbing(variant):
     """BASELINE configs[3] as the driver will launch it on the 8-GPU node -- `bench.py --gpus 8 --scaling strong --global-envs 250` under
     torch.distributed.run -- with the eight ranks sharing this box's one GPU through gloo (uneven shards: 250 = 2 x 32 + 6 x 31; three asynchronous
     per-tower all-reduces in flight on eight ranks; the single count all-reduce; the cost accumulator), short rollouts (T = 4).  RCCL itself needs
@@ -95,12 +96,21 @@ def test_bench_eight_ranks_strong_scaling_fetch_plumbing():
     port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--T", "4",
-           "--no-cpu-baseline", "--no-secondary", "--no-roofline", "--scaling", "strong", "--global-envs", "250", "--task", "Fetch"]
+           "--no-cpu-baseline", "--no-secondary", "--no-roofline", "--scaling", "strong"]
+    # BASELINE configs[3] (Fetch, uneven shards) / configs[4] AS WRITTEN from the command line: mixed task sampler, 64-token instructions, 256 envs over the
+    # eight ranks, fp8 MFMA attention in the headline run -- plus the bf16 gradient exchange, so that both new flags cross eight ranks once
+    cmd += (["--global-envs", "250", "--task", "Fetch"] if variant == "c4_fetch" else
+            ["--global-envs", "256", "--task", "Mixed", "--L", "64", "--fp8-attention", "--grad-allreduce-bf16", "--t5-dropout-per-row"])
+    n_envs = 250 if variant == "c4_fetch" else 256
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["scaling"] == "strong"
-    assert out["config"]["global_envs"] == 250 and out["loss"]["env_steps"] == 4 * 250
+    assert out["scaling_measured"] is False          # eight gloo ranks on one GPU are plumbing, not a point of a scaling curve
+    assert out["config"]["global_envs"] == n_envs and out["loss"]["env_steps"] == 4 * n_envs
+    if variant != "c4_fetch":
+        c = out["config"]
+        assert c["attention"].startswith("fp8") and c["grad_allreduce_dtype"] == "bf16" and c["t5_dropout"].startswith("per (t, b) row") and "configs[4]" in c["workload"]
     assert out["value"] > 0 and all(v == v for v in out["loss"].values() if isinstance(v, float))
 
 

@@ -58,6 +58,19 @@ def _worker(rank, world, port, q):
     handles = [parallel.allreduce_sum_async(flat[a:b]) for a, b in ((0, cut), (cut, 2 * cut), (2 * cut, flat.numel()))]
     for h in handles:
         h.wait()
+    # the same exchange with bf16 on the wire (PPOLagConfig.grad_allreduce_dtype = "bf16", bench.py --grad-allreduce-bf16): the fp32 range comes back holding the
+    # backend's sum of the ranks' bf16-rounded shards -- within bf16 rounding of the fp32 exchange, and identical on every rank
+    local = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    wire = local.clone()
+    hb = [parallel.allreduce_sum_async(wire[a:b], wire_dtype=torch.bfloat16) for a, b in ((0, cut), (cut, 2 * cut), (2 * cut, wire.numel()))]
+    for h in hb:
+        assert h.wait()
+    assert wire.dtype == torch.float32 and torch.equal(wire, wire.to(torch.bfloat16).float())
+    tol = 2.0 ** -7 * (local.abs() + (flat - local).abs()) + 1e-12          # two roundings to 8 significant bits + one of the sum
+    assert bool(((wire - flat).abs() <= tol).all()), float((wire - flat).abs().max())
+    every = [torch.zeros_like(wire) for _ in range(world)]
+    dist.all_gather(every, wire)
+    assert all(torch.equal(e, wire) for e in every)
     jc, n_ep = parallel.mean_episode_cost(3.0 * (rank + 1), 2.0, "cpu")
     # bench.py's collective pre-flight on a stand-in arena (three "tower ranges" of one flat buffer) + the per-rank clock gather
     class _Arena:
