@@ -176,6 +176,24 @@ int svla_attn_bwd_two_pass(int on);
  * (safevla_amd/build.py), so the header stays the single source of truth.  Returns 0, or the first non-zero status with
  * *failed_at = the index of the failing call. */
 int svla_replay_calls(int n, const int* fn_ids, const int* arg_offsets, const unsigned long long* args, int* failed_at);
+
+/* ---- tower-grouped launches (round 6) ---------------------------------------------------------------------------------------------
+ * The three towers of the actor-critic (SafeDinoLLAMATxNavActorCriticSeparate: actor, reward critic, cost critic,
+ * architecture/models/allenact_transformer_models/separate_actor_critic.py:27-37) run the same kernel sequence on the same shapes with
+ * different weights.  Between svla_group_begin(members) and svla_group_end(stream), the launches of the entry points above are not issued but
+ * kept per member (svla_group_member(m) selects whose call comes next); svla_group_end issues launch j of all members as ONE grid -- blockIdx.z /
+ * workgroup_id_z picks the member's argument block -- on `stream`, falling back to one launch per member wherever the members' launches differ in
+ * anything but their arguments (and for kernels without a grouped twin: csrc/launch.h lists how a kernel takes part).  Results are bit-identical
+ * to the per-member launches (same kernels, same arithmetic, same grids per member).  A capture belongs to the calling thread; captures do not nest.
+ * svla_replay_calls_grouped replays `members` recorded sequences that name the same entry points in the same order (args[m] = member m's argument
+ * words, laid out as for svla_replay_calls) as begin / member calls / end per call index: the acting step of the three towers becomes one dependency
+ * chain of grouped launches instead of three streams.  svla_group_stats: launches issued grouped / singly by this thread's captures since the last call. */
+int svla_group_begin(int members);
+int svla_group_member(int member);
+int svla_group_end(void* stream);
+int svla_group_stats(long* grouped, long* single);
+int svla_replay_calls_grouped(int n, int members, const int* fn_ids, const int* arg_offsets, const unsigned long long* const* args, void* stream,
+                              int* failed_at);
 /* fn_ids are positions in THIS header: the generated dispatcher reports the hash of the ordered 'name(types)' list it was built from, and the
  * binding (safevla_amd/_lib.py) refuses a library whose stamp differs from the header it parsed. */
 int svla_replay_abi_stamp(unsigned long long* stamp);

@@ -41,7 +41,7 @@ def abi_signature(path: str = HEADER) -> str:
     src = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
     out = []
     for m in re.finditer(r"\bint\s+(svla_\w+)\s*\((.*?)\)\s*;", src, flags=re.S):
-        if m.group(1) == "svla_replay_calls":
+        if m.group(1).startswith("svla_replay_calls"):
             continue
         tys = []
         for a in m.group(2).split(","):
@@ -84,7 +84,7 @@ class _Lib:
         self.decls = parse_header()
         # ids of the entry points in svla_replay_calls: declaration order of the header, the replay entry itself excluded (build.py generates
         # the dispatcher from the same header in the same order)
-        self.fn_ids = {n: i for i, n in enumerate(k for k in self.decls if k != "svla_replay_calls")}
+        self.fn_ids = {n: i for i, n in enumerate(k for k in self.decls if not k.startswith("svla_replay_calls"))}
         for name, args in self.decls.items():
             fn = getattr(self.cdll, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = ctypes.c_int
@@ -107,7 +107,11 @@ class _Lib:
             # lazily inside a HIP-graph capture or a replay thread.  Deferred to the first call so that CPU-only processes can still load the library.
             self._gpu_init_done = True
             if torch_cuda_available():
-                self.cdll.svla_gemm_force_small_tile(0)
+                rc = self.cdll.svla_gemm_force_small_tile(0)
+                if rc != 0:      # (hipMalloc of the dispatchers' scratch or the load of the assembly code object failed: say so here, not as an opaque status of a later GEMM)
+                    self._gpu_init_done = False
+                    raise SvlaError(f"one-time GPU initialisation of libsvla_hip.so failed with status {rc} (svla_gemm_force_small_tile(0): CU count, zero-bias scratch, "
+                                    "assembly code object)")
         fn = getattr(self.cdll, name)
         if self.recorder is not None:
             self.recorder.append((fn, args))

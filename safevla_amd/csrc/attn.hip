@@ -142,7 +142,7 @@ __device__ __forceinline__ bool masked(const AttnArgs& p, int q, int key, const 
 // in LDS, masked to -inf) -- the per-tile runtime predicates of the general form (28 unrolled wave-uniform conditions) cost 316 spilled SGPRs through
 // v_readlane / v_writelane.
 template <int NKT, bool GENERIC, int NW = 4, bool EXACT = false>
-__global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs p) {
+__device__ __forceinline__ void attn_fwd_kernel_body(AttnArgs p) {
     p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16;
@@ -263,6 +263,8 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs p) {
         if (p.LSE && g == 0 && q < Sq) p.LSE[((size_t)r * p.H + h) * Sq + q] = (mx + __log2f(lsum)) * LN2;   // natural-log LSE
     }
 }
+template <int NKT, bool GENERIC, int NW = 4, bool EXACT = false>
+__global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs p) { attn_fwd_kernel_body<NKT, GENERIC, NW, EXACT>(p); }
 
 // item -> (row, head) with every XCD walking whole rows: item i is processed on XCD i % 8 (workgroup b on XCD b % 8; the persistent forward's grid is a multiple of 8),
 // so items 8 j + x, j = 8 g .. 8 g + 7, become the eight heads of row 8 g + x: the eight 128-byte head slices of a token's line group go through ONE L2
@@ -293,7 +295,7 @@ __device__ __forceinline__ AttDrop att_drop_head(const AttnArgs& p, int r, int h
 // (row, head) items instead and keeps the NEXT item's K/V head slices and Q fragments in flight in registers (72 VGPRs)
 // while it computes the current item from LDS: global latency is off the critical path after the first item.
 template <int NKT>
-__global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_persist_kernel(AttnArgs p, int nitems) {
+__device__ __forceinline__ void attn_fwd_persist_kernel_body(AttnArgs p, int nitems) {
     p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 16, IT = SP * 8 / ATT_THREADS, MAXQT = (NKT + 3) / 4;
@@ -440,6 +442,8 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_persist_kernel(AttnAr
         }
     }
 }
+template <int NKT>
+__global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_persist_kernel(AttnArgs p, int nitems) { attn_fwd_persist_kernel_body<NKT>(p, nitems); }
 
 // ================================================================================================ backward
 // Two kernels, each with only two [S,64] operands resident in LDS (2 workgroups per CU):
@@ -1215,7 +1219,9 @@ static int launch_fwd(const AttnArgs& p, int rows, hipStream_t st) {
                 slots = 2 * n_cu;              // 2 workgroups per CU
             }
             const int nitems = rows * p.H;
-            hipLaunchKernelGGL((attn_fwd_persist_kernel<NKT>), dim3(nitems < slots ? nitems : slots), dim3(ATT_THREADS), ldsp, st, p, nitems);
+            // (a tower group shares the two-workgroups-per-CU budget: the grouped launch carries one third of the slots per member)
+            const int gslots = (slots / svla_group_size()) & ~7;
+            SVLA_LAUNCH((attn_fwd_persist_kernel<NKT>), (attn_fwd_persist_kernel_body<NKT>), ATT_THREADS, 2, dim3(nitems < gslots ? nitems : gslots), dim3(ATT_THREADS), ldsp, st, p, nitems);
             return svla_launch_status();
         }
     }
@@ -1239,6 +1245,11 @@ static int launch_fwd(const AttnArgs& p, int rows, hipStream_t st) {
             else hipLaunchKernelGGL((attn_fwd_kernel<NKT, false, 8>), dim3(rows * p.H), dim3(512), lds, st, p);
             return svla_launch_status();
         }
+    }
+    if constexpr (NKT <= 16) {      // the shapes of an acting step / small update (T5's 12 ... 64 tokens, the decoder's block-causal windows, the pruned layer): tower-groupable
+        if (generic) SVLA_LAUNCH((attn_fwd_kernel<NKT, true>), (attn_fwd_kernel_body<NKT, true>), ATT_THREADS, 1, dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
+        else SVLA_LAUNCH((attn_fwd_kernel<NKT, false>), (attn_fwd_kernel_body<NKT, false>), ATT_THREADS, 1, dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
+        return svla_launch_status();
     }
     if (generic) hipLaunchKernelGGL((attn_fwd_kernel<NKT, true>), dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<NKT, false>), dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
@@ -1307,7 +1318,7 @@ static int launch_bwd(const AttnArgs& p, int rows, hipStream_t st) {
 // before the product with V.
 #define DEC_THREADS 256
 #define DEC_MAXB 16          // S <= 512: 16 blocks of 32 keys
-__global__ void __launch_bounds__(DEC_THREADS) attn_decode_kernel(AttnArgs p) {
+__device__ __forceinline__ void attn_decode_kernel_body(AttnArgs p) {
     __shared__ float red[4][2];
     __shared__ float accs[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1390,6 +1401,7 @@ __global__ void __launch_bounds__(DEC_THREADS) attn_decode_kernel(AttnArgs p) {
         if (p.LSE && tid == 0) p.LSE[(size_t)r * p.H + h] = (mx + __log2f(ls)) * LN2;
     }
 }
+__global__ void __launch_bounds__(DEC_THREADS) attn_decode_kernel(AttnArgs p) { attn_decode_kernel_body(p); }
 
 extern "C" int svla_attn_fwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t* V, long ld, bf16_t* O, long ldo, float* LSE,
                                   int rows, int S, int H, int head_dim, float scale, int mask_mode, const int* traj,
@@ -1407,7 +1419,7 @@ extern "C" int svla_attn_fwd_bf16(const bf16_t* Q, const bf16_t* K, const bf16_t
     p.xcd_rows = 0;      // (measured on the persistent forward: +1.5 % time with whole rows per XCD -- its next-item prefetch already hides the fetch; -1.4 % on the backward)
     hipStream_t st = (hipStream_t)stream;
     if (p.Sq == 1 && !bias && mask_mode == MASK_NONE && !p.drop.thr && !g_attn_no_decode) {      // one query per row: read the valid keys only (KV-cached acting step)
-        hipLaunchKernelGGL(attn_decode_kernel, dim3(rows * H), dim3(DEC_THREADS), 0, st, p);
+        SVLA_LAUNCH(attn_decode_kernel, attn_decode_kernel_body, DEC_THREADS, 1, dim3(rows * H), dim3(DEC_THREADS), 0, st, p);
         return svla_launch_status();
     }
     if (S <= 64) return launch_fwd<4>(p, rows, st);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "launch.h"
 
 #define SVLA_OK 0
 #define SVLA_EINVAL (-1)

@@ -82,7 +82,7 @@ __device__ __forceinline__ float gelu_f(float x) {
     return x * (g + 0.5f);
 }
 
-__global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p) {
+__device__ __forceinline__ void gemm_nt_bf16_kernel_body(GemmNtArgs p) {
     p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* As = (bf16_t*)smem;                 // [NST][BM][BK]
@@ -312,6 +312,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p)
         if (p.bits_out) p.bits_out[relu_bits_word(m, n0 + ecc * 8, p.N) + (((n0 + ecc * 8) & 63) >> 3)] = (unsigned char)obits;
     }
 }
+__global__ void __launch_bounds__(NTHREADS, 2) gemm_nt_bf16_kernel(GemmNtArgs p) { gemm_nt_bf16_kernel_body(p); }
 
 // =================================================================================================
 // 256x256 tile kernel (8 waves = 2(M) x 4(N), wave tile 128x64 = 4x2 MFMA 32x32 tiles) for the big row-streaming GEMMs.
@@ -567,7 +568,7 @@ struct Nt256Epi {
 // ACT / AUX (bit 0: +residual, bit 1: ReLU mask) are compile-time: a runtime-selected epilogue unrolled over the 32 accumulator
 // pieces is ~100 KiB of code (128 inlined erff bodies ...) that evicts the main loop from the instruction cache once per tile.
 template <int ACT, int AUX, bool DROP>
-__global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(GemmNtArgs p) {
+__device__ __forceinline__ void gemm_nt256k64_bf16_kernel_body(GemmNtArgs p) {
     p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* As = (bf16_t*)smem;                    // [NS64][256][64]
@@ -693,6 +694,8 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
         prev_full = epi.run(acc, m0, n0);      // exactly 16 stores were issued behind this wave's in-flight DMA group
     }
 }
+template <int ACT, int AUX, bool DROP>
+__global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(GemmNtArgs p) { gemm_nt256k64_bf16_kernel_body<ACT, AUX, DROP>(p); }
 
 // =================================================================================================
 // 8-phase ("ping-pong") 256x256x64 NT kernel.  Same tile, wave layout (2(M) x 4(N) waves, 128 x 64 per wave) and epilogue as
@@ -717,7 +720,7 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt256k64_bf16_kernel(Ge
 // retired by the lgkmcnt wait in front of its MFMAs, one barrier before the next phase of the same group).
 #define P8_RING_BYTES 131072
 template <int ACT, int AUX, bool DROP>
-__global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt8p_bf16_kernel(GemmNtArgs p) {
+__device__ __forceinline__ void gemm_nt8p_bf16_kernel_body(GemmNtArgs p) {
     p.drop = drop_resolve(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -908,6 +911,8 @@ __global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt8p_bf16_kernel(GemmNt
 #undef P8_LDS
 #undef P8_COMPUTE
 }
+template <int ACT, int AUX, bool DROP>
+__global__ void __launch_bounds__(NT256_THREADS, 2) gemm_nt8p_bf16_kernel(GemmNtArgs p) { gemm_nt8p_bf16_kernel_body<ACT, AUX, DROP>(p); }
 
 template <int ACT, int AUX, bool DROP>
 static int launch_nt8p_inst(const GemmNtArgs& p, int grid, hipStream_t stream) {
@@ -917,7 +922,9 @@ static int launch_nt8p_inst(const GemmNtArgs& p, int grid, hipStream_t stream) {
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt8p_bf16_kernel<ACT, AUX, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_nt8p_bf16_kernel<ACT, AUX, DROP>), dim3(grid), dim3(NT256_THREADS), lds, stream, p);
+    // tower-groupable flavours: plain / ReLU x bias / residual (the fusion encoder's and the compressor's forwards at an acting step)
+    if constexpr (ACT <= 1 && AUX <= 1) SVLA_LAUNCH((gemm_nt8p_bf16_kernel<ACT, AUX, DROP>), (gemm_nt8p_bf16_kernel_body<ACT, AUX, DROP>), NT256_THREADS, 2, dim3(grid), dim3(NT256_THREADS), lds, stream, p);
+    else hipLaunchKernelGGL((gemm_nt8p_bf16_kernel<ACT, AUX, DROP>), dim3(grid), dim3(NT256_THREADS), lds, stream, p);
     return svla_launch_status();
 }
 
@@ -1147,7 +1154,7 @@ static int nt_as_try(const GemmNtArgs& p, hipStream_t stream) {
             HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set = true;
         }
-        hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(mt * nt), dim3(NTHREADS), lds, stream, q);
+        SVLA_LAUNCH(gemm_nt_bf16_kernel, gemm_nt_bf16_kernel_body, NTHREADS, 2, dim3(mt * nt), dim3(NTHREADS), lds, stream, q);
         return svla_launch_status();
     }
     return SVLA_OK;
@@ -1201,7 +1208,7 @@ static int nt_os_try(const GemmNtArgs& p, hipStream_t stream) {
             HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set = true;
         }
-        hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(mt * nt), dim3(NTHREADS), lds, stream, q);
+        SVLA_LAUNCH(gemm_nt_bf16_kernel, gemm_nt_bf16_kernel_body, NTHREADS, 2, dim3(mt * nt), dim3(NTHREADS), lds, stream, q);
         return svla_launch_status();
     }
     return SVLA_OK;
@@ -1256,7 +1263,7 @@ extern "C" int svla_gemm_nt_bf16(const bf16_t* A, long lda, const bf16_t* B, lon
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(mt * nt), dim3(NTHREADS), lds, (hipStream_t)stream, p);
+    SVLA_LAUNCH(gemm_nt_bf16_kernel, gemm_nt_bf16_kernel_body, NTHREADS, 2, dim3(mt * nt), dim3(NTHREADS), lds, (hipStream_t)stream, p);
     return svla_launch_status();
 }
 
@@ -1276,7 +1283,7 @@ extern "C" int svla_gemm_nt_rmsa_bf16(const bf16_t* A, long lda, const bf16_t* B
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(mt * nt), dim3(NTHREADS), lds, (hipStream_t)stream, p);
+    SVLA_LAUNCH(gemm_nt_bf16_kernel, gemm_nt_bf16_kernel_body, NTHREADS, 2, dim3(mt * nt), dim3(NTHREADS), lds, (hipStream_t)stream, p);
     return svla_launch_status();
 }
 

@@ -33,7 +33,7 @@ extern "C" int svla_feat_to_tokens(const float* feat, int R, int C, int P, int c
 
 // ------------------------------------------------------------------------------------------------
 // x0[r, 0, :] = fusion_token; x0[r, text_off + j, :] = text[gid[r], j, :]   (allenact_dino_transformer.py:672-692)
-__global__ void fusion_fill_kernel(const float* __restrict__ fusion_token, const bf16_t* __restrict__ text,
+__device__ __forceinline__ void fusion_fill_kernel_body(const float* __restrict__ fusion_token, const bf16_t* __restrict__ text,
                                    const int* __restrict__ gid, int R, int S, int L, int text_off, int D, bf16_t* __restrict__ x0) {
     const int r = blockIdx.x, lane = threadIdx.x;  // 64 threads x 8 elements per 512-wide slice of the row (D = 512: one slice)
     bf16_t* row = x0 + (size_t)r * S * D;
@@ -47,11 +47,13 @@ __global__ void fusion_fill_kernel(const float* __restrict__ fusion_token, const
             *(u32x4*)(row + (size_t)(text_off + j) * D + c) = *(const u32x4*)(tsrc + (size_t)j * D + c);
     }
 }
+__global__ void fusion_fill_kernel(const float* __restrict__ fusion_token, const bf16_t* __restrict__ text,
+                                   const int* __restrict__ gid, int R, int S, int L, int text_off, int D, bf16_t* __restrict__ x0) { fusion_fill_kernel_body(fusion_token, text, gid, R, S, L, text_off, D, x0); }
 
 extern "C" int svla_fusion_fill(const float* fusion_token, const bf16_t* text, const int* gid, int R, int S, int L,
                                 int text_off, int D, bf16_t* x0, void* stream) {
     if (R <= 0 || text_off + L > S || D <= 0 || (D % 8)) return SVLA_EINVAL;
-    hipLaunchKernelGGL(fusion_fill_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, fusion_token, text, gid, R, S, L, text_off, D, x0);
+    SVLA_LAUNCH(fusion_fill_kernel, fusion_fill_kernel_body, 1024, 1, dim3(R), dim3(64), 0, (hipStream_t)stream, fusion_token, text, gid, R, S, L, text_off, D, x0);
     return svla_launch_status();
 }
 
@@ -93,7 +95,7 @@ extern "C" int svla_fusion_text_bwd(const bf16_t* dx0, const int* gid, int T, in
 // Decoder input (allenact_dino_transformer.py:353-385 + text_cond_visual_encoder.py:263-283):
 //   out[b*T + t, :] = xf[(t*B+b)*S*512 + :]  (fusion token output)  + act_tab[masks ? prev_action : A] + hand_tab[hand]
 //                   + pe(time_step),  pe[2i] = sin(pos*div[i]), pe[2i+1] = cos(pos*div[i])
-__global__ void decoder_embed_kernel(const bf16_t* __restrict__ xf, long xf_row_stride, const float* __restrict__ act_tab,
+__device__ __forceinline__ void decoder_embed_kernel_body(const bf16_t* __restrict__ xf, long xf_row_stride, const float* __restrict__ act_tab,
                                      const float* __restrict__ hand_tab, const float* __restrict__ div_term,
                                      const int64_t* __restrict__ prev_actions, const float* __restrict__ masks,
                                      const int64_t* __restrict__ hand, const int64_t* __restrict__ time_step, int T, int B,
@@ -121,13 +123,18 @@ __global__ void decoder_embed_kernel(const bf16_t* __restrict__ xf, long xf_row_
         *(u32x4*)(out + ((size_t)b * T + t) * D + c) = o;
     }
 }
+__global__ void decoder_embed_kernel(const bf16_t* __restrict__ xf, long xf_row_stride, const float* __restrict__ act_tab,
+                                     const float* __restrict__ hand_tab, const float* __restrict__ div_term,
+                                     const int64_t* __restrict__ prev_actions, const float* __restrict__ masks,
+                                     const int64_t* __restrict__ hand, const int64_t* __restrict__ time_step, int T, int B,
+                                     int n_actions, int D, bf16_t* __restrict__ out) { decoder_embed_kernel_body(xf, xf_row_stride, act_tab, hand_tab, div_term, prev_actions, masks, hand, time_step, T, B, n_actions, D, out); }
 
 extern "C" int svla_decoder_embed_fwd(const bf16_t* xf, long xf_row_stride, const float* act_tab, const float* hand_tab,
                                       const float* div_term, const int64_t* prev_actions, const float* masks,
                                       const int64_t* hand, const int64_t* time_step, int T, int B, int n_actions, int D, bf16_t* out,
                                       void* stream) {
     if (T <= 0 || B <= 0 || D <= 0 || (D % 8)) return SVLA_EINVAL;
-    hipLaunchKernelGGL(decoder_embed_kernel, dim3((T * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, xf, xf_row_stride, act_tab,
+    SVLA_LAUNCH(decoder_embed_kernel, decoder_embed_kernel_body, 1024, 1, dim3((T * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, xf, xf_row_stride, act_tab,
                        hand_tab, div_term, prev_actions, masks, hand, time_step, T, B, n_actions, D, out);
     return svla_launch_status();
 }
@@ -229,7 +236,7 @@ extern "C" int svla_det_finalize(float* f32, long long* i64_shadow, long n, void
 
 // ------------------------------------------------------------------------------------------------
 // llama FeedForward gate (llama/model.py:359-360): g = silu(a) * b with [a | b] = x.[w1 | w3]^T  (row = [a(Hd) | b(Hd)])
-__global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ ab, long M, int Hd, bf16_t* __restrict__ g) {
+__device__ __forceinline__ void swiglu_fwd_kernel_body(const bf16_t* __restrict__ ab, long M, int Hd, bf16_t* __restrict__ g) {
     const long n = M * (Hd / 8);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const long m = i / (Hd / 8);
@@ -244,6 +251,7 @@ __global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ ab, long M, int Hd,
         *(u32x4*)(g + m * Hd + c) = o;
     }
 }
+__global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ ab, long M, int Hd, bf16_t* __restrict__ g) { swiglu_fwd_kernel_body(ab, M, Hd, g); }
 __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ ab, const bf16_t* __restrict__ dg, long M, int Hd,
                                   bf16_t* __restrict__ dab) {
     const long n = M * (Hd / 8);
@@ -272,7 +280,7 @@ __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ ab, const bf16_t* _
 extern "C" int svla_swiglu_fwd(const bf16_t* ab, long M, int Hd, bf16_t* g, void* stream) {
     if (M <= 0 || (Hd % 8)) return SVLA_EINVAL;
     long blocks = (M * (Hd / 8) + 255) / 256; if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, ab, M, Hd, g);
+    SVLA_LAUNCH(swiglu_fwd_kernel, swiglu_fwd_kernel_body, 1024, 1, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, ab, M, Hd, g);
     return svla_launch_status();
 }
 extern "C" int svla_swiglu_bwd(const bf16_t* ab, const bf16_t* dg, long M, int Hd, bf16_t* dab, void* stream) {
@@ -392,7 +400,7 @@ extern "C" int svla_transpose_cast_f32_bf16(const float* src, int rows, int cols
 }
 
 // rows of a table -> bf16 rows (T5 shared embedding gather): out[i, :] = table[ids[i], :]
-__global__ void embed_gather_kernel(const float* __restrict__ table, const int64_t* __restrict__ ids, long n, int D,
+__device__ __forceinline__ void embed_gather_kernel_body(const float* __restrict__ table, const int64_t* __restrict__ ids, long n, int D,
                                     bf16_t* __restrict__ out) {
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
@@ -400,9 +408,11 @@ __global__ void embed_gather_kernel(const float* __restrict__ table, const int64
     const float* src = table + (size_t)ids[wave] * D;
     for (int c = lane * 2; c < D; c += 128) *(uint32_t*)(out + wave * D + c) = pack_bf2(src[c], src[c + 1]);
 }
+__global__ void embed_gather_kernel(const float* __restrict__ table, const int64_t* __restrict__ ids, long n, int D,
+                                    bf16_t* __restrict__ out) { embed_gather_kernel_body(table, ids, n, D, out); }
 extern "C" int svla_embed_gather_f32_bf16(const float* table, const int64_t* ids, long n, int D, bf16_t* out, void* stream) {
     if (n <= 0 || (D % 2)) return SVLA_EINVAL;
-    hipLaunchKernelGGL(embed_gather_kernel, dim3((int)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, table, ids, n, D, out);
+    SVLA_LAUNCH(embed_gather_kernel, embed_gather_kernel_body, 1024, 1, dim3((int)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, table, ids, n, D, out);
     return svla_launch_status();
 }
 
@@ -614,7 +624,7 @@ extern "C" int svla_vit_tokens(const bf16_t* patch, const float* cls, const floa
 // In-place dropout of a [rows, N] bf16 activation (N % 8 == 0) with the counter-based masks of include/svla.h: the two
 // stand-alone sites of the frozen T5 encoder (after the token embedding and after the final layer norm; HF T5Stack), whose
 // other dropouts ride in the GEMM / attention epilogues.
-__global__ void dropout_rows_kernel(bf16_t* __restrict__ x, long n8, int N, DropCfg drop) {
+__device__ __forceinline__ void dropout_rows_kernel_body(bf16_t* __restrict__ x, long n8, int N, DropCfg drop) {
     drop = drop_resolve(drop);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
         u32x4 w = *(u32x4*)(x + i * 8);
@@ -629,13 +639,14 @@ __global__ void dropout_rows_kernel(bf16_t* __restrict__ x, long n8, int N, Drop
         *(u32x4*)(x + i * 8) = w;
     }
 }
+__global__ void dropout_rows_kernel(bf16_t* __restrict__ x, long n8, int N, DropCfg drop) { dropout_rows_kernel_body(x, n8, N, drop); }
 extern "C" int svla_dropout_bf16(bf16_t* x, long rows, int N, const svla_dropout* drop, void* stream) {
     if (rows <= 0 || N <= 0 || (N % 8)) return SVLA_EINVAL;
     const DropCfg c = drop_cfg(drop);
     if (!c.thr) return SVLA_OK;
     const long n8 = rows * N / 8;
     long blocks = (n8 + 255) / 256; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(dropout_rows_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, n8, N, c);
+    SVLA_LAUNCH(dropout_rows_kernel, dropout_rows_kernel_body, 1024, 1, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, n8, N, c);
     return svla_launch_status();
 }
 
@@ -643,7 +654,7 @@ extern "C" int svla_dropout_bf16(bf16_t* x, long rows, int N, const svla_dropout
 // ------------------------------------------------------------------------------------------------
 // llama KV-cache append of the acting path (llama/model.py:279-293: cache[:bsz, start_pos] = xk / xv): cache[b, t, :] = src[b, :] with
 // the slot t read from DEVICE memory, so that a recorded / captured single-step launch sequence is step-independent.
-__global__ void kv_append_kernel(const bf16_t* __restrict__ src, long ld_src, bf16_t* __restrict__ cache, long cache_rows, int width,
+__device__ __forceinline__ void kv_append_kernel_body(const bf16_t* __restrict__ src, long ld_src, bf16_t* __restrict__ cache, long cache_rows, int width,
                                  const int64_t* __restrict__ t_dev, int B) {
     const long t = *t_dev;
     const int cpr = width / 8;
@@ -652,12 +663,77 @@ __global__ void kv_append_kernel(const bf16_t* __restrict__ src, long ld_src, bf
         *(u32x4*)(cache + ((size_t)b * cache_rows + t) * width + c) = *(const u32x4*)(src + (size_t)b * ld_src + c);
     }
 }
+__global__ void kv_append_kernel(const bf16_t* __restrict__ src, long ld_src, bf16_t* __restrict__ cache, long cache_rows, int width,
+                                 const int64_t* __restrict__ t_dev, int B) { kv_append_kernel_body(src, ld_src, cache, cache_rows, width, t_dev, B); }
 extern "C" int svla_kv_append_bf16(const bf16_t* src, long ld_src, bf16_t* cache, long cache_rows, int width, const int64_t* t_dev, int B,
                                    void* stream) {
     if (B <= 0 || width <= 0 || (width % 8) || (ld_src % 8) || !t_dev) return SVLA_EINVAL;
     int blocks = (B * (width / 8) + 255) / 256; if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(kv_append_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, cache, cache_rows, width, t_dev, B);
+    SVLA_LAUNCH(kv_append_kernel, kv_append_kernel_body, 1024, 1, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, cache, cache_rows, width, t_dev, B);
     return svla_launch_status();
+}
+
+// ---- tower-grouped launches (csrc/launch.h; include/svla.h: svla_group_begin) -----------------------------------------------------------
+static thread_local GroupCapture* t_group_open = nullptr;      // this thread's open capture
+static thread_local GroupCapture* t_group_store = nullptr;     // allocated once per thread (~13 KiB of argument blocks)
+GroupCapture* svla_group_capture() { return t_group_open; }
+int svla_group_size() { return t_group_open ? t_group_open->size : 1; }
+extern "C" int svla_group_begin(int members) {
+    if (t_group_open || members < 1 || members > SVLA_MAXG) return SVLA_EINVAL;
+    if (!t_group_store) t_group_store = new GroupCapture();
+    GroupCapture* gc = t_group_store;
+    gc->size = members;
+    gc->member = 0;
+    gc->overflow = 0;
+    for (int m = 0; m < SVLA_MAXG; ++m) gc->n[m] = 0;
+    t_group_open = gc;
+    return SVLA_OK;
+}
+extern "C" int svla_group_member(int member) {
+    GroupCapture* gc = t_group_open;
+    if (!gc || member < 0 || member >= gc->size) return SVLA_EINVAL;
+    gc->member = member;
+    return SVLA_OK;
+}
+static bool group_same_launch(const DeferredLaunch& a, const DeferredLaunch& b) {
+    return a.flush == b.flush && a.smem == b.smem && a.grid.x == b.grid.x && a.grid.y == b.grid.y && a.grid.z == 1 && b.grid.z == 1 &&
+           a.block.x == b.block.x && a.block.y == b.block.y && a.block.z == b.block.z;
+}
+extern "C" int svla_group_end(void* stream) {
+    GroupCapture* gc = t_group_open;
+    if (!gc) return SVLA_EINVAL;
+    t_group_open = nullptr;                      // the launches below are real
+    hipStream_t st = (hipStream_t)stream;
+    bool lockstep = !gc->overflow;
+    for (int m = 1; m < gc->size; ++m) lockstep = lockstep && gc->n[m] == gc->n[0];
+    int rc = SVLA_OK;
+    if (lockstep) {
+        for (int j = 0; j < gc->n[0] && rc == SVLA_OK; ++j) {
+            const DeferredLaunch* ms[SVLA_MAXG];
+            bool same = gc->size > 1;
+            for (int m = 0; m < gc->size; ++m) {
+                ms[m] = &gc->q[m][j];
+                same = same && group_same_launch(gc->q[0][j], gc->q[m][j]);
+            }
+            if (same) { rc = ms[0]->flush(ms, gc->size, st); gc->grouped += 1; }
+            else for (int m = 0; m < gc->size && rc == SVLA_OK; ++m) { rc = ms[m]->flush(&ms[m], 1, st); gc->single += 1; }
+        }
+    } else {        // the members did not issue the same number of launches (e.g. one of them has a ragged row tail): member by member, in call order
+        for (int m = 0; m < gc->size && rc == SVLA_OK; ++m)
+            for (int j = 0; j < gc->n[m] && rc == SVLA_OK; ++j) {
+                const DeferredLaunch* one = &gc->q[m][j];
+                rc = one->flush(&one, 1, st);
+                gc->single += 1;
+            }
+    }
+    return rc;
+}
+extern "C" int svla_group_stats(long* grouped, long* single) {
+    GroupCapture* gc = t_group_store;
+    if (grouped) *grouped = gc ? gc->grouped : 0;
+    if (single) *single = gc ? gc->single : 0;
+    if (gc) gc->grouped = gc->single = 0;
+    return SVLA_OK;
 }
 
 // Zero a device buffer on the launch stream (gradient scratch that the text / embedding backward kernels accumulate into with atomics);

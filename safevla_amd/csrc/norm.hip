@@ -64,7 +64,7 @@ __device__ __forceinline__ void store_row(float* p, const float (&v)[VPL]) {
 // ---------------------------------------------------------------------------------------------- LayerNorm fwd
 // y = [relu](LN(x) * gamma + beta) [+ tok[(m % G) / tok_group]]        (rms != 0: RMS norm, beta ignored)
 template <typename T, int D>
-__global__ void norm_fwd_kernel(const T* __restrict__ x, RowMap xmap, const float* __restrict__ gamma,
+__device__ __forceinline__ void norm_fwd_kernel_body(const T* __restrict__ x, RowMap xmap, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float eps, int rows, int rms, int relu,
                                 const float* __restrict__ tok, int tok_group, T* __restrict__ y, RowMap ymap,
                                 float* __restrict__ mean_out, float* __restrict__ rstd_out) {
@@ -108,6 +108,11 @@ __global__ void norm_fwd_kernel(const T* __restrict__ x, RowMap xmap, const floa
         for (int j = 0; j < RPT; ++j) if (m + j < rows) finish(m + j, v[j]);
     }
 }
+template <typename T, int D>
+__global__ void norm_fwd_kernel(const T* __restrict__ x, RowMap xmap, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float eps, int rows, int rms, int relu,
+                                const float* __restrict__ tok, int tok_group, T* __restrict__ y, RowMap ymap,
+                                float* __restrict__ mean_out, float* __restrict__ rstd_out) { norm_fwd_kernel_body<T, D>(x, xmap, gamma, beta, eps, rows, rms, relu, tok, tok_group, y, ymap, mean_out, rstd_out); }
 
 // ---------------------------------------------------------------------------------------------- LayerNorm bwd
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma [* relu mask];   (rms: no mean(g) term)
@@ -215,7 +220,7 @@ static int norm_fwd_launch(const T* x, int xG, int xGS, int xOFF, const float* g
     if (tok && tok_group <= 0) return SVLA_EINVAL;
     RowMap xm{xG, xGS, xOFF}, ym{yG, yGS, yOFF};
     dim3 grid(norm_grid(rows, 2048)), block(256);
-#define NORM_FWD_CASE(DD) hipLaunchKernelGGL((norm_fwd_kernel<T, DD>), grid, block, 0, (hipStream_t)stream, x, xm, gamma, beta, eps, rows, rms, relu, tok, tok_group, y, ym, mean, rstd)
+#define NORM_FWD_CASE(DD) SVLA_LAUNCH((norm_fwd_kernel<T, DD>), (norm_fwd_kernel_body<T, DD>), 1024, 1, grid, block, 0, (hipStream_t)stream, x, xm, gamma, beta, eps, rows, rms, relu, tok, tok_group, y, ym, mean, rstd)
     // widths on this path: 512 (policy, T5), 384 / 768 / 1024 (frozen ViT-S / ViT-B + SigLIP-B / ViT-L preprocessors)
     if (D == 512) NORM_FWD_CASE(512);
     else if (D == 384) NORM_FWD_CASE(384);

@@ -322,7 +322,7 @@ extern "C" int svla_ce_loss_fwd_bwd_f32(const float* logits, const long* target,
 // D <= 1024 in 512-wide slices (8 values per lane and slice, one wave per row; the policy's D = 512 is one slice), N <= 32.  ``row_perm_T``/``row_perm_B`` > 0:
 // x rows are stored (b*T + t) (decoder layout) while out rows are (t*B + b) (the [step, sampler] layout of the API).
 template <int N_MAX>
-__global__ void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+__device__ __forceinline__ void small_linear_fwd_kernel_body(const float* __restrict__ x, const float* __restrict__ W,
                                         const float* __restrict__ bias, int rows, int N, int D, int T, int B,
                                         float* __restrict__ out) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -354,6 +354,10 @@ __global__ void small_linear_fwd_kernel(const float* __restrict__ x, const float
         if (lane == 0) out[(size_t)wave * N + n] = s + (bias ? bias[n] : 0.f);
     }
 }
+template <int N_MAX>
+__global__ void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                        const float* __restrict__ bias, int rows, int N, int D, int T, int B,
+                                        float* __restrict__ out) { small_linear_fwd_kernel_body<N_MAX>(x, W, bias, rows, N, D, T, B, out); }
 
 // dx[src_row,:] (+)= sum_n dout[r,n] W[n,:]; dW[n,:] += sum_r dout[r,n] x[src_row,:]; db[n] += sum_r dout[r,n]
 template <int N_MAX>
@@ -410,7 +414,7 @@ extern "C" int svla_small_linear_fwd_f32(const float* x, const float* W, const f
                                          int B, float* out, void* stream) {
     if (D <= 0 || D > 1024 || (D % 8) || N <= 0 || N > 32 || rows <= 0) return SVLA_EINVAL;
     if (T > 0 && T * B != rows) return SVLA_EINVAL;
-    hipLaunchKernelGGL(small_linear_fwd_kernel<32>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, bias,
+    SVLA_LAUNCH(small_linear_fwd_kernel<32>, small_linear_fwd_kernel_body<32>, 1024, 1, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, bias,
                        rows, N, D, T, B, out);
     return svla_launch_status();
 }

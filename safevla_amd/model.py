@@ -19,6 +19,7 @@ MI355X-first design (not a translation of the nn.Module graph):
 No CPU / eager fallback: every op below is a C-ABI kernel (include/svla.h); missing library => import error.
 """
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -859,6 +860,8 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
         # unique goal); the reference draws one per (t, b) row (it encodes every row).  True = the reference's statistics, at the price of
         # encoding R rows instead of U unique goals (+13 % FLOPs at L = 12).  Token-id goals only; eval mode is unaffected.
         self.t5_dropout_per_row = False
+        # recorded acting steps replay the three towers as grouped launches (ops.GroupedPlans); SVLA_GROUPED_TOWERS=0: the three-stream replay (A/B, tests)
+        self.grouped_towers = os.environ.get("SVLA_GROUPED_TOWERS", "1") != "0"
         self._acting_graphs, self._acting_backend = None, "plan"
         if self.concurrent_towers and precision == "bf16" and _os.environ.get("SVLA_NO_ACTING_PLANS", "0") != "1":
             self.enable_acting_plans(True)              # recorded single-step launches are the default acting path
@@ -1090,6 +1093,18 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
                 res = self.run_towers_concurrently(rec)          # the recording pass is a real step
                 assert versions == tuple(getattr(t, "_kv_version", 0) for t in self.towers)
                 st.plans, st.outs = [r[0] for r in res], [(r[1], r[2]) for r in res]
+                st.gplans = {}
+            elif self.grouped_towers and ops.GroupedPlans.compatible(st.plans):
+                # tower-grouped replay (round 6): call i of the three recorded sequences is issued as ONE grid whose blockIdx.z picks the tower's
+                # arguments (csrc/launch.h) -- one dependency chain on the current stream instead of three chains on three streams, three times
+                # the workgroups per dispatch.  Same kernels, same arithmetic: bit-identical to the three-stream replay (tests/test_grouped_gpu.py)
+                main = torch.cuda.current_stream()
+                gp = st.gplans.get(main.cuda_stream)
+                if gp is None:
+                    gp = st.gplans[main.cuda_stream] = ops.GroupedPlans(st.plans, main.cuda_stream)
+                for t in self.towers:
+                    t._seed_dev_buf.add_(0x3C6EF35)              # fresh dropout noise per step (device-resident seed, wraps in int32)
+                gp.replay()
             else:
                 main = torch.cuda.current_stream()
                 for t in self.towers:

@@ -83,6 +83,69 @@ class LaunchPlan:
                 raise RuntimeError(f"replayed {fn.__name__} failed with status {rc}")
 
 
+class GroupedPlans:
+    """The recorded single-step sequences of the three towers (same entry points in the same order on the same shapes, different weights and
+    buffers) replayed as ONE dependency chain of tower-grouped launches (svla_replay_calls_grouped, include/svla.h: call i of every tower inside
+    one launch-group capture -- blockIdx.z / workgroup_id_z selects the tower's argument block) on ``stream`` instead of three chains on three
+    streams: three times the workgroups per dispatch, a third of the dispatches, and no tower waiting behind another tower's chip-filling
+    kernel.  Bit-identical to replaying the plans one by one (tests/test_grouped_gpu.py).  ``GroupedPlans.compatible(plans)`` says whether the
+    sequences line up (if not -- e.g. towers with different critic heads -- the caller keeps the three-stream replay)."""
+
+    def __init__(self, plans, stream: int):
+        assert self.compatible(plans)
+        L = lib()
+        self.plans = list(plans)           # keeps the recorded tensors alive
+        ref = plans[0]
+        ids, offs, words = [], [], [[] for _ in plans]
+        for i, (fn, a) in enumerate(ref.calls):
+            name = fn.__name__
+            decl = L.decls[name]
+            ids.append(L.fn_ids[name])
+            offs.append(len(words[0]))
+            for m, pl in enumerate(plans):
+                am = pl.calls[i][1]
+                assert len(decl) == len(am), name
+                for (an, ct), v in zip(decl, am):
+                    if an == "stream":     # every launch of the group goes to the one stream the group is replayed on
+                        words[m].append(int(stream) & 0xFFFFFFFFFFFFFFFF)
+                    elif ct is ctypes.c_float:
+                        words[m].append(struct.unpack("<I", struct.pack("<f", float(v)))[0])
+                    elif ct is ctypes.c_double:
+                        words[m].append(struct.unpack("<Q", struct.pack("<d", float(v)))[0])
+                    elif v is None:
+                        words[m].append(0)
+                    elif isinstance(v, ctypes.c_void_p):
+                        words[m].append(int(v.value or 0))
+                    else:
+                        words[m].append(int(v) & 0xFFFFFFFFFFFFFFFF)
+        self._n, self._members, self._stream = len(ids), len(plans), ctypes.c_void_p(int(stream))
+        self._ids = (ctypes.c_int * max(1, len(ids)))(*ids)
+        self._offs = (ctypes.c_int * max(1, len(offs)))(*offs)
+        self._words = [(ctypes.c_ulonglong * max(1, len(w)))(*w) for w in words]
+        self._argv = (ctypes.POINTER(ctypes.c_ulonglong) * len(plans))(*[ctypes.cast(w, ctypes.POINTER(ctypes.c_ulonglong)) for w in self._words])
+        self._failed = ctypes.c_int(-1)
+        self._fn = L.cdll.svla_replay_calls_grouped
+
+    @staticmethod
+    def compatible(plans) -> bool:
+        if len(plans) < 2 or len(plans) > 3:
+            return False
+        names = [[fn.__name__ for fn, _ in pl.calls] for pl in plans]
+        return all(n == names[0] for n in names[1:]) and all(len(a) == len(b) for pl in plans[1:] for (_, a), (_, b) in zip(plans[0].calls, pl.calls))
+
+    def replay(self):
+        rc = self._fn(self._n, self._members, self._ids, self._offs, self._argv, self._stream, ctypes.byref(self._failed))
+        if rc != 0:
+            raise RuntimeError(f"grouped replay of {self.plans[0].calls[self._failed.value][0].__name__} (call {self._failed.value}) failed with status {rc}")
+
+
+def group_stats():
+    """(launches issued grouped, launches issued singly) by this thread's launch-group captures since the last call"""
+    g, s1 = ctypes.c_long(0), ctypes.c_long(0)
+    lib().cdll.svla_group_stats(ctypes.byref(g), ctypes.byref(s1))
+    return g.value, s1.value
+
+
 _REC: Optional["LaunchPlan"] = None
 
 

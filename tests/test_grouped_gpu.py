@@ -1,0 +1,173 @@
+"""Tower-grouped launches (csrc/launch.h, include/svla.h: svla_group_begin / svla_replay_calls_grouped; round 6).
+
+The three towers (separate_actor_critic.py:27-37) run the same kernels on the same shapes with different weights; a grouped launch issues the
+three as ONE grid (blockIdx.z = tower).  What must hold: a grouped launch is bit-identical to the three single launches (same kernels, same
+per-member grids), members that differ in anything but their arguments fall back to single launches, and the acting step replayed as grouped
+launches equals the three-stream replay step for step -- logits, values and the KV caches, with the train-mode dropout on."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF16 = torch.bfloat16
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def _grouped(fn_per_member, members=3):
+    """run fn_per_member(m) for m in range(members) inside one launch-group capture on the current stream"""
+    from safevla_amd import _lib
+
+    L = _lib.lib()
+    L.call("svla_group_begin", members)
+    try:
+        outs = []
+        for m in range(members):
+            L.call("svla_group_member", m)
+            outs.append(fn_per_member(m))
+    finally:
+        rc = L.cdll.svla_group_end(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, rc
+    return outs
+
+
+@pytest.mark.parametrize("M,N,K,flavour", [(64, 1536, 512, "plain"), (768, 512, 512, "residual_drop"), (11584, 1536, 512, "plain"),
+                                           (11584, 2048, 512, "relu_drop"), (11584, 512, 2048, "residual_drop"), (333, 512, 512, "relu")])
+def test_grouped_gemm_equals_single_launches(M, N, K, flavour):
+    """svla_gemm_nt_bf16 of three 'towers' in one capture == the three calls alone, bit for bit (128-tile kernel and the persistent 256-tile kernel,
+    dropout counters included), and the launches really were grouped."""
+    _need_gpu()
+    from safevla_amd import ops
+
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    A = [torch.randn(M, K, device=DEV, generator=g).to(BF16) for _ in range(3)]
+    W = [(torch.randn(N, K, device=DEV, generator=g) * 0.05).to(BF16) for _ in range(3)]
+    b = [torch.randn(N, device=DEV, generator=g) for _ in range(3)]
+    R = [torch.randn(M, N, device=DEV, generator=g).to(BF16) for _ in range(3)]
+    kw = {"plain": {}, "relu": dict(act=ops.ACT_RELU), "relu_drop": dict(act=ops.ACT_RELU), "residual_drop": {}}[flavour]
+
+    def call(m):
+        extra = dict(kw)
+        if "drop" in flavour:
+            extra["drop"] = ops.Dropout(1234 + m, 3, 0.1)
+        if "residual" in flavour:
+            extra["residual"] = R[m]
+        return ops.gemm_nt(A[m], W[m], M, N, K, bias=b[m], **extra)
+
+    want = [call(m) for m in range(3)]
+    ops.group_stats()
+    got = _grouped(call)
+    torch.cuda.synchronize()
+    grouped, single = ops.group_stats()
+    assert grouped >= 1 and single == 0, (grouped, single)
+    for m in range(3):
+        assert torch.equal(got[m], want[m]), (m, float((got[m].float() - want[m].float()).abs().max()))
+    assert not torch.equal(got[0], got[1])
+
+
+def test_grouped_norm_attention_and_glue_kernels():
+    """LayerNorm / RMSNorm forward, the T5-style masked attention, the decode attention, SwiGLU: grouped == single, bit for bit"""
+    _need_gpu()
+    from safevla_amd import ops
+
+    g = torch.Generator(device=DEV).manual_seed(7)
+    rows, D, H = 768, 512, 8
+    x = [torch.randn(rows, D, device=DEV, generator=g).to(BF16) for _ in range(3)]
+    gam = [torch.rand(D, device=DEV, generator=g) + 0.5 for _ in range(3)]
+    bet = [torch.randn(D, device=DEV, generator=g) for _ in range(3)]
+    norm = lambda m: ops.norm_fwd(x[m], gam[m], bet[m], 1e-5, rows, D=D)[0]
+    rms = lambda m: ops.norm_fwd(x[m], gam[m], None, 1e-6, rows, rms=True, save_stats=False, D=D)[0]
+    qkv = [torch.randn(64 * 12, 3 * D, device=DEV, generator=g).to(BF16) for _ in range(3)]
+    bias = [torch.randn(H, 12, 12, device=DEV, generator=g) for _ in range(3)]
+    att = lambda m: ops.attn_fwd(qkv[m], qkv[m][:, D:], qkv[m][:, 2 * D:], 3 * D, 64, 12, H, 1.0, bias=bias[m], save_lse=False, drop=ops.Dropout(5 + m, 1, 0.1))[0]
+    ab = [torch.randn(64, 4096, device=DEV, generator=g).to(BF16) for _ in range(3)]
+    swi = lambda m: ops.swiglu_fwd(ab[m], 64, 2048)
+    for name, fn in (("layernorm", norm), ("rmsnorm", rms), ("t5 attention", att), ("swiglu", swi)):
+        want = [fn(m) for m in range(3)]
+        ops.group_stats()
+        got = _grouped(fn)
+        torch.cuda.synchronize()
+        grouped, single = ops.group_stats()
+        assert grouped >= 1 and single == 0, (name, grouped, single)
+        for m in range(3):
+            assert torch.equal(got[m], want[m]), (name, m)
+
+
+def test_members_with_different_shapes_fall_back_to_single_launches():
+    _need_gpu()
+    from safevla_amd import ops
+
+    g = torch.Generator(device=DEV).manual_seed(3)
+    Ms = [64, 300, 64]          # 1 / 3 / 1 row tiles: the grids differ
+    A = [torch.randn(M, 512, device=DEV, generator=g).to(BF16) for M in Ms]
+    W = [(torch.randn(512, 512, device=DEV, generator=g) * 0.05).to(BF16) for _ in range(3)]
+    call = lambda m: ops.gemm_nt(A[m], W[m], Ms[m], 512, 512)
+    want = [call(m) for m in range(3)]
+    ops.group_stats()
+    got = _grouped(call)
+    torch.cuda.synchronize()
+    grouped, single = ops.group_stats()
+    assert grouped == 0 and single == 3, (grouped, single)
+    for m in range(3):
+        assert torch.equal(got[m], want[m])
+
+
+def test_capture_protocol_errors():
+    _need_gpu()
+    from safevla_amd import _lib
+
+    L = _lib.lib().cdll
+    assert L.svla_group_end(None) != 0                      # nothing open
+    assert L.svla_group_begin(4) != 0 and L.svla_group_begin(0) != 0
+    assert L.svla_group_begin(2) == 0
+    assert L.svla_group_begin(2) != 0                       # captures do not nest
+    assert L.svla_group_member(2) != 0 and L.svla_group_member(1) == 0
+    assert L.svla_group_end(None) == 0                      # empty capture: nothing issued
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_acting_steps_grouped_equal_three_stream_replay(train):
+    """The recorded acting step at 8 envs, stepped 12 times through the tower-grouped replay and through the three-stream replay from identical
+    states: same logits / values / cost values at every step and the same KV caches at the end -- with dropout on (``train``: device-resident seeds
+    advance identically) and off.  And the grouped path really grouped (no single-launch fall-back left in the chain)."""
+    _need_gpu()
+    from safevla_amd import ops
+    from safevla_amd.model import SafeDinoLLAMATxNavActorCriticSeparate
+    from safevla_amd.synth_env import SynthSpec, fill_synthetic_rollout
+
+    B, n = 8, 12
+    outs = {}
+    for mode in (True, False):
+        torch.manual_seed(11)
+        m = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV)
+        m.train(train)
+        st, _, _ = fill_synthetic_rollout(m, SynthSpec(T=n + 2, B=B, L=12, task="PickUp", seed=5), device=DEV)
+        for t in m.towers:
+            t.time_step_counter, t._kv = 0, None
+        m.grouped_towers = mode
+        m.enable_acting_plans(True)
+        res = []
+        ops.group_stats()
+        with torch.no_grad():
+            for t in range(n):
+                o, _ = m({k: v[t:t + 1] for k, v in st.observations.items()}, None, st.prev_actions[t:t + 1], st.masks[t:t + 1])
+                res.append((o.distributions.logits.float().clone(), o.values.float().clone(), o.c_values.float().clone()))
+        torch.cuda.synchronize()
+        stats = ops.group_stats()
+        kv = [c.clone() for t in m.towers for c in t._kv]
+        outs[mode] = (res, kv, stats)
+        del m, st
+    (rg, kvg, sg), (rs, kvs, ss) = outs[True], outs[False]
+    assert sg[0] > 50 * (n - 1) and sg[1] == 0, sg              # ~100 grouped launches per step, none issued singly
+    assert ss == (0, 0), ss
+    for t in range(n):
+        for a, b in zip(rg[t], rs[t]):
+            assert torch.equal(a, b), (t, float((a - b).abs().max()))
+    for a, b in zip(kvg, kvs):
+        assert torch.equal(a, b)
