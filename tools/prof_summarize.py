@@ -15,6 +15,35 @@ def stats(db, out, title):
     open(out, "w").write("\n".join(o) + "\n")
     print("\n".join(o[:14]))
 
+def timeline(db, out, n_last=140):
+    """the last ``n_last`` kernel dispatches in start order: short name, workgroups, duration, idle gap before it (one acting step is ~100 dispatches)"""
+    con = sqlite3.connect(db)
+    cur = con.cursor()
+    names = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+    cand = [n for n in names if n == "kernels"] or [n for n in names if "kernel_dispatch" in n]
+    if not cand:
+        open(out, "w").write("no kernel table: " + ", ".join(names) + "\n"); return
+    t = cand[0]
+    cols = [r[1] for r in cur.execute(f"pragma table_info({t})")]
+    pick = lambda *c: next((x for x in c if x in cols), None)
+    nm, st, en = pick("name", "kernel_name"), pick("start", "start_timestamp"), pick("end", "end_timestamp")
+    gx, wx = pick("grid_x", "grid_size_x", "grid_size"), pick("workgroup_x", "workgroup_size_x", "workgroup_size")
+    gz = pick("grid_z", "grid_size_z")
+    if not (nm and st and en):
+        open(out, "w").write(f"table {t}: columns {cols}\n"); return
+    sel = ", ".join(x for x in (nm, st, en, gx, wx, gz) if x)
+    rows = cur.execute(f"select {sel} from {t} order by {st} desc limit {int(n_last)}").fetchall()[::-1]
+    o = [f"# last {len(rows)} dispatches of {db} ({t}); columns: kernel | workgroups (x) | z | us | gap_us"]
+    prev = None
+    for r in rows:
+        name, s0, e0 = r[0], r[1], r[2]
+        wg = (r[3] // r[4]) if (gx and wx and r[4]) else -1
+        z = r[5] if gz else 1
+        short = name.replace("_Z12svla_groupedITnDaXadL_Z", "G:").split("(")[0][:70]
+        o.append(f"{short:70s} | {wg:6d} | {z} | {(e0 - s0) / 1e3:8.1f} | {((s0 - prev) / 1e3 if prev else 0):7.1f}")
+        prev = e0
+    open(out, "w").write("\n".join(o) + "\n")
+
 def _sources_sha():
     """Same hash as bench.py: kernel_sources_sha() -- bench.py refuses a traffic file measured on other kernel sources."""
     import os
@@ -87,6 +116,8 @@ def pmc(fdb, wdb, out):
 
 if sys.argv[1] == "stats":
     stats(sys.argv[2], sys.argv[3], " ".join(sys.argv[4:]))
+elif sys.argv[1] == "timeline":
+    timeline(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 140)
 elif sys.argv[1] == "pmc_shapes":
     pmc_shapes(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
 else:
