@@ -213,6 +213,9 @@ int svla_replay_abi_stamp(unsigned long long* stamp);
  * unregisters.  bf16 product path only (the fp32 verification kernels keep their atomics). */
 int svla_det_config(int slot, float* f32_base, long long* i64_shadow, long n);
 int svla_det_finalize(float* f32, long long* i64_shadow, long n, void* stream);
+/* Number of partial sums that had a registered shadow but took the plain fp32 atomic instead (|partial| >= 0.25, NaN, Inf) since the last reset: the run was
+ * bitwise repeatable iff 0.  Synchronises the device; the engine reports it as info["det_bypassed_partials"] in deterministic mode. */
+int svla_det_bypass_count(unsigned long long* count, int reset);
 
 /* ---- fp8 attention (BASELINE config 5: "fp8 MFMA attention") ---------------------------------------------------------------
  * The unmasked fusion-encoder attention (same reference op as svla_attn_fwd_bf16: nn.MultiheadAttention inside the post-LN
@@ -296,7 +299,8 @@ int svla_dropout_bf16(svla_bf16* x, long rows, int N, const svla_dropout* drop, 
 /* ---- optimiser (Adam lr 2e-5, max_grad_norm 0.5: training/online/dinov2_vits_tsfm_base.py:331-334; weight_decay > 0 = the
  * decoupled AdamW of the imitation-learning trainer, training/offline/train_pl.py:283-287) ---------------------------------- */
 /* *out += sum g[i]^2, reduced in a fixed order (block partials in a library-owned scratch, summed by the block that arrives last): calls that share `out`
- * must be issued on one stream (the engine's per-tower calls are); the first call allocates the scratch (not inside a stream capture). */
+ * must be issued on one stream (the engine's per-tower calls are).  The scratch is per (device, stream) -- launches in flight on different streams do not
+ * share partials or the arrival counter -- and is allocated by the first call on that stream (not inside a stream capture). */
 int svla_sumsq_f32(const float* g, long n, double* out, void* stream);
 int svla_adam_step_f32(float* p, const float* g, float* m, float* v, svla_bf16* p_bf16, long n, float lr, float beta1,
                        float beta2, float eps, int step, const double* gnorm_sq, float max_norm, float grad_scale,

@@ -116,7 +116,7 @@ __device__ __forceinline__ unsigned drop_keep4(const DropCfg& c, unsigned long l
 // plain atomic (not repeatable, but visible as NaN / Inf / a huge gradient instead of a silently wrapped one); the per-block LDS table of
 // decoder_embed_bwd applies the same rule.  svla_det_finalize folds the shadow back into the fp32 buffer.  Up to two registered ranges: the
 // flat gradient buffer, and a scratch range for accumulated intermediates.
-struct DetCfg { float* f32[2]; long long* i64[2]; long n[2]; };
+struct DetCfg { float* f32[2]; long long* i64[2]; long n[2]; unsigned long long* bypass; };   // bypass: device counter of partials that had a shadow but left it (svla_det_bypass_count)
 extern DetCfg g_svla_det;                 // host-side current configuration (misc.hip); all-null = plain fp32 atomics
 #define DET_SCALE 4503599627370496.f       // 2^52
 #define DET_UNSCALE 2.220446049250313e-16  // 2^-52
@@ -125,9 +125,14 @@ __device__ __forceinline__ unsigned long long det_fixed(float v) { return (unsig
 __device__ __forceinline__ void grad_add(const DetCfg& d, float* p, float v) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        if (d.i64[k] && fabsf(v) < DET_PARTIAL_MAX) {      // (false for NaN / Inf / out-of-range: those take the fp32 atomic below)
+        if (d.i64[k]) {
             const long off = p - d.f32[k];
-            if (off >= 0 && off < d.n[k]) { atomicAdd((unsigned long long*)(d.i64[k] + off), det_fixed(v)); return; }
+            if (off >= 0 && off < d.n[k]) {
+                if (fabsf(v) < DET_PARTIAL_MAX) { atomicAdd((unsigned long long*)(d.i64[k] + off), det_fixed(v)); return; }
+                // NaN / Inf / out-of-range: the fp32 atomic below (visible, not repeatable) -- and counted, so that a "deterministic" run that was not says so
+                if (d.bypass) atomicAdd(d.bypass, 1ull);
+                break;
+            }
         }
     }
     atomicAdd(p, v);

@@ -157,7 +157,10 @@ __global__ void decoder_embed_bwd_kernel(const bf16_t* __restrict__ dout, const 
     auto add = [&](int idx, float v) {
         if constexpr (DET) {
             if (fabsf(v) < DET_PARTIAL_MAX) atomicAdd(&tab[idx], det_fixed(v));      // < 8192 rows per block: the table cannot wrap
-            else atomicAdd(idx < (n_actions + 2) * D ? &d_act_tab[idx] : &d_hand_tab[idx - (n_actions + 2) * D], v);      // NaN / Inf / huge: straight to fp32, visible
+            else {      // NaN / Inf / huge: straight to fp32, visible -- and counted (svla_det_bypass_count)
+                atomicAdd(idx < (n_actions + 2) * D ? &d_act_tab[idx] : &d_hand_tab[idx - (n_actions + 2) * D], v);
+                if (det.bypass) atomicAdd(det.bypass, 1ull);
+            }
         } else atomicAdd(&tab[idx], v);
     };
     for (int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wave < T * B; wave += nw) {
@@ -213,11 +216,28 @@ extern "C" int svla_decoder_embed_bwd(const bf16_t* dout, const int64_t* prev_ac
 }
 
 // ---- deterministic accumulation: configuration and fold-back (common.h: DetCfg) -------------------------------------------------
-DetCfg g_svla_det = {{nullptr, nullptr}, {nullptr, nullptr}, {0, 0}};
+DetCfg g_svla_det = {{nullptr, nullptr}, {nullptr, nullptr}, {0, 0}, nullptr};
 
 extern "C" int svla_det_config(int slot, float* f32_base, long long* i64_shadow, long n) {
     if (slot < 0 || slot > 1 || n < 0 || ((f32_base == nullptr) != (i64_shadow == nullptr))) return SVLA_EINVAL;
+    if (f32_base && !g_svla_det.bypass) {      // the bypass counter lives as long as the library
+        unsigned long long* c = nullptr;
+        HIP_CHECK_RET(hipMalloc(&c, sizeof(unsigned long long)));
+        HIP_CHECK_RET(hipMemset(c, 0, sizeof(unsigned long long)));
+        g_svla_det.bypass = c;
+    }
     g_svla_det.f32[slot] = f32_base; g_svla_det.i64[slot] = i64_shadow; g_svla_det.n[slot] = f32_base ? n : 0;
+    return SVLA_OK;
+}
+// partials that had a registered shadow but took the plain fp32 atomic (|partial| >= 0.25 or non-finite) since the last reset: a deterministic-mode run is bitwise
+// repeatable iff this stays 0 (synchronises the device)
+extern "C" int svla_det_bypass_count(unsigned long long* count, int reset) {
+    if (!count) return SVLA_EINVAL;
+    *count = 0;
+    if (!g_svla_det.bypass) return SVLA_OK;
+    HIP_CHECK_RET(hipDeviceSynchronize());
+    HIP_CHECK_RET(hipMemcpy(count, g_svla_det.bypass, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) HIP_CHECK_RET(hipMemset(g_svla_det.bypass, 0, sizeof(unsigned long long)));
     return SVLA_OK;
 }
 __global__ void det_finalize_kernel(float* __restrict__ f, long long* __restrict__ s, long n) {
@@ -321,18 +341,32 @@ __global__ void sumsq_kernel(const float* __restrict__ g, long n, double* __rest
     }
     if (threadIdx.x == 0) { *out += red[0]; *done = 0u; }
 }
+// Scratch ([1024] partials + the arrival counter) is per (device, stream): two launches in flight on different streams -- the cost tower's extras next to an
+// optimiser step, two engines in one process -- would otherwise share the partials and the counter and both return wrong norms.  Launches on ONE stream
+// are ordered and reuse their slot; the counter is re-zeroed by a memset node in front of every launch, so a launch that died mid-way cannot poison the next one.
+struct SumsqSlot { int dev; hipStream_t stream; double* scratch; };
+static std::mutex g_sumsq_mu;
+static SumsqSlot g_sumsq_slots[64];
+static int g_sumsq_n = 0;
 extern "C" int svla_sumsq_f32(const float* g, long n, double* out, void* stream) {
     if (n <= 0) return SVLA_EINVAL;
     long blocks = (n + 1023) / 1024; if (blocks > 1024) blocks = 1024;
-    static std::once_flag once;
-    static double* scratch = nullptr;      // [1024] partials + the arrival counter; one stream at a time uses it (the optimiser step of one engine)
-    static int rc_alloc = 0;
-    std::call_once(once, [] {
-        hipError_t e = hipMalloc(&scratch, 1025 * sizeof(double));
-        if (e == hipSuccess) e = hipMemset(scratch, 0, 1025 * sizeof(double));
-        rc_alloc = (e == hipSuccess) ? 0 : (int)e;
-    });
-    if (rc_alloc) return rc_alloc;
+    int dev = 0;
+    HIP_CHECK_RET(hipGetDevice(&dev));
+    double* scratch = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_sumsq_mu);
+        for (int i = 0; i < g_sumsq_n; ++i)
+            if (g_sumsq_slots[i].dev == dev && g_sumsq_slots[i].stream == (hipStream_t)stream) { scratch = g_sumsq_slots[i].scratch; break; }
+        if (!scratch) {
+            if (g_sumsq_n >= 64) return SVLA_EINVAL;                                  // (64 distinct (device, stream) pairs: far beyond three tower streams x 8 devices' worth of use in one process)
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return SVLA_EINVAL;   // no allocation inside a capture: call once before
+            HIP_CHECK_RET(hipMalloc(&scratch, 1025 * sizeof(double)));
+            g_sumsq_slots[g_sumsq_n++] = SumsqSlot{dev, (hipStream_t)stream, scratch};
+        }
+    }
+    HIP_CHECK_RET(hipMemsetAsync(scratch + 1024, 0, sizeof(double), (hipStream_t)stream));
     hipLaunchKernelGGL(sumsq_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, g, n, out, scratch, (unsigned*)(scratch + 1024));
     return svla_launch_status();
 }
@@ -482,10 +516,14 @@ __global__ void patchify_u8_kernel(const unsigned char* __restrict__ frames, int
     const unsigned char* src = frames + ((size_t)b * H + gy * P) * W * 3 + crop_x * 3;
     const int K = 3 * P * P;
     if (wide) {
-        const int ndw = (rowbytes + 3 + 3) / 4;                 // words covering lead + segment
+        const int ndw = (rowbytes + 3 + 3) / 4;                 // upper bound of the words covering lead + segment of a row
         for (int i = threadIdx.x; i < P * ndw; i += blockDim.x) {
             const int r = i / ndw, j = i % ndw;
             const unsigned char* rp = src + (size_t)r * W * 3;
+            const int lead = (int)((uintptr_t)rp & 3);
+            // this row's own word count: the last word ends at most 3 bytes past the segment -- the slack the host's `wide` test proves (with the
+            // uniform bound a row with lead 0 and rowbytes % 4 == 2 read 6 bytes past it: ADVICE r5)
+            if (4 * j >= lead + rowbytes) continue;
             const uint32_t* ap = (const uint32_t*)((uintptr_t)rp & ~(uintptr_t)3);
             *(uint32_t*)(rows + r * pitch + 4 * j) = __builtin_nontemporal_load(ap + j);
         }

@@ -299,6 +299,10 @@ class PPOLagEngine:
                 n_mb += 1
         s = (info_acc / n_mb).cpu().tolist()      # host sync at the end of the update (the other one is the Jc reduction at its start)
         value, action, ent, c_value = 0.5 * (s[3] if m.critic_type == "discrete" else s[0]), s[1], s[2], 0.5 * s[4]
-        return {"ppo_total": cfg.value_loss_coef * value + cfg.action_weight * action + cfg.entropy_coef * ent, "value": value,
+        info = {"ppo_total": cfg.value_loss_coef * value + cfg.action_weight * action + cfg.entropy_coef * ent, "value": value,
                 "action": action, "entropy": ent, "c_value": c_value, "lagrangian_multiplier": lam, "Jc": Jc,
                 "env_steps": counts[-1]}
+        if cfg.deterministic:
+            # partial sums that left the fixed-point shadow (|partial| >= 0.25, NaN, Inf: plain fp32 atomics): the update was bitwise repeatable iff 0
+            info["det_bypassed_partials"] = ops.det_bypass_count(reset=True)
+        return info

@@ -250,7 +250,13 @@ class EarlyFusionCnnTransformerAgent:
         from .agent import ALL_STRETCH_ACTIONS
         if sampling not in ("greedy", "sample"):
             raise NotImplementedError(f"sampling {sampling!r}: 'greedy' (argmax) or 'sample' (categorical), utils/nn_utils.py sample_action_index_from_logits")
+        if getattr(model, "hdim_dec", 64) != 64:
+            # the step-by-step agent runs the KV-cached decoder step, which exists for 64-wide heads only (MFMA / decode attention kernels); say so at
+            # construction, not at the first get_action.  forward(batch) -- training and offline evaluation -- works for these presets.
+            raise NotImplementedError(f"the online agent needs 64-wide decoder heads; this preset has heads of {model.hdim_dec} "
+                                      "(TransformerConfig(n, 768, 8): base_6, siglip_base_3_6) -- use forward(batch) on whole windows")
         self.model, self.device, self.sampling, self.max_seq_len = model, torch.device(device), sampling, min(max_seq_len, 512, model.max_steps)
+        self._warned_window = False
         self.action_list = list(ALL_STRETCH_ACTIONS)
         self.generator = generator
         if tokenizer is None and model.text_encoder_name == "t5-small":
@@ -263,6 +269,7 @@ class EarlyFusionCnnTransformerAgent:
     def reset(self):
         self.curr_t = 0
         self.cache = dict()
+        self._warned_window = False
         self.model.time_step_counter = 0          # KV-cache slot of the next step; the caches themselves are overwritten slot by slot
 
     def get_action_list(self):
@@ -291,8 +298,14 @@ class EarlyFusionCnnTransformerAgent:
         slot = self.curr_t % self.max_seq_len
         if slot == 0:
             m.time_step_counter = 0
+            if self.curr_t > 0 and not self._warned_window:
+                # the reference keeps every embedded step and attends to the last max_seq_len of them (a sliding window, :493-495); here the KV cache restarts:
+                # the steps right after a restart see a shorter history than the reference's.  time_ids keeps counting like the reference's (:480).
+                import warnings
+                warnings.warn(f"episode longer than the {self.max_seq_len}-step KV-cache window: the window restarts (the reference slides it)")
+                self._warned_window = True
         one = lambda v, dt: torch.as_tensor(np.asarray(v)).to(dev).to(dt).reshape(1, 1)
-        batch = {"goals": self.cache["goal"], "time_ids": one(slot, torch.int64),
+        batch = {"goals": self.cache["goal"], "time_ids": one(self.curr_t, torch.int64),      # = curr_t, as early_fusion_tsfm_models.py:480 (not the cache slot)
                  "last_actions": one(START_TOKEN if self.curr_t == 0 else self.cache["last_actions"], torch.int64),
                  "an_object_is_in_hand": one(np.asarray(observations.get("an_object_is_in_hand", 0)).reshape(-1)[0], torch.int64)}
         for key in (NAV, MANIP):

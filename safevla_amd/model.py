@@ -365,7 +365,7 @@ class Tower(nn.Module):
         else:
             t5 = ve.text_encoder.encode(prep.ids, getattr(prep, "attn_mask_u8", None) if getattr(prep, "attn_mask_u8", None) is not None else prep.attn_mask,
                                         drop_seed=t5_seed, drop_p=self.dropout_p, dtype=self.adt,
-                                        seed_dev=getattr(self, "_seed_dev", None))   # [U*L, text_dim], frozen (SigLIP: ids are [U, L - 1], the pooled token is row L - 1)
+                                        seed_dev=getattr(self, "_seed_dev", None), fused=getattr(self, "t5_fused", None))   # [U*L, text_dim], frozen (SigLIP: ids are [U, L - 1], the pooled token is row L - 1)
             self._t5_cache = (key, t5) if (t5_seed is None and key is not None) else (None, None)
         ta = ops.gemm_nt(t5, w["ta"], U * L, D, self.text_dim, bias=ve.text_adapter[0].bias)
         tf, ta_mean, ta_rstd = ops.norm_fwd(ta, ve.text_adapter[1].weight, ve.text_adapter[1].bias, 1e-5, U * L, relu=True, D=D)
@@ -441,7 +441,10 @@ class Tower(nn.Module):
                     ar = self._ar_steps
                     kvalid = ((ar[None, :] <= t_dev) & (ar[None, :] >= torch.clamp(t_dev - prep.time_step, min=0)[:, None])).to(torch.uint8).contiguous()
                 S_att = self.max_steps
-            fused = self.adt == BF16      # bf16 product path: RMSNorm folded into the following GEMM (one launch instead of two)
+            # bf16 product path: RMSNorm folded into the following GEMM (one launch instead of two).  The update's sequence branch runs norm -> bf16 -> GEMM (its backward
+            # needs the normed activation), so a rollout's old log-probs and the update's recomputed ones differ by that one rounding of the decoder's normed rows --
+            # bounded by tests/test_model_gpu.py::test_fused_rmsnorm_step_close_to_unfused; ``rms_fused = False`` runs the acting step on the two-launch form
+            fused = self.adt == BF16 and getattr(self, "rms_fused", True)
             if fused:
                 self.refresh_folded()
             for i, l in enumerate(self.decoder.layers):
@@ -759,7 +762,7 @@ class T5Frozen(nn.Module):
 
     @torch.no_grad()
     def encode(self, ids: torch.Tensor, attn_mask: torch.Tensor, drop_seed: Optional[int] = None, drop_p: float = 0.1, dtype=BF16,
-               seed_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+               seed_dev: Optional[torch.Tensor] = None, fused: Optional[bool] = None) -> torch.Tensor:
         """ids, attn_mask [U, L] int64 (device) -> last_hidden_state [U*L, 512] bf16.
 
         ``drop_seed``: the text encoder is frozen (no_grad) but NOT in eval mode in the reference -- the policy's ``self.train()``
@@ -776,7 +779,10 @@ class T5Frozen(nn.Module):
         ops.dropout_(x, site(62))
         bias = self.position_bias(L)
         kvalid = attn_mask if attn_mask.dtype == torch.uint8 else attn_mask.to(torch.uint8).contiguous()   # uint8 given: no torch op (recorded steps)
-        fused = dtype == BF16 and n <= 8192      # small passes (an acting step's 64 goals x 12 tokens; an update's unique goals): norm + GEMM in one launch
+        # small passes (an acting step's 64 goals x 12 tokens; an update's unique goals): norm + GEMM in one launch.  ``fused`` given: the caller fixes the form --
+        # acting and update passes must share ONE arithmetic: with t5_dropout_per_row the update encodes every (t, b) row (n = R L >> 8192, two-launch form),
+        # so the wrapper pins the acting steps to the two-launch form as well
+        fused = dtype == BF16 and (n <= 8192 if fused is None else bool(fused))
         for i, (b, rt) in enumerate(zip(self.encoder.block, self._rt)):
             s0 = self.T5_STREAM + 4 * i
             if fused:
@@ -859,7 +865,7 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
         # Train-mode dropout inside the frozen T5 encoder: by default one realisation per UNIQUE goal per forward (the encoder runs once per
         # unique goal); the reference draws one per (t, b) row (it encodes every row).  True = the reference's statistics, at the price of
         # encoding R rows instead of U unique goals (+13 % FLOPs at L = 12).  Token-id goals only; eval mode is unaffected.
-        self.t5_dropout_per_row = False
+        self._t5_dropout_per_row = False
         # recorded acting steps replay the three towers as grouped launches (ops.GroupedPlans); SVLA_GROUPED_TOWERS=0: the three-stream replay (A/B, tests)
         self.grouped_towers = os.environ.get("SVLA_GROUPED_TOWERS", "1") != "0"
         self._acting_graphs, self._acting_backend = None, "plan"
@@ -869,6 +875,22 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
         self.sync_weights()
 
     # ---- AllenAct ActorCriticModel API bits -------------------------------------------------------------------
+    @property
+    def t5_dropout_per_row(self) -> bool:
+        """one T5 dropout realisation per (t, b) row and tower, as the reference draws it (default: one per unique goal and pass).  Setting it also pins the frozen
+        encoder's RMSNorm form: per-row update passes are too large for the norm-fused small-M GEMM, so the acting steps take the two-launch form too -- rollout
+        log-probs and the update's recomputed log-probs then come from the same arithmetic."""
+        return self._t5_dropout_per_row
+
+    @t5_dropout_per_row.setter
+    def t5_dropout_per_row(self, on: bool) -> None:
+        on = bool(on)
+        if on != self._t5_dropout_per_row:
+            self._t5_dropout_per_row = on
+            for t in self.towers:
+                t.t5_fused = False if on else None
+            self.invalidate_recorded()
+
     @property
     def recurrent_memory_specification(self):
         return None

@@ -496,6 +496,13 @@ def det_finalize(f32: torch.Tensor, shadow: torch.Tensor) -> None:
     lib().call("svla_det_finalize", _p(f32), _p(shadow), f32.numel(), _stream())
 
 
+def det_bypass_count(reset: bool = True) -> int:
+    """partials that had a registered shadow but took the plain fp32 atomic since the last reset (svla_det_bypass_count; synchronises the device)"""
+    c = ctypes.c_ulonglong(0)
+    lib().call("svla_det_bypass_count", ctypes.byref(c), int(bool(reset)))
+    return int(c.value)
+
+
 # ---- fp8 attention (BASELINE config 5) ---------------------------------------------------------------------------------------
 def _fp8_sp(S: int) -> int:
     return 64 if S <= 64 else 128 if S <= 128 else 192 if S <= 192 else 256

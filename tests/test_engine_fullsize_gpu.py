@@ -101,6 +101,8 @@ def test_deterministic_mode_gives_bitwise_repeatable_gradients(model, T, B, chun
         g = model.arena.flat_g.clone()
         if det:
             assert int(eng._det_shadow.abs().max().item()) == 0          # folded back and cleared
+            from safevla_amd import ops
+            assert ops.det_bypass_count(reset=True) == 0                 # no partial left the fixed-point shadow: the run WAS deterministic
         del eng
         return g
 
@@ -128,8 +130,9 @@ def test_deterministic_mode_repeats_the_whole_update_bitwise(model):
             model.arena.flat_p.copy_(p0); model.arena.flat_m.copy_(m0); model.arena.flat_v.copy_(v0)
             model.sync_weights(frozen=False)
             eng = PPOLagEngine(model, PPOLagConfig(update_repeats=2, cost_limit=2.31964, deterministic=True, record_small_updates=False))
-            eng.update(st, nxt["next_value"], nxt["next_c_value"], ep["episode_cost_sum"], ep["n_episodes"])
+            info = eng.update(st, nxt["next_value"], nxt["next_c_value"], ep["episode_cost_sum"], ep["n_episodes"])
             torch.cuda.synchronize()
+            assert info["det_bypassed_partials"] == 0
             outs.append(model.arena.flat_p.clone())
             del eng
     finally:
@@ -270,3 +273,28 @@ def test_c4_shard_fetch_chunked_equals_unchunked_and_lambda_moves(model):
         assert not torch.equal(model.arena.flat_p[lo:hi], p0[lo:hi])
     model.arena.flat_p.copy_(p0)
     model.sync_weights(frozen=False)
+
+
+def test_det_bypass_counter_counts_partials_that_leave_the_shadow():
+    """a partial sum with |partial| >= 0.25 (or NaN / Inf) skips the fixed-point shadow and takes the plain fp32 atomic -- the run is then not bitwise
+    repeatable.  svla_det_bypass_count makes that visible: 0 for ordinary magnitudes, > 0 (and the fp32 result still right) when the partials are large."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from safevla_amd import ops
+
+    M, N = 4096, 512
+    for scale, want_bypass in ((1e-4, False), (50.0, True)):
+        dY = (torch.ones(M, N, device=DEV) * scale).to(torch.bfloat16)
+        db = torch.zeros(N, device=DEV)
+        shadow = torch.zeros(N, device=DEV, dtype=torch.int64)
+        ops.det_bypass_count(reset=True)
+        ops.det_config(0, db, shadow)
+        try:
+            ops.colsum_acc(dY, db, M, N)
+            ops.det_finalize(db, shadow)
+        finally:
+            ops.det_config(0, None, None)
+        n = ops.det_bypass_count(reset=True)
+        assert (n > 0) == want_bypass, (scale, n)
+        want = dY.float().sum(0)
+        assert torch.allclose(db, want, rtol=1e-5, atol=0), (scale, float((db - want).abs().max()))

@@ -107,7 +107,8 @@ def _three_towers_vs_reference(model, tag, prune_last, grad_probe, SafePPOLogGra
 
     e_l, e_v, e_c = rel(lg, g["logits"]), rel(aco.values.detach().cpu().numpy(), g["values"]), rel(aco.c_values.detach().cpu().numpy(), g["c_values"])
     print(f"[{tag}] rel-to-max err: logits {e_l:.3e} values {e_v:.3e} c_values {e_c:.3e}")
-    assert e_l < 3e-2 and e_v < 3e-2 and e_c < 3e-2
+    # gate = 2x the largest error measured over every kernel-selection variant (4e-3 ... 1.5e-2); VERDICT r5 item 6 (was 3e-2)
+    assert e_l < 2e-2 and e_v < 2e-2 and e_c < 2e-2
     # ---- losses (fused HIP) vs the reference's SafePPOLogGrad scalars
     loss = SafePPOLogGrad(clip_param=0.1, value_loss_coef=0.5, entropy_coef=0.0, use_clipped_value_loss=False,
                           action_loss_schedule=None, discrete_critics=False, normalize_advantage=False)
@@ -127,7 +128,7 @@ def _three_towers_vs_reference(model, tag, prune_last, grad_probe, SafePPOLogGra
         worst.append((abs(nrm - wn) / (wn + 1e-12), abs(prj - wp) / (wn + 1e-12), n))
     worst.sort(reverse=True)
     print(f"[{tag}] worst grad-norm rel errs:", [(f"{a:.2e}", f"{b:.2e}", n) for a, b, n in worst[:5]])
-    bad = [w for w in worst if w[0] > 6e-2 or w[1] > 6e-2]
+    bad = [w for w in worst if w[0] > 4e-2 or w[1] > 4e-2]      # measured <= 3.2e-2; was 6e-2
     assert not bad, bad[:10]
     # exactly the reference's set of parameters receives gradient
     have = {n for n, p in named.items() if p.grad is not None and float(p.grad.abs().sum()) > 0}
@@ -324,3 +325,40 @@ def test_acting_graph_replay_equals_eager_acting(model):
         model.eval()
         for t in model.towers:
             t._kv, t.time_step_counter = None, 0
+
+
+def test_fused_rmsnorm_step_close_to_unfused():
+    """an acting step folds the llama decoder's (and, for small passes, the frozen T5's) RMSNorm into the following GEMM -- RMSNorm(x) W^T = rstd (x (W gamma)^T),
+    no bf16 rounding of the normed row -- while the update's sequence branch runs norm -> bf16 -> GEMM.  Rollout log-probs and the update's recomputed ones therefore
+    differ by that rounding; this pins how much: 12 KV-cached steps at 8 envs with the fold on and off (``rms_fused`` / ``t5_fused``), eval mode, same weights."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle.detfill import fill_state_dict
+    from safevla_amd.model import SafeDinoLLAMATxNavActorCriticSeparate
+    from safevla_amd.synth_env import SynthSpec, fill_synthetic_rollout
+
+    m = SafeDinoLLAMATxNavActorCriticSeparate(device=DEV)
+    fill_state_dict(m, seed=3)
+    m.sync_weights()
+    m.eval()
+    B, n = 8, 12
+    st, _, _ = fill_synthetic_rollout(m, SynthSpec(T=n + 1, B=B, L=12, task="PickUp", seed=9), device=DEV)
+    outs = {}
+    for fused in (True, False):
+        for t in m.towers:
+            t.time_step_counter, t._kv, t.rms_fused, t.t5_fused, t._t5_cache = 0, None, fused, fused, (None, None)
+        m.invalidate_recorded()
+        res = []
+        with torch.no_grad():
+            for t in range(n):
+                o, _ = m({k: v[t:t + 1] for k, v in st.observations.items()}, None, st.prev_actions[t:t + 1], st.masks[t:t + 1])
+                res.append((torch.log_softmax(o.distributions.logits.float(), -1).clone(), o.values.float().clone(), o.c_values.float().clone()))
+        outs[fused] = res
+    for t in m.towers:
+        t.rms_fused, t.t5_fused = True, None
+    d_logp = max(float((a[0] - b[0]).abs().max()) for a, b in zip(outs[True], outs[False]))
+    scale_v = max(float(b[1].abs().max()) for b in outs[False]) + 1e-6
+    d_v = max(float((a[1] - b[1]).abs().max()) for a, b in zip(outs[True], outs[False])) / scale_v
+    print(f"fused vs unfused RMSNorm: max |d log p| {d_logp:.3e}, values rel-to-max {d_v:.3e}")
+    assert d_logp > 0.0                       # the two forms ARE different arithmetic ...
+    assert d_logp < 2e-2 and d_v < 2e-2       # ... one bf16 rounding of the normed rows apart (PPO's ratio clip is 0.1)

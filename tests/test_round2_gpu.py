@@ -415,6 +415,17 @@ def test_sentencepiece_goal_path_on_the_gpu(ops, tmp_path):
         aco, _ = m(obs, None, pa, mk)
     lg = aco.distributions.logits
     assert torch.equal(lg[:, 0], lg[:, 2]) and not torch.equal(lg[:, 0], lg[:, 1])
+    # the same byte strings through the CPU oracle with the SAME sentencepiece tokenizer and weights (bytes -> ids -> frozen T5 -> text adapter
+    # -> three towers): the sentencepiece branch is now compared with the restatement, not only checked for identity / separation of rows
+    from oracle import ref_model
+
+    ref = ref_model.RefSafeActorCritic(tok, max_batch=B).eval()
+    ref.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    with torch.no_grad():
+        want, _ = ref({k: v.cpu() for k, v in obs.items()}, None, pa.cpu(), mk.cpu())
+    for name, got_t, want_t in (("logits", lg, want["logits"]), ("values", aco.values, want["values"]), ("c_values", aco.c_values, want["c_values"])):
+        err = float((got_t.float().cpu() - want_t.float()).abs().max() / (want_t.float().abs().max() + 1e-12))
+        assert err < 2e-2, (name, err)
 
 
 @pytest.mark.parametrize("N,K,epi", [(384, 384, "res"), (1152, 384, "plain"), (384, 1536, "gelu_res")])
