@@ -177,6 +177,18 @@ int svla_attn_bwd_two_pass(int on);
  * *failed_at = the index of the failing call. */
 int svla_replay_calls(int n, const int* fn_ids, const int* arg_offsets, const unsigned long long* args, int* failed_at);
 
+/* ---- inputs of a recorded acting step (round 6) ---------------------------------------------------------------------------------------------
+ * A recorded single-step forward (svla_replay_calls / svla_replay_calls_grouped) reads its observation from static buffers.  svla_acting_stage fills them in ONE launch
+ * from the step's tensors -- the rollout collection of the reference calls the policy once per env step with a fresh observation dict
+ * (training/online/allenact_trainer.py via AllenAct's collect_step; forward at allenact_dino_transformer.py:326-475): DINO tokens (tok_bytes of bf16 [B, 2, 84, C]), previous
+ * actions [B], masks [B], object-in-hand [B], time step [B], goal token ids [B, L] -> their static copies, the T5 padding mask as int64 and uint8 ((id != 0), column 0 always on),
+ * the KV-cache window mask kvalid[b, s] = (s <= t) & (s >= max(t - time_step[b], 0)) for s < max_steps (:388-397), the device-resident step counter t_dev = t, and
+ * seed_k += seed_inc (mod 2^32) for the up to three device-resident dropout seeds (NULL: skipped). */
+int svla_acting_stage(const void* tok_src, void* tok_dst, long tok_bytes, const int64_t* pa_src, int64_t* pa_dst, const float* mask_src, float* mask_dst,
+                      const int64_t* hand_src, int64_t* hand_dst, const int64_t* ts_src, int64_t* ts_dst, const int64_t* ids_src, int64_t* ids_dst, int64_t* am_dst,
+                      unsigned char* am8_dst, unsigned char* kvalid_dst, int64_t* t_dev, int B, int L, int max_steps, int t, int* seed0, int* seed1, int* seed2,
+                      int seed_inc, void* stream);
+
 /* ---- tower-grouped launches (round 6) ---------------------------------------------------------------------------------------------
  * The three towers of the actor-critic (SafeDinoLLAMATxNavActorCriticSeparate: actor, reward critic, cost critic,
  * architecture/models/allenact_transformer_models/separate_actor_critic.py:27-37) run the same kernel sequence on the same shapes with
@@ -216,6 +228,10 @@ int svla_det_finalize(float* f32, long long* i64_shadow, long n, void* stream);
 /* Number of partial sums that had a registered shadow but took the plain fp32 atomic instead (|partial| >= 0.25, NaN, Inf) since the last reset: the run was
  * bitwise repeatable iff 0.  Synchronises the device; the engine reports it as info["det_bypassed_partials"] in deterministic mode. */
 int svla_det_bypass_count(unsigned long long* count, int reset);
+/* Grid of the shadow: 2^-frac_bits, frac_bits in [36, 52] (default 52); partials with |partial| < 2^(50 - frac_bits) enter it, so 8192 of them cannot wrap the int64.
+ * Gradients are 1 / n_total-scaled: the engine lowers frac_bits for small minibatches (52 - ceil(log2(16384 / n_total)), clamped), whose partials are larger -- at 64 rows
+ * the default grid sent thousands of partials >= 0.25 around the shadow.  Change it only while the shadows are empty (between updates). */
+int svla_det_set_grid(int frac_bits);
 
 /* ---- fp8 attention (BASELINE config 5: "fp8 MFMA attention") ---------------------------------------------------------------
  * The unmasked fusion-encoder attention (same reference op as svla_attn_fwd_bf16: nn.MultiheadAttention inside the post-LN

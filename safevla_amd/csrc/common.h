@@ -110,25 +110,26 @@ __device__ __forceinline__ unsigned drop_keep4(const DropCfg& c, unsigned long l
 // same partial sums are added as 64-bit FIXED-POINT integers (2^-52 resolution: the gradients are 1/n_total-scaled, per-workgroup partials
 // of 1e-10 .. 1e-12 are common, and a 2^-40 grid flushed the smallest of them -- ADVICE r3): integer addition is associative, so the
 // result is bitwise repeatable; each partial is rounded once to the 2^-52 grid (relative error < 2^-24 for every partial above 1e-9,
-// absolute 1.1e-16 below), no rounding between the adds.  RANGE: the int64 holds +-2048; a partial enters the shadow only if
-// |partial| < DET_PARTIAL_MAX = 0.25, so a sum of up to 8192 partials (the largest grid that accumulates into one element is norm_bwd's
+// absolute 1.1e-16 below), no rounding between the adds.  RANGE (numbers for the default grid b = 52): the int64 holds +-2048; a partial enters the shadow only if
+// |partial| < max_partial = 0.25, so a sum of up to 8192 partials (the largest grid that accumulates into one element is norm_bwd's
 // 4096 workgroups) cannot wrap.  Larger and non-finite partials -- a diverged backward -- bypass the shadow and go to the fp32 buffer with a
 // plain atomic (not repeatable, but visible as NaN / Inf / a huge gradient instead of a silently wrapped one); the per-block LDS table of
 // decoder_embed_bwd applies the same rule.  svla_det_finalize folds the shadow back into the fp32 buffer.  Up to two registered ranges: the
 // flat gradient buffer, and a scratch range for accumulated intermediates.
-struct DetCfg { float* f32[2]; long long* i64[2]; long n[2]; unsigned long long* bypass; };   // bypass: device counter of partials that had a shadow but left it (svla_det_bypass_count)
+struct DetCfg { float* f32[2]; long long* i64[2]; long n[2]; unsigned long long* bypass; float scale, max_partial; double unscale; };
+// bypass: device counter of partials that had a shadow but left it (svla_det_bypass_count).  scale = 2^b, unscale = 2^-b, max_partial = 2^(50 - b): the grid of the shadow
+// (svla_det_set_grid; b = 52 by default).  8192 partials of magnitude < 2^(50 - b) sum to < 2^63 grid units: the int64 cannot wrap.  The engine lowers b for small
+// minibatches, whose 1 / n_total-scaled partials are larger (64 rows: b = 44, partials up to 64) -- round 6: with the fixed b = 52 a 64-row update sent 5 964 partials >= 0.25
+// around the shadow (tests/test_engine_fullsize_gpu.py found it through the new counter).
 extern DetCfg g_svla_det;                 // host-side current configuration (misc.hip); all-null = plain fp32 atomics
-#define DET_SCALE 4503599627370496.f       // 2^52
-#define DET_UNSCALE 2.220446049250313e-16  // 2^-52
-#define DET_PARTIAL_MAX 0.25f              // see RANGE above
-__device__ __forceinline__ unsigned long long det_fixed(float v) { return (unsigned long long)__float2ll_rn(v * DET_SCALE); }
+__device__ __forceinline__ unsigned long long det_fixed(const DetCfg& d, float v) { return (unsigned long long)__float2ll_rn(v * d.scale); }
 __device__ __forceinline__ void grad_add(const DetCfg& d, float* p, float v) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         if (d.i64[k]) {
             const long off = p - d.f32[k];
             if (off >= 0 && off < d.n[k]) {
-                if (fabsf(v) < DET_PARTIAL_MAX) { atomicAdd((unsigned long long*)(d.i64[k] + off), det_fixed(v)); return; }
+                if (fabsf(v) < d.max_partial) { atomicAdd((unsigned long long*)(d.i64[k] + off), det_fixed(d, v)); return; }
                 // NaN / Inf / out-of-range: the fp32 atomic below (visible, not repeatable) -- and counted, so that a "deterministic" run that was not says so
                 if (d.bypass) atomicAdd(d.bypass, 1ull);
                 break;

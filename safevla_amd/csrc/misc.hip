@@ -156,7 +156,7 @@ __global__ void decoder_embed_bwd_kernel(const bf16_t* __restrict__ dout, const 
     const int nw = (gridDim.x * blockDim.x) >> 6;
     auto add = [&](int idx, float v) {
         if constexpr (DET) {
-            if (fabsf(v) < DET_PARTIAL_MAX) atomicAdd(&tab[idx], det_fixed(v));      // < 8192 rows per block: the table cannot wrap
+            if (fabsf(v) < det.max_partial) atomicAdd(&tab[idx], det_fixed(det, v));      // < 8192 rows per block: the table cannot wrap
             else {      // NaN / Inf / huge: straight to fp32, visible -- and counted (svla_det_bypass_count)
                 atomicAdd(idx < (n_actions + 2) * D ? &d_act_tab[idx] : &d_hand_tab[idx - (n_actions + 2) * D], v);
                 if (det.bypass) atomicAdd(det.bypass, 1ull);
@@ -183,7 +183,7 @@ __global__ void decoder_embed_bwd_kernel(const bf16_t* __restrict__ dout, const 
     __syncthreads();
     for (int i = threadIdx.x; i < nrows_tab * D; i += blockDim.x) {
         float v;
-        if constexpr (DET) v = (float)((double)(long long)tab[i] * DET_UNSCALE); else v = tab[i];
+        if constexpr (DET) v = (float)((double)(long long)tab[i] * det.unscale); else v = tab[i];
         if (v != 0.f) {
             if (i < (n_actions + 2) * D) grad_add(det, &d_act_tab[i], v);
             else grad_add(det, &d_hand_tab[i - (n_actions + 2) * D], v);
@@ -216,7 +216,16 @@ extern "C" int svla_decoder_embed_bwd(const bf16_t* dout, const int64_t* prev_ac
 }
 
 // ---- deterministic accumulation: configuration and fold-back (common.h: DetCfg) -------------------------------------------------
-DetCfg g_svla_det = {{nullptr, nullptr}, {nullptr, nullptr}, {0, 0}, nullptr};
+DetCfg g_svla_det = {{nullptr, nullptr}, {nullptr, nullptr}, {0, 0}, nullptr, 4503599627370496.f, 0.25f, 2.220446049250313e-16};      // grid 2^-52, partials < 2^-2
+// frac_bits in [36, 52]: the shadow's grid becomes 2^-frac_bits and partials up to 2^(50 - frac_bits) enter it (8192 of them cannot wrap the int64).  Call between updates:
+// shadows must be empty (folded back) when the grid changes.
+extern "C" int svla_det_set_grid(int frac_bits) {
+    if (frac_bits < 36 || frac_bits > 52) return SVLA_EINVAL;
+    g_svla_det.scale = ldexpf(1.f, frac_bits);
+    g_svla_det.unscale = ldexp(1.0, -frac_bits);
+    g_svla_det.max_partial = ldexpf(1.f, 50 - frac_bits);
+    return SVLA_OK;
+}
 
 extern "C" int svla_det_config(int slot, float* f32_base, long long* i64_shadow, long n) {
     if (slot < 0 || slot > 1 || n < 0 || ((f32_base == nullptr) != (i64_shadow == nullptr))) return SVLA_EINVAL;
@@ -240,17 +249,17 @@ extern "C" int svla_det_bypass_count(unsigned long long* count, int reset) {
     if (reset) HIP_CHECK_RET(hipMemset(g_svla_det.bypass, 0, sizeof(unsigned long long)));
     return SVLA_OK;
 }
-__global__ void det_finalize_kernel(float* __restrict__ f, long long* __restrict__ s, long n) {
+__global__ void det_finalize_kernel(float* __restrict__ f, long long* __restrict__ s, long n, double unscale) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const long long v = s[i];
-        if (v != 0) { f[i] += (float)((double)v * DET_UNSCALE); s[i] = 0; }
+        if (v != 0) { f[i] += (float)((double)v * unscale); s[i] = 0; }
     }
 }
 extern "C" int svla_det_finalize(float* f32, long long* i64_shadow, long n, void* stream) {
     if (n <= 0 || !f32 || !i64_shadow) return SVLA_EINVAL;
     long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(det_finalize_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, f32, i64_shadow, n);
+    hipLaunchKernelGGL(det_finalize_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, f32, i64_shadow, n, g_svla_det.unscale);
     return svla_launch_status();
 }
 
@@ -708,6 +717,57 @@ extern "C" int svla_kv_append_bf16(const bf16_t* src, long ld_src, bf16_t* cache
     if (B <= 0 || width <= 0 || (width % 8) || (ld_src % 8) || !t_dev) return SVLA_EINVAL;
     int blocks = (B * (width / 8) + 255) / 256; if (blocks > 1024) blocks = 1024;
     SVLA_LAUNCH(kv_append_kernel, kv_append_kernel_body, 1024, 1, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, cache, cache_rows, width, t_dev, B);
+    return svla_launch_status();
+}
+
+// ---- inputs of a recorded acting step -> the static buffers the recorded launches read (include/svla.h: svla_acting_stage) --------------------------
+// One launch instead of ~20 framework copies / compares per env step: blocks [0, nb_tok) copy the DINO tokens (16 bytes per lane), block nb_tok + b stages env b:
+// previous action, mask, object-in-hand, time step, goal ids (+ the T5 padding mask in both formats the kernels read) and row b of the KV-cache window mask
+// kvalid[b, s] = (s <= t) & (s >= max(t - time_step[b], 0))  (allenact_dino_transformer.py:388-397); block nb_tok also writes the step counter and bumps the towers' dropout seeds.
+struct ActingStageArgs {
+    const u32x4* tok_src; u32x4* tok_dst; long n_tok16; int nb_tok;
+    const int64_t* pa_src; int64_t* pa_dst; const float* mask_src; float* mask_dst; const int64_t* hand_src; int64_t* hand_dst;
+    const int64_t* ts_src; int64_t* ts_dst; const int64_t* ids_src; int64_t* ids_dst; int64_t* am_dst; unsigned char* am8_dst;
+    unsigned char* kvalid_dst; int64_t* t_dev; int B, L, max_steps, t; int* seed[3]; int seed_inc;
+};
+__global__ void acting_stage_kernel(ActingStageArgs a) {
+    const int bid = blockIdx.x;
+    if (bid < a.nb_tok) {
+        for (long i = (long)bid * blockDim.x + threadIdx.x; i < a.n_tok16; i += (long)a.nb_tok * blockDim.x) a.tok_dst[i] = a.tok_src[i];
+        return;
+    }
+    const int b = bid - a.nb_tok;
+    const long ts = a.ts_src[b];
+    if (threadIdx.x == 0) {
+        a.pa_dst[b] = a.pa_src[b]; a.mask_dst[b] = a.mask_src[b]; a.hand_dst[b] = a.hand_src[b]; a.ts_dst[b] = ts;
+        if (b == 0) {
+            *a.t_dev = (int64_t)a.t;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) if (a.seed[k]) *a.seed[k] = (int)((unsigned)*a.seed[k] + (unsigned)a.seed_inc);      // wraps in int32 like the framework's add_
+        }
+    }
+    for (int j = threadIdx.x; j < a.L; j += blockDim.x) {
+        const int64_t id = a.ids_src[(long)b * a.L + j];
+        const int on = (id != 0 || j == 0) ? 1 : 0;
+        a.ids_dst[(long)b * a.L + j] = id; a.am_dst[(long)b * a.L + j] = on; a.am8_dst[(long)b * a.L + j] = (unsigned char)on;
+    }
+    const long lo = (long)a.t - ts > 0 ? (long)a.t - ts : 0;
+    for (int s0 = threadIdx.x; s0 < a.max_steps; s0 += blockDim.x) a.kvalid_dst[(long)b * a.max_steps + s0] = (unsigned char)((s0 <= a.t && s0 >= lo) ? 1 : 0);
+}
+extern "C" int svla_acting_stage(const void* tok_src, void* tok_dst, long tok_bytes, const int64_t* pa_src, int64_t* pa_dst, const float* mask_src, float* mask_dst,
+                                 const int64_t* hand_src, int64_t* hand_dst, const int64_t* ts_src, int64_t* ts_dst, const int64_t* ids_src, int64_t* ids_dst,
+                                 int64_t* am_dst, unsigned char* am8_dst, unsigned char* kvalid_dst, int64_t* t_dev, int B, int L, int max_steps, int t,
+                                 int* seed0, int* seed1, int* seed2, int seed_inc, void* stream) {
+    if (B <= 0 || L <= 0 || max_steps <= 0 || t < 0 || tok_bytes <= 0 || (tok_bytes % 16) || ((uintptr_t)tok_src % 16) || ((uintptr_t)tok_dst % 16)) return SVLA_EINVAL;
+    if (!pa_src || !pa_dst || !mask_src || !mask_dst || !hand_src || !hand_dst || !ts_src || !ts_dst || !ids_src || !ids_dst || !am_dst || !am8_dst || !kvalid_dst || !t_dev) return SVLA_EINVAL;
+    ActingStageArgs a;
+    a.tok_src = (const u32x4*)tok_src; a.tok_dst = (u32x4*)tok_dst; a.n_tok16 = tok_bytes / 16;
+    long nb = (a.n_tok16 + 1023) / 1024; if (nb > 512) nb = 512; if (nb < 1) nb = 1;
+    a.nb_tok = (int)nb;
+    a.pa_src = pa_src; a.pa_dst = pa_dst; a.mask_src = mask_src; a.mask_dst = mask_dst; a.hand_src = hand_src; a.hand_dst = hand_dst; a.ts_src = ts_src; a.ts_dst = ts_dst;
+    a.ids_src = ids_src; a.ids_dst = ids_dst; a.am_dst = am_dst; a.am8_dst = am8_dst; a.kvalid_dst = kvalid_dst; a.t_dev = t_dev;
+    a.B = B; a.L = L; a.max_steps = max_steps; a.t = t; a.seed[0] = seed0; a.seed[1] = seed1; a.seed[2] = seed2; a.seed_inc = seed_inc;
+    hipLaunchKernelGGL(acting_stage_kernel, dim3(a.nb_tok + B), dim3(256), 0, (hipStream_t)stream, a);
     return svla_launch_status();
 }
 

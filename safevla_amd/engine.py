@@ -202,6 +202,7 @@ class PPOLagEngine:
             return plan
 
         if cfg.deterministic:
+            ops.det_set_grid(ops.det_grid_bits(n_total))      # (shadows are empty here: every range is folded back at the end of its tower's pass)
             ops.det_config(0, m.arena.flat_g, self._det_shadow)
         try:
             if small:

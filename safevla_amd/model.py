@@ -358,6 +358,7 @@ class Tower(nn.Module):
         x = torch.empty(R, S, D, device=self.device_, dtype=self.adt)
         _, va_mean, va_rstd = ops.norm_fwd(a1, ve.visual_adapter[1].weight, ve.visual_adapter[1].bias, 1e-5, M2, relu=True,
                                            tok=self._camtok, tok_group=NPATCH, y=x, ymap=(2 * NPATCH, S, 1), D=D)
+        ops.plan_mark("text_begin")      # recorded steps: [text_begin, text_end) depends on the goal ids only -- GroupedPlans may issue it on a side stream
         t5_seed = c["drop_seed"] if self.t5_dropout else None
         key = getattr(prep, "ids_key", None)
         if t5_seed is None and key is not None and getattr(self, "_t5_cache", (None, None))[0] == key:
@@ -369,6 +370,7 @@ class Tower(nn.Module):
             self._t5_cache = (key, t5) if (t5_seed is None and key is not None) else (None, None)
         ta = ops.gemm_nt(t5, w["ta"], U * L, D, self.text_dim, bias=ve.text_adapter[0].bias)
         tf, ta_mean, ta_rstd = ops.norm_fwd(ta, ve.text_adapter[1].weight, ve.text_adapter[1].bias, 1e-5, U * L, relu=True, D=D)
+        ops.plan_mark("text_end")
         ops.fusion_fill(ve.fusion_token, tf, prep.gid, x, R, S, L, TEXT_OFF)
         c.update(c1=c1, c2=c2, c1b=c1b, c2b=c2b, a1=a1, va=(va_mean, va_rstd), t5=t5, ta=ta, ta_stats=(ta_mean, ta_rstd))
         xf = x.view(M, D)
@@ -1116,17 +1118,14 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
                 assert versions == tuple(getattr(t, "_kv_version", 0) for t in self.towers)
                 st.plans, st.outs = [r[0] for r in res], [(r[1], r[2]) for r in res]
                 st.gplans = {}
-            elif self.grouped_towers and ops.GroupedPlans.compatible(st.plans):
+                st.grouped_ok = ops.GroupedPlans.compatible(st.plans)
+            elif self.grouped_towers and st.grouped_ok:
                 # tower-grouped replay (round 6): call i of the three recorded sequences is issued as ONE grid whose blockIdx.z picks the tower's
                 # arguments (csrc/launch.h) -- one dependency chain on the current stream instead of three chains on three streams, three times
                 # the workgroups per dispatch.  Same kernels, same arithmetic: bit-identical to the three-stream replay (tests/test_grouped_gpu.py)
-                main = torch.cuda.current_stream()
-                gp = st.gplans.get(main.cuda_stream)
-                if gp is None:
-                    gp = st.gplans[main.cuda_stream] = ops.GroupedPlans(st.plans, main.cuda_stream)
                 for t in self.towers:
                     t._seed_dev_buf.add_(0x3C6EF35)              # fresh dropout noise per step (device-resident seed, wraps in int32)
-                gp.replay()
+                self._grouped_replay(st)
             else:
                 main = torch.cuda.current_stream()
                 for t in self.towers:
@@ -1169,8 +1168,57 @@ class SafeDinoLLAMATxNavActorCriticSeparate(Tower):
             t.time_step_counter += 1
         return st.outs[0][0].clone(), st.outs[1][1].clone(), st.outs[2][1].clone()
 
+    def _grouped_replay(self, st):
+        """the recorded step of the three towers as grouped launches on the current stream; the text path (frozen T5 + text adapter: ~40 small launches that leave
+        most CUs idle) on a side stream next to the visual compressor's chip-filling GEMMs (SVLA_GROUPED_SIDE=0: one chain)"""
+        main = torch.cuda.current_stream()
+        gp = st.gplans.get(main.cuda_stream)
+        if gp is None:
+            side = None
+            if os.environ.get("SVLA_GROUPED_SIDE", "1") != "0":
+                if getattr(self, "_side_stream", None) is None:
+                    self._side_stream = torch.cuda.Stream(device=self.device_)
+                side = self._side_stream.cuda_stream
+            gp = st.gplans[main.cuda_stream] = ops.GroupedPlans(st.plans, main.cuda_stream, side_stream=side)
+        gp.replay(main, getattr(self, "_side_stream", None))
+
+    def _acting_fast(self, observations, prev_actions, masks):
+        """A recorded, tower-grouped step issued straight from the observation dict: ONE staging launch (svla_acting_stage: inputs -> static buffers, T5 padding masks,
+        KV-window mask, step counter, seed bumps) + the grouped replay -- no ``prepare``, none of the ~30 framework copies / compares the general path spends on a
+        step.  Returns None whenever anything is not exactly as the recorded step expects (first step of a shape, other dtypes / layouts, string goals, a cache
+        window about to wrap): the general path then handles -- and, if needed, records -- the step."""
+        if getattr(self, "_acting_graphs", None) is None or self._acting_backend != "plan" or not self.grouped_towers or torch.is_grad_enabled():
+            return None
+        tk, ids = observations.get("dino_tokens"), observations.get("goal_token_ids")
+        if tk is None or ids is None or prev_actions.dim() != 2 or prev_actions.shape[0] != 1:
+            return None
+        B, L, tc = prev_actions.shape[1], ids.shape[-1], self.time_step_counter
+        if not (tc < self.max_steps - 1 and all(t.time_step_counter == tc and getattr(t, "_kv", None) is not None and t._kv[0].shape[0] >= B for t in self.towers)):
+            return None
+        st = self._acting_graphs.get((B, L, self.training, self._acting_backend, tuple(getattr(t, "_kv_version", 0) for t in self.towers)))
+        if st is None or st.plans is None or not getattr(st, "grouped_ok", False):
+            return None
+        u = self.uuids
+        hand, ts = observations.get(u["hand"]), observations.get(u["time"])
+        i64 = torch.int64
+        if hand is None or ts is None or not (tk.dtype == self.adt and tk.is_contiguous() and tk.numel() == st.tokens.numel() and prev_actions.dtype == i64 and prev_actions.is_contiguous()
+                                              and masks.dtype == F32 and masks.is_contiguous() and masks.numel() == B and hand.dtype == i64 and hand.is_contiguous() and hand.numel() == B
+                                              and ts.dtype == i64 and ts.is_contiguous() and ts.numel() == B and ids.dtype == i64 and ids.is_contiguous() and ids.numel() == B * L):
+            return None
+        for t in self.towers:
+            t.refresh_folded()
+        ops.acting_stage(tk, st.tokens, prev_actions, st.prev_actions, masks, st.masks, hand, st.hand, ts, st.time_step, ids, st.ids, st.attn_mask, st.attn_mask_u8,
+                         st.kvalid_static, st.t_dev, B, L, self.max_steps, tc, [t._seed_dev_buf for t in self.towers], 0x3C6EF35)
+        self._grouped_replay(st)
+        for t in self.towers:
+            t.time_step_counter += 1
+        return SafeActorCriticOutput(distributions=CategoricalDistr(st.outs[0][0].clone()), values=st.outs[1][1].clone(), c_values=st.outs[2][1].clone(), extras={})
+
     # ---- reference forward API -------------------------------------------------------------------------------------
     def forward(self, observations, memory, prev_actions, masks):
+        fast = self._acting_fast(observations, prev_actions, masks)
+        if fast is not None:
+            return fast, memory
         prep = self.prepare(observations, prev_actions, masks)
         if (prep.T == 1 and getattr(self, "_acting_graphs", None) is not None and not torch.is_grad_enabled()
                 and self.time_step_counter < self.max_steps - 1 and all(t.time_step_counter == self.time_step_counter for t in self.towers)):

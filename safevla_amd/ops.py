@@ -25,6 +25,7 @@ class LaunchPlan:
 
     def __init__(self):
         self.calls, self.keep = [], []
+        self.marks = {}            # name -> index of the next recorded call (plan_mark): segment boundaries for GroupedPlans' side stream
 
     def __enter__(self):
         global _REC
@@ -83,6 +84,12 @@ class LaunchPlan:
                 raise RuntimeError(f"replayed {fn.__name__} failed with status {rc}")
 
 
+def plan_mark(name: str) -> None:
+    """While a LaunchPlan records: remember the position of the next call under ``name`` (no-op otherwise)."""
+    if _REC is not None:
+        _REC.marks[name] = len(_REC.calls)
+
+
 class GroupedPlans:
     """The recorded single-step sequences of the three towers (same entry points in the same order on the same shapes, different weights and
     buffers) replayed as ONE dependency chain of tower-grouped launches (svla_replay_calls_grouped, include/svla.h: call i of every tower inside
@@ -91,23 +98,31 @@ class GroupedPlans:
     kernel.  Bit-identical to replaying the plans one by one (tests/test_grouped_gpu.py).  ``GroupedPlans.compatible(plans)`` says whether the
     sequences line up (if not -- e.g. towers with different critic heads -- the caller keeps the three-stream replay)."""
 
-    def __init__(self, plans, stream: int):
+    def __init__(self, plans, stream: int, side_stream: Optional[int] = None, side=("text_begin", "text_end")):
+        """``side_stream``: the calls between the marks ``side`` (ops.plan_mark while recording: the frozen text encoder + text adapter of a step, which depend on
+        the goal ids only) are issued on that stream, concurrently with the calls in front of them (the visual compressor, which fills the chip); the caller orders
+        the two streams around ``replay`` (GroupedPlans.replay does it with events when given torch streams)."""
         assert self.compatible(plans)
         L = lib()
         self.plans = list(plans)           # keeps the recorded tensors alive
         ref = plans[0]
+        lo, hi = ref.marks.get(side[0]), ref.marks.get(side[1])
+        if side_stream is None or lo is None or hi is None or not (0 < lo < hi <= len(ref.calls)) or any(pl.marks.get(side[0]) != lo or pl.marks.get(side[1]) != hi for pl in plans):
+            lo = hi = None
+        self.side = (lo, hi)
         ids, offs, words = [], [], [[] for _ in plans]
         for i, (fn, a) in enumerate(ref.calls):
             name = fn.__name__
             decl = L.decls[name]
             ids.append(L.fn_ids[name])
             offs.append(len(words[0]))
+            st_i = side_stream if (lo is not None and lo <= i < hi) else stream
             for m, pl in enumerate(plans):
                 am = pl.calls[i][1]
                 assert len(decl) == len(am), name
                 for (an, ct), v in zip(decl, am):
-                    if an == "stream":     # every launch of the group goes to the one stream the group is replayed on
-                        words[m].append(int(stream) & 0xFFFFFFFFFFFFFFFF)
+                    if an == "stream":     # every launch of the group goes to the one stream its segment is replayed on
+                        words[m].append(int(st_i) & 0xFFFFFFFFFFFFFFFF)
                     elif ct is ctypes.c_float:
                         words[m].append(struct.unpack("<I", struct.pack("<f", float(v)))[0])
                     elif ct is ctypes.c_double:
@@ -118,13 +133,15 @@ class GroupedPlans:
                         words[m].append(int(v.value or 0))
                     else:
                         words[m].append(int(v) & 0xFFFFFFFFFFFFFFFF)
-        self._n, self._members, self._stream = len(ids), len(plans), ctypes.c_void_p(int(stream))
+        self._n, self._members = len(ids), len(plans)
+        self._stream, self._side_stream = ctypes.c_void_p(int(stream)), (ctypes.c_void_p(int(side_stream)) if lo is not None else None)
         self._ids = (ctypes.c_int * max(1, len(ids)))(*ids)
         self._offs = (ctypes.c_int * max(1, len(offs)))(*offs)
         self._words = [(ctypes.c_ulonglong * max(1, len(w)))(*w) for w in words]
         self._argv = (ctypes.POINTER(ctypes.c_ulonglong) * len(plans))(*[ctypes.cast(w, ctypes.POINTER(ctypes.c_ulonglong)) for w in self._words])
         self._failed = ctypes.c_int(-1)
         self._fn = L.cdll.svla_replay_calls_grouped
+        self._ip = ctypes.POINTER(ctypes.c_int)
 
     @staticmethod
     def compatible(plans) -> bool:
@@ -133,10 +150,26 @@ class GroupedPlans:
         names = [[fn.__name__ for fn, _ in pl.calls] for pl in plans]
         return all(n == names[0] for n in names[1:]) and all(len(a) == len(b) for pl in plans[1:] for (_, a), (_, b) in zip(plans[0].calls, pl.calls))
 
-    def replay(self):
-        rc = self._fn(self._n, self._members, self._ids, self._offs, self._argv, self._stream, ctypes.byref(self._failed))
+    def _seg(self, a, b, stream):
+        if b <= a:
+            return
+        ids = ctypes.cast(ctypes.byref(self._ids, 4 * a), self._ip)
+        offs = ctypes.cast(ctypes.byref(self._offs, 4 * a), self._ip)
+        rc = self._fn(b - a, self._members, ids, offs, self._argv, stream, ctypes.byref(self._failed))
         if rc != 0:
-            raise RuntimeError(f"grouped replay of {self.plans[0].calls[self._failed.value][0].__name__} (call {self._failed.value}) failed with status {rc}")
+            raise RuntimeError(f"grouped replay of {self.plans[0].calls[a + self._failed.value][0].__name__} (call {a + self._failed.value}) failed with status {rc}")
+
+    def replay(self, main: Optional["torch.cuda.Stream"] = None, side: Optional["torch.cuda.Stream"] = None):
+        """``main`` / ``side``: the torch streams behind the handles given at construction (needed only with a side segment: they are ordered with events here)."""
+        lo, hi = self.side
+        if lo is None:
+            self._seg(0, self._n, self._stream)
+            return
+        side.wait_stream(main)                    # the side segment reads the staged goal ids
+        self._seg(lo, hi, self._side_stream)      # text encoder + adapter (small kernels, most CUs idle) ...
+        self._seg(0, lo, self._stream)            # ... next to the visual compressor (chip-filling GEMMs)
+        main.wait_stream(side)
+        self._seg(hi, self._n, self._stream)
 
 
 def group_stats():
@@ -496,6 +529,17 @@ def det_finalize(f32: torch.Tensor, shadow: torch.Tensor) -> None:
     lib().call("svla_det_finalize", _p(f32), _p(shadow), f32.numel(), _stream())
 
 
+def det_set_grid(frac_bits: int) -> None:
+    """grid 2^-frac_bits of the deterministic shadows (svla_det_set_grid): partials below 2^(50 - frac_bits) enter them"""
+    lib().call("svla_det_set_grid", int(frac_bits))
+
+
+def det_grid_bits(n_total: int) -> int:
+    """the engine's choice: 52 bits at >= 16 384 global rows, one bit fewer per halving of the minibatch (the partials are 1 / n_total-scaled), at least 36"""
+    import math
+    return max(36, min(52, 52 - max(0, math.ceil(math.log2(16384.0 / max(1, int(n_total)))))))
+
+
 def det_bypass_count(reset: bool = True) -> int:
     """partials that had a registered shadow but took the plain fp32 atomic since the last reset (svla_det_bypass_count; synchronises the device)"""
     c = ctypes.c_ulonglong(0)
@@ -580,6 +624,15 @@ def zeros(*shape, device, dtype):
     t = torch.empty(*shape, device=device, dtype=dtype)
     lib().call("svla_zero_bytes", _p(t), t.numel() * t.element_size(), _stream())
     return t
+
+
+def acting_stage(tok_src, tok_dst, pa_src, pa_dst, mask_src, mask_dst, hand_src, hand_dst, ts_src, ts_dst, ids_src, ids_dst, am_dst, am8_dst, kvalid_dst, t_dev,
+                 B, L, max_steps, t, seeds, seed_inc):
+    """svla_acting_stage: every input of a recorded acting step -> its static buffer, the T5 padding masks, the KV-window mask, the step counter and the seed bumps in ONE launch"""
+    sp = [_p(s_) for s_ in seeds] + [None] * (3 - len(seeds))
+    lib().call("svla_acting_stage", _p(tok_src), _p(tok_dst), tok_src.numel() * tok_src.element_size(), _p(pa_src), _p(pa_dst), _p(mask_src), _p(mask_dst), _p(hand_src), _p(hand_dst),
+               _p(ts_src), _p(ts_dst), _p(ids_src), _p(ids_dst), _p(am_dst), _p(am8_dst), _p(kvalid_dst), _p(t_dev), int(B), int(L), int(max_steps), int(t), sp[0], sp[1], sp[2],
+               int(seed_inc), _stream())
 
 
 def kv_append(src, ld_src, cache, t_dev, B, width):

@@ -171,3 +171,36 @@ def test_acting_steps_grouped_equal_three_stream_replay(train):
             assert torch.equal(a, b), (t, float((a - b).abs().max()))
     for a, b in zip(kvg, kvs):
         assert torch.equal(a, b)
+
+
+def test_acting_stage_kernel_equals_the_framework_staging():
+    """svla_acting_stage (one launch) == what the general path does with ~20 framework ops: static copies of the step's inputs, the T5 padding mask (int64 and uint8, column 0 on),
+    kvalid[b, s] = (s <= t) & (s >= max(t - time_step_b, 0)) (allenact_dino_transformer.py:388-397), the device step counter and the int32-wrapping seed bumps."""
+    _need_gpu()
+    from safevla_amd import ops
+
+    g = torch.Generator(device=DEV).manual_seed(2)
+    B, L, MS = 13, 7, 500
+    for t in (0, 1, 37, 498):
+        tok = torch.randn(B, 2, 84, 384, device=DEV, generator=g).to(BF16)
+        pa = torch.randint(0, 20, (1, B), device=DEV, generator=g)
+        mk = (torch.rand(1, B, 1, device=DEV, generator=g) > 0.2).float()
+        hand = torch.randint(0, 2, (1, B, 1), device=DEV, generator=g)
+        ts = torch.randint(0, 600, (1, B), device=DEV, generator=g)
+        ids = torch.randint(0, 5, (1, B, L), device=DEV, generator=g)
+        d = dict(tok=torch.zeros_like(tok), pa=torch.zeros(B, dtype=torch.int64, device=DEV), mk=torch.zeros(B, device=DEV), hand=torch.zeros(B, dtype=torch.int64, device=DEV),
+                 ts=torch.zeros(B, dtype=torch.int64, device=DEV), ids=torch.zeros(B, L, dtype=torch.int64, device=DEV), am=torch.zeros(B, L, dtype=torch.int64, device=DEV),
+                 am8=torch.zeros(B, L, dtype=torch.uint8, device=DEV), kv=torch.full((B, MS), 7, dtype=torch.uint8, device=DEV), t_dev=torch.zeros((), dtype=torch.int64, device=DEV))
+        seeds = [torch.tensor([v], dtype=torch.int32, device=DEV) for v in (5, 0x7FFFFFF0, -3)]
+        want_seeds = [s_.clone().add_(0x3C6EF35) for s_ in seeds]
+        ops.acting_stage(tok, d["tok"], pa, d["pa"], mk, d["mk"], hand, d["hand"], ts, d["ts"], ids, d["ids"], d["am"], d["am8"], d["kv"], d["t_dev"], B, L, MS, t, seeds, 0x3C6EF35)
+        torch.cuda.synchronize()
+        assert torch.equal(d["tok"], tok) and torch.equal(d["pa"], pa.reshape(B)) and torch.equal(d["mk"], mk.reshape(B)) and torch.equal(d["hand"], hand.reshape(B))
+        assert torch.equal(d["ts"], ts.reshape(B)) and torch.equal(d["ids"], ids.reshape(B, L)) and int(d["t_dev"]) == t
+        am = (ids.reshape(B, L) != 0).to(torch.int64); am[:, 0] = 1
+        assert torch.equal(d["am"], am) and torch.equal(d["am8"], am.to(torch.uint8))
+        ar = torch.arange(MS, device=DEV)
+        kv = ((ar[None, :] <= t) & (ar[None, :] >= torch.clamp(t - ts.reshape(B), min=0)[:, None])).to(torch.uint8)
+        assert torch.equal(d["kv"], kv)
+        for a, b in zip(seeds, want_seeds):
+            assert torch.equal(a, b)
