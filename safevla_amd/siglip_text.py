@@ -77,9 +77,9 @@ class SigLIPTextFrozen(nn.Module):
         self._rt = rt
 
     @torch.no_grad()
-    def encode(self, ids: torch.Tensor, attn_mask=None, drop_seed=None, drop_p: float = 0.0, dtype=BF16, seed_dev=None) -> torch.Tensor:
+    def encode(self, ids: torch.Tensor, attn_mask=None, drop_seed=None, drop_p: float = 0.0, dtype=BF16, seed_dev=None, fused=None) -> torch.Tensor:
         """ids [U, L] int64 (device; L <= context, normally the tokenizer's 64) -> ``cat([tokens, pooled])`` as rows [U * out_tokens(L), width].
-        ``attn_mask`` / dropout arguments are those of ``T5Frozen.encode`` and are unused: the tower has neither."""
+        ``attn_mask`` / dropout / ``fused`` arguments are those of ``T5Frozen.encode`` and are unused: the tower has neither padding, dropout nor RMSNorms."""
         if self._rt is None:
             self.sync()
         rt, W, H = self._rt, self.width, self.heads

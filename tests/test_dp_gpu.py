@@ -102,8 +102,13 @@ def test_bench_eight_ranks_strong_scaling_fetch_plumbing(variant):
     cmd += (["--global-envs", "250", "--task", "Fetch"] if variant == "c4_fetch" else
             ["--global-envs", "256", "--task", "Mixed", "--L", "64", "--fp8-attention", "--grad-allreduce-bf16", "--t5-dropout-per-row"])
     n_envs = 250 if variant == "c4_fetch" else 256
+    torch.cuda.empty_cache()          # eight more processes are about to share this GPU with whatever this process has cached
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stderr[-3000:]
+    if r.returncode != 0:             # eight ranks initialising HIP / gloo on ONE GPU at once is not what the code under test is about: one retry, the first error kept
+        first = r.stderr[-1500:]
+        cmd[cmd.index("--master-port") + 1] = str(_free_port())
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, "first attempt:\n" + first + "\nsecond attempt:\n" + r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["scaling"] == "strong"
     assert out["scaling_measured"] is False          # eight gloo ranks on one GPU are plumbing, not a point of a scaling curve
