@@ -25,7 +25,6 @@ class LaunchPlan:
 
     def __init__(self):
         self.calls, self.keep = [], []
-        self.marks = {}            # name -> index of the next recorded call (plan_mark): segment boundaries for GroupedPlans' side stream
 
     def __enter__(self):
         global _REC
@@ -84,12 +83,6 @@ class LaunchPlan:
                 raise RuntimeError(f"replayed {fn.__name__} failed with status {rc}")
 
 
-def plan_mark(name: str) -> None:
-    """While a LaunchPlan records: remember the position of the next call under ``name`` (no-op otherwise)."""
-    if _REC is not None:
-        _REC.marks[name] = len(_REC.calls)
-
-
 class GroupedPlans:
     """The recorded single-step sequences of the three towers (same entry points in the same order on the same shapes, different weights and
     buffers) replayed as ONE dependency chain of tower-grouped launches (svla_replay_calls_grouped, include/svla.h: call i of every tower inside
@@ -98,31 +91,23 @@ class GroupedPlans:
     kernel.  Bit-identical to replaying the plans one by one (tests/test_grouped_gpu.py).  ``GroupedPlans.compatible(plans)`` says whether the
     sequences line up (if not -- e.g. towers with different critic heads -- the caller keeps the three-stream replay)."""
 
-    def __init__(self, plans, stream: int, side_stream: Optional[int] = None, side=("text_begin", "text_end")):
-        """``side_stream``: the calls between the marks ``side`` (ops.plan_mark while recording: the frozen text encoder + text adapter of a step, which depend on
-        the goal ids only) are issued on that stream, concurrently with the calls in front of them (the visual compressor, which fills the chip); the caller orders
-        the two streams around ``replay`` (GroupedPlans.replay does it with events when given torch streams)."""
+    def __init__(self, plans, stream: int):
         assert self.compatible(plans)
         L = lib()
         self.plans = list(plans)           # keeps the recorded tensors alive
         ref = plans[0]
-        lo, hi = ref.marks.get(side[0]), ref.marks.get(side[1])
-        if side_stream is None or lo is None or hi is None or not (0 < lo < hi <= len(ref.calls)) or any(pl.marks.get(side[0]) != lo or pl.marks.get(side[1]) != hi for pl in plans):
-            lo = hi = None
-        self.side = (lo, hi)
         ids, offs, words = [], [], [[] for _ in plans]
         for i, (fn, a) in enumerate(ref.calls):
             name = fn.__name__
             decl = L.decls[name]
             ids.append(L.fn_ids[name])
             offs.append(len(words[0]))
-            st_i = side_stream if (lo is not None and lo <= i < hi) else stream
             for m, pl in enumerate(plans):
                 am = pl.calls[i][1]
                 assert len(decl) == len(am), name
                 for (an, ct), v in zip(decl, am):
-                    if an == "stream":     # every launch of the group goes to the one stream its segment is replayed on
-                        words[m].append(int(st_i) & 0xFFFFFFFFFFFFFFFF)
+                    if an == "stream":     # every launch of the group goes to the one stream the group is replayed on
+                        words[m].append(int(stream) & 0xFFFFFFFFFFFFFFFF)
                     elif ct is ctypes.c_float:
                         words[m].append(struct.unpack("<I", struct.pack("<f", float(v)))[0])
                     elif ct is ctypes.c_double:
@@ -134,14 +119,13 @@ class GroupedPlans:
                     else:
                         words[m].append(int(v) & 0xFFFFFFFFFFFFFFFF)
         self._n, self._members = len(ids), len(plans)
-        self._stream, self._side_stream = ctypes.c_void_p(int(stream)), (ctypes.c_void_p(int(side_stream)) if lo is not None else None)
+        self._stream = ctypes.c_void_p(int(stream))
         self._ids = (ctypes.c_int * max(1, len(ids)))(*ids)
         self._offs = (ctypes.c_int * max(1, len(offs)))(*offs)
         self._words = [(ctypes.c_ulonglong * max(1, len(w)))(*w) for w in words]
         self._argv = (ctypes.POINTER(ctypes.c_ulonglong) * len(plans))(*[ctypes.cast(w, ctypes.POINTER(ctypes.c_ulonglong)) for w in self._words])
         self._failed = ctypes.c_int(-1)
         self._fn = L.cdll.svla_replay_calls_grouped
-        self._ip = ctypes.POINTER(ctypes.c_int)
 
     @staticmethod
     def compatible(plans) -> bool:
@@ -150,26 +134,10 @@ class GroupedPlans:
         names = [[fn.__name__ for fn, _ in pl.calls] for pl in plans]
         return all(n == names[0] for n in names[1:]) and all(len(a) == len(b) for pl in plans[1:] for (_, a), (_, b) in zip(plans[0].calls, pl.calls))
 
-    def _seg(self, a, b, stream):
-        if b <= a:
-            return
-        ids = ctypes.cast(ctypes.byref(self._ids, 4 * a), self._ip)
-        offs = ctypes.cast(ctypes.byref(self._offs, 4 * a), self._ip)
-        rc = self._fn(b - a, self._members, ids, offs, self._argv, stream, ctypes.byref(self._failed))
+    def replay(self):
+        rc = self._fn(self._n, self._members, self._ids, self._offs, self._argv, self._stream, ctypes.byref(self._failed))
         if rc != 0:
-            raise RuntimeError(f"grouped replay of {self.plans[0].calls[a + self._failed.value][0].__name__} (call {a + self._failed.value}) failed with status {rc}")
-
-    def replay(self, main: Optional["torch.cuda.Stream"] = None, side: Optional["torch.cuda.Stream"] = None):
-        """``main`` / ``side``: the torch streams behind the handles given at construction (needed only with a side segment: they are ordered with events here)."""
-        lo, hi = self.side
-        if lo is None:
-            self._seg(0, self._n, self._stream)
-            return
-        side.wait_stream(main)                    # the side segment reads the staged goal ids
-        self._seg(lo, hi, self._side_stream)      # text encoder + adapter (small kernels, most CUs idle) ...
-        self._seg(0, lo, self._stream)            # ... next to the visual compressor (chip-filling GEMMs)
-        main.wait_stream(side)
-        self._seg(hi, self._n, self._stream)
+            raise RuntimeError(f"grouped replay of {self.plans[0].calls[self._failed.value][0].__name__} (call {self._failed.value}) failed with status {rc}")
 
 
 def group_stats():
