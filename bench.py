@@ -120,6 +120,12 @@ def acting_bench(model, st, B, dev, n=24):
         return r
 
     pol_eager, pol_plan, pol = policy_rate(None), policy_rate("plan"), policy_rate("hipgraph")
+    grouped = bool(getattr(model, "grouped_towers", False))
+    model.grouped_towers = False            # the same recorded step replayed as three call lists on three streams (the pre-round-6 acting path): A/B of the tower-grouped launches
+    model.invalidate_recorded()
+    pol_plan_3s = policy_rate("plan")
+    model.grouped_towers = grouped
+    model.invalidate_recorded()
     model.enable_acting_plans(True)         # back to the default acting path
     vit = DinoViTPreprocessor("rgb_raw", "rgb_dinov2", device=dev)
     fr = torch.randint(0, 256, (2 * B, 224, 384, 3), device=dev, dtype=torch.uint8)
@@ -131,12 +137,15 @@ def acting_bench(model, st, B, dev, n=24):
     torch.cuda.synchronize()
     fps = 3 * 2 * B / (time.perf_counter() - t0)
     best = max(pol, pol_eager, pol_plan)
-    return {"policy_single_step_env_steps_per_s": round(pol_plan, 1), "policy_single_step_eager_env_steps_per_s": round(pol_eager, 1),
+    return {"policy_single_step_env_steps_per_s": round(pol_plan, 1), "policy_single_step_three_streams_env_steps_per_s": round(pol_plan_3s, 1),
+            "policy_single_step_ms": round(1e3 * B / pol_plan, 3), "tower_grouped_launches": grouped,
+            "policy_single_step_eager_env_steps_per_s": round(pol_eager, 1),
             "policy_single_step_hipgraph_env_steps_per_s": round(pol, 1),
             "vit_frames_per_s": round(fps, 1),
             "acting_env_steps_per_s": round(1.0 / (1.0 / best + 2.0 / fps), 1), "envs": B,
             "note": "per env step: 2 frames (224x384) through DINOv2 ViT-S/14 + one KV-cached 3-tower step; eager = one Python-issued launch "
-                    "per kernel, hipgraph = the same step captured once and replayed (model.enable_acting_graphs); synthetic frames"}
+                    "per kernel, hipgraph = the same step captured once and replayed (model.enable_acting_graphs); policy_single_step = the recorded step of the three towers replayed as "
+                    "tower-grouped launches (one grid per kernel, blockIdx.z = tower: csrc/launch.h) behind one staging launch, three_streams = the same recorded step as three call lists on three streams; synthetic frames"}
 
 
 def north_star_probe(model, dev, rows_T=32, rows_B=8, L=64):

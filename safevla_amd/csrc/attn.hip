@@ -263,8 +263,7 @@ __device__ __forceinline__ void attn_fwd_kernel_body(AttnArgs p) {
         if (p.LSE && g == 0 && q < Sq) p.LSE[((size_t)r * p.H + h) * Sq + q] = (mx + __log2f(lsum)) * LN2;   // natural-log LSE
     }
 }
-template <int NKT, bool GENERIC, int NW = 4, bool EXACT = false>
-__global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs p) { attn_fwd_kernel_body<NKT, GENERIC, NW, EXACT>(p); }
+// (no same-named __global__: every launch goes through the grouped form, a single launch being a group of one -- SVLA_LAUNCH_TWIN, csrc/launch.h)
 
 // item -> (row, head) with every XCD walking whole rows: item i is processed on XCD i % 8 (workgroup b on XCD b % 8; the persistent forward's grid is a multiple of 8),
 // so items 8 j + x, j = 8 g .. 8 g + 7, become the eight heads of row 8 g + x: the eight 128-byte head slices of a token's line group go through ONE L2
@@ -442,8 +441,7 @@ __device__ __forceinline__ void attn_fwd_persist_kernel_body(AttnArgs p, int nit
         }
     }
 }
-template <int NKT>
-__global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_persist_kernel(AttnArgs p, int nitems) { attn_fwd_persist_kernel_body<NKT>(p, nitems); }
+// (launched as svla_grouped<&attn_fwd_persist_kernel_body<NKT>, ATT_THREADS, 2>: SVLA_LAUNCH_TWIN)
 
 // ================================================================================================ backward
 // Two kernels, each with only two [S,64] operands resident in LDS (2 workgroups per CU):
@@ -1199,12 +1197,6 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 12 ? 3 : 2) attn_bwd_fused
 template <int NKT>
 static int launch_fwd(const AttnArgs& p, int rows, hipStream_t st) {
     const size_t lds = (size_t)2 * NKT * 16 * LDSROW * sizeof(bf16_t) + NKT * 16 * (sizeof(int) + 1);
-    static bool attr = false;
-    if (!attr) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
     const bool generic = p.mask_mode != MASK_NONE || p.bias || p.kvalid;
     // persistent forward: S in (160, 192] (fusion encoder with short goals, S = 181) and S in (224, 256] (64-token instructions, S = 233)
     if constexpr (NKT == 12 || NKT == 16) {
@@ -1215,45 +1207,26 @@ static int launch_fwd(const AttnArgs& p, int rows, hipStream_t st) {
                 int dev = 0, n_cu = 0;
                 HIP_CHECK_RET(hipGetDevice(&dev));
                 HIP_CHECK_RET(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-                HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_persist_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
                 slots = 2 * n_cu;              // 2 workgroups per CU
             }
             const int nitems = rows * p.H;
             // (a tower group shares the two-workgroups-per-CU budget: the grouped launch carries one third of the slots per member)
             const int gslots = (slots / svla_group_size()) & ~7;
-            SVLA_LAUNCH((attn_fwd_persist_kernel<NKT>), (attn_fwd_persist_kernel_body<NKT>), ATT_THREADS, 2, dim3(nitems < gslots ? nitems : gslots), dim3(ATT_THREADS), ldsp, st, p, nitems);
-            return svla_launch_status();
+            return SVLA_LAUNCH_TWIN((attn_fwd_persist_kernel_body<NKT>), ATT_THREADS, 2, dim3(nitems < gslots ? nitems : gslots), dim3(ATT_THREADS), ldsp, st, p, nitems);
         }
     }
     if constexpr (NKT == 18) {           // S in (256, 288]: the ViT on 224 x 224 frames (16 x 16 patches + class token = 257): two workgroups per CU, exact tiles
-        if (!generic && p.S > (NKT - 2) * 16 && p.Sq == p.S) {
-            static bool attr18 = false;
-            if (!attr18) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT, false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr18 = true; }
-            hipLaunchKernelGGL((attn_fwd_kernel<NKT, false, 4, true>), dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
-            return svla_launch_status();
-        }
+        if (!generic && p.S > (NKT - 2) * 16 && p.Sq == p.S)
+            return SVLA_LAUNCH_TWIN((attn_fwd_kernel_body<NKT, false, 4, true>), ATT_THREADS, 1, dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
     }
     if constexpr (NKT >= 28) {           // one workgroup per CU (K + V > 80 KiB): eight waves share the LDS image
         if (!generic) {
-            static bool attr8 = false;
-            if (!attr8) {
-                HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT, false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr8 = true;
-            }
-            if (p.S > (NKT - 2) * 16 && p.Sq == p.S) hipLaunchKernelGGL((attn_fwd_kernel<NKT, false, 8, true>), dim3(rows * p.H), dim3(512), lds, st, p);      // the ViT's 433 tokens
-            else hipLaunchKernelGGL((attn_fwd_kernel<NKT, false, 8>), dim3(rows * p.H), dim3(512), lds, st, p);
-            return svla_launch_status();
+            if (p.S > (NKT - 2) * 16 && p.Sq == p.S) return SVLA_LAUNCH_TWIN((attn_fwd_kernel_body<NKT, false, 8, true>), 512, 1, dim3(rows * p.H), dim3(512), lds, st, p);      // the ViT's 433 tokens
+            return SVLA_LAUNCH_TWIN((attn_fwd_kernel_body<NKT, false, 8>), 512, 1, dim3(rows * p.H), dim3(512), lds, st, p);
         }
     }
-    if constexpr (NKT <= 16) {      // the shapes of an acting step / small update (T5's 12 ... 64 tokens, the decoder's block-causal windows, the pruned layer): tower-groupable
-        if (generic) SVLA_LAUNCH((attn_fwd_kernel<NKT, true>), (attn_fwd_kernel_body<NKT, true>), ATT_THREADS, 1, dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
-        else SVLA_LAUNCH((attn_fwd_kernel<NKT, false>), (attn_fwd_kernel_body<NKT, false>), ATT_THREADS, 1, dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
-        return svla_launch_status();
-    }
-    if (generic) hipLaunchKernelGGL((attn_fwd_kernel<NKT, true>), dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
-    else hipLaunchKernelGGL((attn_fwd_kernel<NKT, false>), dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
-    return svla_launch_status();
+    if (generic) return SVLA_LAUNCH_TWIN((attn_fwd_kernel_body<NKT, true>), ATT_THREADS, 1, dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
+    return SVLA_LAUNCH_TWIN((attn_fwd_kernel_body<NKT, false>), ATT_THREADS, 1, dim3(rows * p.H), dim3(ATT_THREADS), lds, st, p);
 }
 static int g_attn_no_decode = 0;      // svla_attn_bwd_two_pass(4): single-query forwards on the tile kernels (A/B, tests)
 static int g_attn_bwd_two_pass = 0;   // svla_attn_bwd_two_pass(1): the dQ + dK/dV kernel pair instead of the single-pass kernel (A/B, tests)

@@ -62,11 +62,37 @@ struct GroupCapture {
 GroupCapture* svla_group_capture();    // misc.hip: this thread's open capture, or nullptr
 int svla_group_size();                 // members of the open capture (1: none) -- dispatchers size persistent grids / choose kernels for the GROUP's work
 
+// issue n >= 1 members' argument blocks as ONE grid of the grouped twin (grid.z = n)
+template <auto Body, int MAXT, int MINB, typename... Ts>
+inline int svla_twin_launch(const DeferredLaunch* const* m, int n, hipStream_t s) {
+    using Pack = ArgPack<Ts...>;
+    GroupedArgs<Pack> g;
+    for (int i = 0; i < SVLA_MAXG; ++i) memcpy((void*)&g.a[i], m[i < n ? i : 0]->args, sizeof(Pack));
+    static unsigned attr_smem = 0;      // dynamic LDS this twin has been cleared for (the single-launch kernels set theirs at their launch sites)
+    if (m[0]->smem > attr_smem) {
+        const hipError_t e = hipFuncSetAttribute((const void*)svla_grouped<Body, MAXT, MINB, Ts...>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m[0]->smem);
+        if (e != hipSuccess) return (int)e;
+        attr_smem = m[0]->smem;
+    }
+    dim3 grid = m[0]->grid;
+    grid.z = (unsigned)n;
+    hipLaunchKernelGGL((svla_grouped<Body, MAXT, MINB, Ts...>), grid, m[0]->block, m[0]->smem, s, g);
+    return (int)hipGetLastError();
+}
+template <typename... Ts> inline void svla_defer_fill(DeferredLaunch& d, int (*flush)(const DeferredLaunch* const*, int, hipStream_t), dim3 grid, dim3 block, size_t smem,
+                                                      hipStream_t s, const Ts&... a) {
+    static_assert(sizeof(ArgPack<Ts...>) <= SVLA_DEFER_ARG_BYTES, "deferred argument block too small");
+    d.flush = flush;
+    d.grid = grid; d.block = block; d.smem = (unsigned)smem; d.stream = s;
+    const ArgPack<Ts...> p = pack_make<Ts...>(a...);
+    memcpy(d.args, (const void*)&p, sizeof(p));
+}
+
+// A kernel with a same-named single-launch __global__ (Kern) and a grouped twin generated from its body
 template <auto Kern, auto Body, int MAXT, int MINB> struct Launch;
 template <typename... Ts, void (*Kern)(Ts...), void (*Body)(Ts...), int MAXT, int MINB>
 struct Launch<Kern, Body, MAXT, MINB> {
     using Pack = ArgPack<Ts...>;
-    static_assert(sizeof(Pack) <= SVLA_DEFER_ARG_BYTES, "deferred argument block too small");
     template <size_t... I>
     static void single(const DeferredLaunch& d, hipStream_t s, std::index_sequence<I...>) {
         Pack p;
@@ -78,38 +104,42 @@ struct Launch<Kern, Body, MAXT, MINB> {
             single(*m[0], s, std::index_sequence_for<Ts...>{});
             return (int)hipGetLastError();
         }
-        GroupedArgs<Pack> g;
-        for (int i = 0; i < SVLA_MAXG; ++i) memcpy((void*)&g.a[i], m[i < n ? i : 0]->args, sizeof(Pack));
-        static unsigned attr_smem = 0;      // dynamic LDS this twin has been cleared for (the single-launch kernels set theirs at their launch sites)
-        if (m[0]->smem > attr_smem) {
-            const hipError_t e = hipFuncSetAttribute((const void*)svla_grouped<Body, MAXT, MINB, Ts...>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m[0]->smem);
-            if (e != hipSuccess) return (int)e;
-            attr_smem = m[0]->smem;
-        }
-        dim3 grid = m[0]->grid;
-        grid.z = (unsigned)n;
-        hipLaunchKernelGGL((svla_grouped<Body, MAXT, MINB, Ts...>), grid, m[0]->block, m[0]->smem, s, g);
-        return (int)hipGetLastError();
+        return svla_twin_launch<Body, MAXT, MINB, Ts...>(m, n, s);
     }
     static void go(dim3 grid, dim3 block, size_t smem, hipStream_t s, Ts... a) {
         GroupCapture* gc = svla_group_capture();
-        if (!gc) {
+        if (!gc || gc->n[gc->member] >= SVLA_MAXQ) {      // (no call issues SVLA_MAXQ launches; if one ever does, it is launched at once and the capture is marked)
+            if (gc) gc->overflow = 1;
             hipLaunchKernelGGL(Kern, grid, block, smem, s, a...);
             return;
         }
-        const int mb = gc->member;
-        if (gc->n[mb] >= SVLA_MAXQ) {      // (no call issues that many launches; if one ever does, it is launched at once and the capture is marked)
-            gc->overflow = 1;
-            hipLaunchKernelGGL(Kern, grid, block, smem, s, a...);
-            return;
+        svla_defer_fill<Ts...>(gc->q[gc->member][gc->n[gc->member]], &flush, grid, block, smem, s, a...);
+        gc->n[gc->member] += 1;
+    }
+};
+// A kernel that exists ONLY as the grouped form: a single launch is a group of one (grid.z = 1).  For the attention forward kernels: their bodies inlined into a
+// plain same-named __global__ compiled worse than the original kernels did (attn_fwd_persist_kernel<12>: 109 spilled VGPRs against 6, 2.99 -> 5.97 ms per launch
+// in the update -- caught by an A/B against the round-5 tree on one box), while the same body inside svla_grouped<> compiles like the original
+template <auto Body, int MAXT, int MINB> struct LaunchTwin;
+template <typename... Ts, void (*Body)(Ts...), int MAXT, int MINB>
+struct LaunchTwin<Body, MAXT, MINB> {
+    static int flush(const DeferredLaunch* const* m, int n, hipStream_t s) { return svla_twin_launch<Body, MAXT, MINB, Ts...>(m, n, s); }
+    static int go(dim3 grid, dim3 block, size_t smem, hipStream_t s, Ts... a) {
+        GroupCapture* gc = svla_group_capture();
+        if (!gc || gc->n[gc->member] >= SVLA_MAXQ) {
+            if (gc) gc->overflow = 1;
+            DeferredLaunch d;
+            svla_defer_fill<Ts...>(d, &flush, grid, block, smem, s, a...);
+            const DeferredLaunch* one = &d;
+            return flush(&one, 1, s);
         }
-        DeferredLaunch& d = gc->q[mb][gc->n[mb]++];
-        d.flush = &flush;
-        d.grid = grid; d.block = block; d.smem = (unsigned)smem; d.stream = s;
-        const Pack p = pack_make<Ts...>(a...);
-        memcpy(d.args, (const void*)&p, sizeof(Pack));
+        svla_defer_fill<Ts...>(gc->q[gc->member][gc->n[gc->member]], &flush, grid, block, smem, s, a...);
+        gc->n[gc->member] += 1;
+        return 0;
     }
 };
 // kern / body may be template-ids with commas: pass them in parentheses
 #define SVLA_LAUNCH(kern, body, maxt, minb, grid, block, smem, stream, ...) \
     Launch<&kern, &body, maxt, minb>::go(grid, block, smem, stream, __VA_ARGS__)
+#define SVLA_LAUNCH_TWIN(body, maxt, minb, grid, block, smem, stream, ...) \
+    LaunchTwin<&body, maxt, minb>::go(grid, block, smem, stream, __VA_ARGS__)
