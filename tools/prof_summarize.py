@@ -10,7 +10,10 @@ def stats(db, out, title):
     rows = cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc limit 45").fetchall()
     tot = sum(r[2] for r in cur.execute("select name,total_calls,total_duration from top_kernels"))
     o = [f"# {title}", "# columns: kernel | calls | total_ms | avg_ms | pct", f"# total kernel time {tot/1e3:.1f} ms"]
+    import re
     for n, c, t, a, p in rows:
+        # kernels that exist only in the tower-grouped form (csrc/launch.h): _Z12svla_groupedITnDaXadL_Z<len><body name>I<template args>... -> "svla_grouped<body name ...>"
+        n = re.sub(r"^_Z12svla_groupedITnDaXadL_Z\d+", "svla_grouped<", n)
         o.append(f"{n[:90]:90s} | {c:6d} | {t/1e3:10.2f} | {a/1e3:9.4f} | {p:6.2f}")
     open(out, "w").write("\n".join(o) + "\n")
     print("\n".join(o[:14]))
