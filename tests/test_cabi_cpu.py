@@ -56,3 +56,24 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 s = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", s, flags=re.M), f
+
+
+def test_launch_group_capture_protocol_without_a_gpu(built_lib):
+    """svla_group_begin / _member / _end / _stats (tower-grouped launches, csrc/launch.h) are host logic: the protocol -- one capture per thread, members in range,
+    an empty capture issues nothing -- holds without a GPU; so do the argument checks of svla_det_set_grid and svla_acting_stage (refused before any launch)."""
+    cdll = ctypes.CDLL(built_lib)
+    assert cdll.svla_group_end(None) != 0                                 # nothing open
+    assert cdll.svla_group_begin(0) != 0 and cdll.svla_group_begin(4) != 0
+    assert cdll.svla_group_begin(3) == 0
+    assert cdll.svla_group_begin(3) != 0                                  # captures do not nest
+    assert cdll.svla_group_member(3) != 0 and cdll.svla_group_member(-1) != 0 and cdll.svla_group_member(2) == 0
+    assert cdll.svla_group_end(None) == 0                                 # empty capture
+    g, s = ctypes.c_long(-1), ctypes.c_long(-1)
+    assert cdll.svla_group_stats(ctypes.byref(g), ctypes.byref(s)) == 0 and (g.value, s.value) == (0, 0)
+    assert cdll.svla_det_set_grid(35) != 0 and cdll.svla_det_set_grid(53) != 0 and cdll.svla_det_set_grid(44) == 0 and cdll.svla_det_set_grid(52) == 0
+    cdll.svla_acting_stage.restype = ctypes.c_int
+    null = ctypes.c_void_p(0)
+    args = [null, null, ctypes.c_long(0)] + [null] * 14 + [ctypes.c_int(0)] * 4 + [null] * 3 + [ctypes.c_int(0), null]
+    assert cdll.svla_acting_stage(*args) != 0                             # B = 0 / null buffers: invalid, nothing launched
+    from safevla_amd import ops
+    assert [ops.det_grid_bits(n) for n in (64, 4096, 16384, 10 ** 6)] == [44, 50, 52, 52]
