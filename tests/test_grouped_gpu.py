@@ -204,3 +204,49 @@ def test_acting_stage_kernel_equals_the_framework_staging():
         assert torch.equal(d["kv"], kv)
         for a, b in zip(seeds, want_seeds):
             assert torch.equal(a, b)
+
+
+def test_grouped_launches_random_shapes_and_flavours():
+    """40 random (M, N, K, epilogue, group size 2 / 3) GEMMs and norms: a capture's result equals the single launches bit for bit whatever kernel the dispatcher picks
+    (128-tile, persistent 256-tile, assembly with a 128-tile row tail), and nothing is left in a capture afterwards."""
+    _need_gpu()
+    from safevla_amd import ops
+
+    rs = np.random.RandomState(2026)
+    g = torch.Generator(device=DEV).manual_seed(99)
+    for case in range(40):
+        members = int(rs.choice([2, 3]))
+        M = int(rs.choice([1, 17, 64, 200, 768, 1500, 4096, 11584, 20000]))
+        N = int(rs.choice([128, 256, 512, 1024, 1536, 2048]))
+        K = int(rs.choice([384, 512, 1024, 2048]))
+        flav = rs.choice(["plain", "relu", "res", "res_drop", "relu_drop", "f32"])
+        A = [torch.randn(M, K, device=DEV, generator=g).to(BF16) for _ in range(members)]
+        W = [(torch.randn(N, K, device=DEV, generator=g) * 0.05).to(BF16) for _ in range(members)]
+        b = [torch.randn(N, device=DEV, generator=g) for _ in range(members)]
+        R = [torch.randn(M, N, device=DEV, generator=g).to(BF16) for _ in range(members)]
+
+        def call(m):
+            kw = {}
+            if "relu" in flav: kw["act"] = ops.ACT_RELU
+            if "res" in flav: kw["residual"] = R[m]
+            if "drop" in flav: kw["drop"] = ops.Dropout(77 + m + case, 2, 0.1)
+            if flav == "f32": kw["out_f32"] = True
+            return ops.gemm_nt(A[m], W[m], M, N, K, bias=b[m], **kw)
+
+        want = [call(m) for m in range(members)]
+        ops.group_stats()
+        got = _grouped(call, members)
+        torch.cuda.synchronize()
+        for m in range(members):
+            assert torch.equal(got[m], want[m]), (case, M, N, K, flav, members, m)
+        if M >= 8 and N == 512:
+            x = [t.clone() for t in got] if flav != "f32" else [t.to(BF16) for t in got]
+            gam = [torch.rand(512, device=DEV, generator=g) + 0.5 for _ in range(members)]
+            nf = lambda m: ops.norm_fwd(x[m], gam[m], b[m], 1e-5, M, D=512)[0]
+            wn = [nf(m) for m in range(members)]
+            gn = _grouped(nf, members)
+            torch.cuda.synchronize()
+            for m in range(members):
+                assert torch.equal(gn[m], wn[m]), (case, "norm", M)
+    from safevla_amd import _lib
+    assert _lib.lib().cdll.svla_group_end(None) != 0          # no capture left open
